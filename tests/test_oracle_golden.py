@@ -1,0 +1,69 @@
+"""The oracle (oracle/rvdd_oracle.py) against the fixtures that
+tools/make_golden.py captured from the reference itself.  CPU only.
+
+Tolerances: the Hamilton-Adams restatement must be bit-exact (hard sign()
+selections); everything else is fp32 re-association noise, bounded here by
+max-abs 2e-5 on O(1) data (observed <= 4e-6)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import rvdd_oracle as O
+from conftest import GOLDEN, VARIANTS, load_weights
+
+
+def _npz(name):
+    return {k: torch.from_numpy(v) for k, v in np.load(os.path.join(GOLDEN, name)).items()}
+
+
+def test_hamilton_adams_bit_exact():
+    g = _npz("op_hamilton_adams.npz")
+    rgb = O.hamilton_adams(g["raw"])
+    assert rgb.shape == g["rgb"].shape
+    assert torch.equal(rgb, g["rgb"])
+    assert torch.equal(O.remosaick(rgb[:, :3]), g["remosaick"])
+
+
+def test_warp_bicubic():
+    g = _npz("op_warp_bicubic.npz")
+    assert (O.warp(g["x"], g["flow"]) - g["y"]).abs().max() < 1e-6
+    # the explicit 16-tap statement the HIP kernel follows
+    assert (O.warp_explicit(g["x"], g["flow"]) - g["y"]).abs().max() < 2e-5
+
+
+def test_upsample_flow():
+    g = _npz("op_upsample_flow.npz")
+    assert torch.equal(O.upsample_factor_2(g["flow"], 2), g["up"])
+    assert (O.upsample_factor_2_explicit(g["flow"], 2) - g["up"]).abs().max() < 1e-5
+
+
+@pytest.mark.parametrize("name", sorted(VARIANTS))
+def test_net_forward(name):
+    stem, fut, _ = VARIANTS[name]
+    sd = load_weights(stem)
+    g = _npz(f"net_{name}.npz")
+    for tag in ("20x28", "16x24"):
+        fin = g.get(f"feat_in_{tag}")
+        out, f = O.net_forward(sd, g[f"x_{tag}"], fin)
+        assert (out - g[f"out_{tag}"]).abs().max() < 2e-5
+        if fin is not None:
+            assert (f - g[f"feat_out_{tag}"]).abs().max() < 2e-5
+
+
+@pytest.mark.parametrize("name", sorted(VARIANTS))
+def test_sequence(name):
+    stem, fut, _ = VARIANTS[name]
+    sd = load_weights(stem)
+    g = _npz(f"seq_{name}.npz")
+    orc = O.RecurrentOracle(sd, future=fut)
+    outs = orc.run_sequence(g["raw"], g["flow_prev"], g["flow_next"])
+    assert outs.shape == g["denoised"].shape
+    assert (outs - g["denoised"]).abs().max() < 2e-5
+    if "feat_last" in g:
+        assert (orc.lastfeat[0] - g["feat_last"]).abs().max() < 2e-5
+    for i in range(outs.shape[0]):
+        gt = g["gt"][i + 1][None]
+        assert abs(O.psnr(outs[i][None], gt) - float(g["PSNR"][i])) < 1e-3
+        assert abs(O.l1_loss(outs[i][None], gt) - float(g["L1"][i])) < 1e-4
