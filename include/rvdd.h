@@ -1,0 +1,152 @@
+/*
+ * rvdd.h -- C ABI of librvdd_hip.so, the MI355X (gfx950) runtime for the
+ * recurrent video denoise+demosaic inference path of centreborelli/RVDD-release.
+ *
+ * The reference has no FFI on this path: the path sits behind two string-keyed
+ * Python plugin registries (models/__init__.py:25-45 `--model recurrent`,
+ * networks/__init__.py:121-176 `--netDenoiser ...`).  This header is what a
+ * binding for that plugin surface binds (the ctypes stub is in INTEGRATION.md
+ * and rvdd-release_amd/runtime.py).  Conventions mirror the reference's only
+ * real FFI, library.CPPbridge (library.py:143-175): plain pointers and sizes,
+ * caller-allocated buffers, no exceptions across the boundary.
+ *
+ *  - every function returns 0 on success or a negative rvdd_status;
+ *    rvdd_last_error() gives the message (per handle; NULL -> last create error);
+ *  - all tensor pointers are DEVICE pointers to dense fp32 tensors in the
+ *    reference's own layout (NCHW), owned by the caller (e.g. obtained from
+ *    torch.Tensor.data_ptr() on PyTorch-ROCm);
+ *  - `stream` is a hipStream_t passed as void* (NULL = the default stream);
+ *    calls are asynchronous and stream-ordered unless stated otherwise;
+ *  - a handle owns its weights, workspace and the recurrent state; one handle
+ *    = one device; a handle is not thread-safe, distinct handles are.
+ */
+#ifndef RVDD_H
+#define RVDD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rvdd_handle rvdd_t;
+
+enum rvdd_status {
+    RVDD_OK = 0,
+    RVDD_ERR_ARG = -1,      /* bad argument / shape */
+    RVDD_ERR_STATE = -2,    /* call sequence violated (e.g. step before weights) */
+    RVDD_ERR_WEIGHT = -3,   /* unknown / missing / mis-shaped state_dict key */
+    RVDD_ERR_HIP = -4,      /* HIP runtime error */
+    RVDD_ERR_NOMEM = -5
+};
+
+/* netDenoiser families (networks/__init__.py:121-176). */
+enum rvdd_arch {
+    RVDD_ARCH_CONVUNET = 0,       /* convunet-mode=fixedfeatures       networks/unet.py:595-720 */
+    RVDD_ARCH_CONVUNET_FEAT = 1,  /* convunet-mode=fixedfeatures+feat  networks/unet.py:725-825 */
+    RVDD_ARCH_CONVNEXT = 2,       /* newunet                           networks/new_unet.py:207-362 */
+    RVDD_ARCH_CONVNEXT_FEAT = 3   /* newunet-mode=feat                 networks/new_unet.py:365-430 */
+};
+
+typedef struct rvdd_cfg {
+    int32_t arch;     /* enum rvdd_arch */
+    int32_t future;   /* --future_patch_depth: 0 or 1 (options/base_options.py:56) */
+    int32_t batch;    /* B sequences advanced in lockstep */
+    int32_t height;   /* RGB frame height H (even); raw frames are 4 x H/2 x W/2 */
+    int32_t width;    /* RGB frame width  W (even) */
+    int32_t device;   /* HIP device ordinal */
+} rvdd_cfg;
+
+/* ---- life cycle ---------------------------------------------------------- */
+
+/* Replaces recurrentModel.__init__ + networks.define_net_arch
+ * (models/recurrent_model.py:38-99, networks/__init__.py:121-176). */
+int rvdd_create(const rvdd_cfg* cfg, rvdd_t** out);
+void rvdd_destroy(rvdd_t* h);
+const char* rvdd_last_error(const rvdd_t* h);
+
+/* Replaces BaseModel.load_networks -> net.load_state_dict
+ * (models/base_model.py:173-196).  `host` points to HOST fp32 data of one
+ * state_dict entry in PyTorch layout (conv weight = OIHW).  Unlike the
+ * reference (strict=False) loading is strict: an unknown key fails here, a
+ * missing one fails in rvdd_finalize_weights. */
+int rvdd_set_weight(rvdd_t* h, const char* key, const float* host, const int64_t* shape, int32_t ndim);
+int rvdd_finalize_weights(rvdd_t* h);
+
+/* ---- the recurrent hot path ---------------------------------------------- */
+
+/* FirstOfVideo (validate.py:76-77 -> recurrent_model.py:115,233-245): the next
+ * rvdd_step re-initialises lastden from raw_prev and zeroes the features. */
+int rvdd_reset(rvdd_t* h);
+
+/* One output frame for each of the B sequences: recurrentModel.set_input +
+ * forward, test branch (models/recurrent_model.py:105-135, 161-349):
+ * Hamilton-Adams demosaic, flow x2 upsample, bicubic backward warp of the
+ * previous output / features / next frame, U-Net forward, state hand-over.
+ *   raw_prev, raw_cur, raw_next : [B,4,H/2,W/2] packed GBRG raw in [-1,1]
+ *                                 (raw_prev is read only on the first step after
+ *                                  create/reset; raw_next only when future=1)
+ *   flow_prev : [B,2,H/2,W/2] raw-resolution flow cur->prev (x first)
+ *   flow_next : [B,2,H/2,W/2] raw-resolution flow cur->next (future=1)
+ *   out_rgb   : [B,3,H,W] denoised linear RGB
+ */
+int rvdd_step(rvdd_t* h, const float* raw_prev, const float* raw_cur, const float* raw_next,
+              const float* flow_prev, const float* flow_next, float* out_rgb, void* stream);
+
+/* Recurrent state in the reference's layout, for get_current_features /
+ * set_rec_features parity (networks/unet.py:814-818) and for tests.
+ *   lastden  [B,3,H,W]; lastfeat [B,48,H,W] (NULL to skip either). */
+int rvdd_get_state(rvdd_t* h, float* lastden, float* lastfeat, void* stream);
+int rvdd_set_state(rvdd_t* h, const float* lastden, const float* lastfeat, void* stream);
+
+/* compute_losses, test branch (models/recurrent_model.py:512-525;
+ * util/util.py:9-20): out2 (HOST, 2 floats) = { 100*mean|den-gt|,
+ * 10*log10(4/mean((den-gt)^2)) } over `count` elements.  Synchronises
+ * `stream` (the reference reads the losses back with float(), base_model.py:151). */
+int rvdd_psnr_l1(rvdd_t* h, const float* den, const float* gt, int64_t count, float* out2, void* stream);
+
+/* ---- the same ops one at a time (plugin-level entry points; also test hooks) */
+
+/* netDenoise(x) (networks/unet.py:544-588 / networks/new_unet.py:332-362).
+ *   x [B,Cin,H,W] with Cin = 3*(2+future); feat_in/feat_out [B,48,H,W] for the
+ *   *_FEAT archs (NULL otherwise); out [B,3,H,W]. */
+int rvdd_unet_forward(rvdd_t* h, const float* x, const float* feat_in, float* out, float* feat_out,
+                      void* stream);
+
+/* HamiltonAdam('gbrg').forward (util/Hamilton_Adam_demo.py:249-289):
+ *   raw [n,4,h,w] -> rgb [n,3,2h,2w]. */
+int rvdd_demosaic_ha(rvdd_t* h, const float* raw, int32_t n, int32_t hh, int32_t ww, float* rgb,
+                     void* stream);
+
+/* util.flow_utils.warp(x, flow, "bicubic")[0] (util/flow_utils.py:70-102):
+ *   x [n,c,H,W], flow [n,2,H,W] at full resolution -> y [n,c,H,W]. */
+int rvdd_warp_bicubic(rvdd_t* h, const float* x, const float* flow, int32_t n, int32_t c, int32_t H,
+                      int32_t W, float* y, void* stream);
+
+/* util.flow_utils.upsample_factor_2(t, multiply_by) (util/flow_utils.py:159-174):
+ *   t [n,c,hh,ww] -> [n,c,2hh,2ww]. */
+int rvdd_upsample_factor_2(rvdd_t* h, const float* t, int32_t n, int32_t c, int32_t hh, int32_t ww,
+                           float multiply_by, float* out, void* stream);
+
+/* ---- measurement ----------------------------------------------------------- */
+
+/* When enabled, every launch of the U-Net kernels is bracketed by HIP events
+ * on the launch stream.  rvdd_profile_read synchronises, accumulates and
+ * returns, for kernel class `idx` (0..rvdd_profile_count()-1): its name, the
+ * number of launches, the summed duration (ms) and the summed algorithmic
+ * FLOPs and bytes since the last rvdd_profile_enable(h, 1). */
+int rvdd_profile_enable(rvdd_t* h, int32_t on);
+int rvdd_profile_count(const rvdd_t* h);
+int rvdd_profile_read(rvdd_t* h, int32_t idx, char* name, int32_t name_cap, int64_t* launches,
+                      double* total_ms, double* flops, double* bytes);
+
+/* HIP-event stopwatch on `stream` (bench.py times the whole step loop with it). */
+int rvdd_timer_start(rvdd_t* h, void* stream);
+int rvdd_timer_stop_ms(rvdd_t* h, void* stream, float* ms);   /* synchronises */
+
+const char* rvdd_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RVDD_H */

@@ -1,0 +1,529 @@
+// HBM-bound stages around the U-Net: Hamilton-Adams demosaic, bicubic backward
+// warp with the x2 flow upsample fused, map reshaping (bilinear x2, max-pool,
+// NCHW<->NHWC), the final 1x1 conv and the loss reduction.
+// This translation unit is compiled with -ffp-contract=off: the demosaic has
+// hard sign() selections (util/Hamilton_Adam_demo.py:138-139,168-169) and the
+// warp round-trips its coordinates through the [-1,1] normalisation in fp32
+// (util/flow_utils.py:93-94), so the arithmetic is kept operation for
+// operation as the reference's ATen ops evaluate it.
+#include "rvdd_internal.h"
+
+namespace {
+
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+__device__ __forceinline__ float signf(float v) { return (float)((v > 0.f) - (v < 0.f)); }
+
+// ------------------------------------------------------------------ demosaic --
+// CFA of the packed GBRG frame (util/Hamilton_Adam_demo.py:226-234), replicate
+// padded: coordinates are clamped BEFORE the lookup.
+struct Cfa {
+    const float* raw;  // [4][h][w] of one frame
+    int h, w, H, W;
+    __device__ __forceinline__ float at(int y, int x) const {
+        y = clampi(y, 0, H - 1);
+        x = clampi(x, 0, W - 1);
+        return raw[((size_t)(((y & 1) << 1) | (x & 1)) * h + (y >> 1)) * w + (x >> 1)];
+    }
+    // sparse colour plane `site` (0 = G(e,e), 1 = B(e,o), 2 = R(o,e), 3 = G(o,o)), replicate padded
+    __device__ __forceinline__ float plane(int y, int x, int site) const {
+        y = clampi(y, 0, H - 1);
+        x = clampi(x, 0, W - 1);
+        const int s = ((y & 1) << 1) | (x & 1);
+        return s == site ? raw[((size_t)s * h + (y >> 1)) * w + (x >> 1)] : 0.f;
+    }
+};
+
+// algo1 (util/Hamilton_Adam_demo.py:123-142)
+__global__ void ha_green_kernel(const float* __restrict__ raw, float* __restrict__ green, int n, int h,
+                                int w) {
+    const int H = 2 * h, W = 2 * w;
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)n * H * W) return;
+    const int x = idx % W;
+    const int y = (idx / W) % H;
+    const int b = idx / ((size_t)W * H);
+    Cfa c{raw + (size_t)b * 4 * h * w, h, w, H, W};
+    const float cc = c.at(y, x);
+    float gval;
+    if (((y ^ x) & 1) == 0) {
+        gval = cc;  // measured green
+    } else {
+        const float l1 = c.at(y, x - 1), r1 = c.at(y, x + 1), l2 = c.at(y, x - 2), r2 = c.at(y, x + 2);
+        const float u1 = c.at(y - 1, x), d1 = c.at(y + 1, x), u2 = c.at(y - 2, x), d2 = c.at(y + 2, x);
+        const float Kh = 0.5f * l1 + 0.5f * r1;
+        const float Kv = 0.5f * u1 + 0.5f * d1;
+        const float Dh = (l2 + (-2.f) * cc) + r2;
+        const float Dv = (u2 + (-2.f) * cc) + d2;
+        const float Fh = l1 + (-1.f) * r1;
+        const float Fv = u1 + (-1.f) * d1;
+        const float rawh = Kh - Dh / 4.f;
+        const float rawv = Kv - Dv / 4.f;
+        const float CLh = fabsf(Fh) + fabsf(Dh);
+        const float CLv = fabsf(Fv) + fabsf(Dv);
+        const float sg = signf(CLh - CLv);
+        gval = (1.f + sg) * rawv / 2.f + (1.f - sg) * rawh / 2.f;
+    }
+    green[idx] = gval;
+}
+
+// algo2 (util/Hamilton_Adam_demo.py:145-172) for red (mode 1) and blue (mode 2)
+__global__ void ha_rb_kernel(const float* __restrict__ raw, const float* __restrict__ green,
+                             float* __restrict__ out, int n, int h, int w, int64_t bstride, int pstride,
+                             int cstride) {
+    const int H = 2 * h, W = 2 * w;
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)n * H * W) return;
+    const int x = idx % W;
+    const int y = (idx / W) % H;
+    const int b = idx / ((size_t)W * H);
+    Cfa c{raw + (size_t)b * 4 * h * w, h, w, H, W};
+    const float* gp = green + (size_t)b * H * W;
+    auto G = [&](int yy, int xx) { return gp[(size_t)clampi(yy, 0, H - 1) * W + clampi(xx, 0, W - 1)]; };
+    const int site = ((y & 1) << 1) | (x & 1);   // 0 Gb(e,e) 1 B 2 R 3 Gr(o,o)
+    const float g0 = G(y, x);
+
+    float rb[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int own = k == 0 ? 2 : 1;          // the channel's own CFA site (R / B)
+        const int hsite = k == 0 ? 3 : 0;        // sites with horizontal neighbours of the channel
+        const int vsite = k == 0 ? 0 : 3;        // sites with vertical neighbours
+        float v;
+        if (site == own) {
+            v = c.at(y, x);
+        } else if (site == hsite) {
+            const float Kh = 0.5f * c.plane(y, x - 1, own) + 0.5f * c.plane(y, x + 1, own);
+            const float gD = (0.25f * G(y, x - 1) + (-0.5f) * g0) + 0.25f * G(y, x + 1);
+            v = Kh - gD;
+        } else if (site == vsite) {
+            const float Kv = 0.5f * c.plane(y - 1, x, own) + 0.5f * c.plane(y + 1, x, own);
+            const float gD = (0.25f * G(y - 1, x) + (-0.5f) * g0) + 0.25f * G(y + 1, x);
+            v = Kv - gD;
+        } else {  // mask_ochan site (B sites for red, R sites for blue): diagonal, hard selection
+            const float a = c.plane(y - 1, x - 1, own), d = c.plane(y + 1, x + 1, own);
+            const float bq = c.plane(y - 1, x + 1, own), cq = c.plane(y + 1, x - 1, own);
+            const float Kp = 0.5f * a + 0.5f * d;
+            const float Kn = 0.5f * bq + 0.5f * cq;
+            const float Fp = (-1.f) * a + d;
+            const float Fn = (-1.f) * bq + cq;
+            const float gDp = (G(y - 1, x - 1) + (-2.f) * g0) + G(y + 1, x + 1);
+            const float gDn = (G(y - 1, x + 1) + (-2.f) * g0) + G(y + 1, x - 1);
+            const float Cp = Kp - gDp / 4.f;
+            const float Cn = Kn - gDn / 4.f;
+            const float CLp = fabsf(Fp) + fabsf(gDp);
+            const float CLn = fabsf(Fn) + fabsf(gDn);
+            const float sl = signf(CLp - CLn);
+            v = (1.f + sl) * Cn / 2.f + (1.f - sl) * Cp / 2.f;
+        }
+        rb[k] = v;
+    }
+    float* o = out + (size_t)b * bstride + ((size_t)y * W + x) * pstride;
+    o[0] = rb[0];
+    o[cstride] = g0;
+    o[2 * (size_t)cstride] = rb[1];
+}
+
+// ---------------------------------------------------------------------- warp --
+// Cubic-convolution weights, A = -0.75 (ATen UpSample.h get_cubic_upsample_coefficients).
+__device__ __forceinline__ void cubic_w(float t, float w[4]) {
+    const float A = -0.75f;
+    float x = t + 1.f;
+    w[0] = ((A * x - 5.f * A) * x + 8.f * A) * x - 4.f * A;
+    x = t;
+    w[1] = ((A + 2.f) * x - (A + 3.f)) * x * x + 1.f;
+    x = 1.f - t;
+    w[2] = ((A + 2.f) * x - (A + 3.f)) * x * x + 1.f;
+    x = 2.f - t;
+    w[3] = ((A * x - 5.f * A) * x + 8.f * A) * x - 4.f * A;
+}
+
+// full-resolution flow at (y,x) from the raw-resolution one:
+// F.interpolate(x2, bilinear, align_corners=True) * 2  (util/flow_utils.py:159-174,
+// models/recurrent_model.py:128-129)
+__device__ __forceinline__ void flow_at(const float* __restrict__ fr, int h, int w, int H, int W, int y,
+                                        int x, float& fx, float& fy) {
+    const float sy = H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.f;
+    const float sx = W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.f;
+    const float py = sy * (float)y, px = sx * (float)x;
+    const int y0 = (int)py, x0 = (int)px;
+    const int y1 = y0 + (y0 < h - 1 ? 1 : 0), x1 = x0 + (x0 < w - 1 ? 1 : 0);
+    const float ly1 = py - (float)y0, lx1 = px - (float)x0;
+    const float ly0 = 1.f - ly1, lx0 = 1.f - lx1;
+    const float* f0 = fr;
+    const float* f1 = fr + (size_t)h * w;
+    fx = (ly0 * (lx0 * f0[y0 * w + x0] + lx1 * f0[y0 * w + x1]) +
+          ly1 * (lx0 * f0[y1 * w + x0] + lx1 * f0[y1 * w + x1])) * 2.f;
+    fy = (ly0 * (lx0 * f1[y0 * w + x0] + lx1 * f1[y0 * w + x1]) +
+          ly1 * (lx0 * f1[y1 * w + x0] + lx1 * f1[y1 * w + x1])) * 2.f;
+}
+
+// util/flow_utils.py:90-99 + ATen grid_sampler (bicubic, border, align_corners=True)
+struct Taps {
+    int xi[4], yi[4];
+    float wx[4], wy[4];
+};
+__device__ __forceinline__ void make_taps(float fx, float fy, int x, int y, int H, int W, Taps& t) {
+    const float vx = (float)x + fx, vy = (float)y + fy;
+    const float gx = 2.0f * vx / (float)(W - 1) - 1.0f;
+    const float gy = 2.0f * vy / (float)(H - 1) - 1.0f;
+    const float ix = ((gx + 1.f) / 2.f) * (float)(W - 1);
+    const float iy = ((gy + 1.f) / 2.f) * (float)(H - 1);
+    const float x0 = floorf(ix), y0 = floorf(iy);
+    cubic_w(ix - x0, t.wx);
+    cubic_w(iy - y0, t.wy);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        // clip_coordinates on the float tap coordinate, then the integer cast
+        float cx = x0 - 1.f + (float)i, cy = y0 - 1.f + (float)i;
+        cx = fminf((float)(W - 1), fmaxf(cx, 0.f));
+        cy = fminf((float)(H - 1), fmaxf(cy, 0.f));
+        t.xi[i] = (int)cx;
+        t.yi[i] = (int)cy;
+    }
+}
+
+__global__ void warp3_kernel(const float* __restrict__ src4, const float* __restrict__ flow_raw,
+                             float* __restrict__ dst, int dpstride, int B, int H, int W) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)B * H * W) return;
+    const int x = idx % W;
+    const int y = (idx / W) % H;
+    const int b = idx / ((size_t)W * H);
+    const int h = H / 2, w = W / 2;
+    float fx, fy;
+    flow_at(flow_raw + (size_t)b * 2 * h * w, h, w, H, W, y, x, fx, fy);
+    Taps t;
+    make_taps(fx, fy, x, y, H, W, t);
+    const f32x4* s = reinterpret_cast<const f32x4*>(src4) + (size_t)b * H * W;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        f32x4 row = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) row = row + s[(size_t)t.yi[j] * W + t.xi[i]] * t.wx[i];
+        acc = acc + row * t.wy[j];
+    }
+    float* o = dst + idx * dpstride;
+    o[0] = acc[0];
+    o[1] = acc[1];
+    o[2] = acc[2];
+}
+
+// 12 threads per pixel, one float4 (4 channels) each
+__global__ void warp48_kernel(const float* __restrict__ src, const float* __restrict__ flow_raw,
+                              float* __restrict__ dst, int B, int H, int W) {
+    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t pix = gid / 12;
+    const int c4 = gid - pix * 12;
+    if (pix >= (size_t)B * H * W) return;
+    const int x = pix % W;
+    const int y = (pix / W) % H;
+    const int b = pix / ((size_t)W * H);
+    const int h = H / 2, w = W / 2;
+    float fx, fy;
+    flow_at(flow_raw + (size_t)b * 2 * h * w, h, w, H, W, y, x, fx, fy);
+    Taps t;
+    make_taps(fx, fy, x, y, H, W, t);
+    const f32x4* s = reinterpret_cast<const f32x4*>(src) + (size_t)b * H * W * 12 + c4;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        f32x4 row = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) row = row + s[((size_t)t.yi[j] * W + t.xi[i]) * 12] * t.wx[i];
+        acc = acc + row * t.wy[j];
+    }
+    reinterpret_cast<f32x4*>(dst)[gid] = acc;
+}
+
+__global__ void warp_nchw_kernel(const float* __restrict__ xin, const float* __restrict__ flow,
+                                 float* __restrict__ yout, int n, int c, int H, int W) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)n * H * W) return;
+    const int x = idx % W;
+    const int y = (idx / W) % H;
+    const int b = idx / ((size_t)W * H);
+    const size_t hw = (size_t)H * W;
+    const float fx = flow[((size_t)b * 2 + 0) * hw + (size_t)y * W + x];
+    const float fy = flow[((size_t)b * 2 + 1) * hw + (size_t)y * W + x];
+    Taps t;
+    make_taps(fx, fy, x, y, H, W, t);
+    for (int ch = 0; ch < c; ++ch) {
+        const float* s = xin + ((size_t)b * c + ch) * hw;
+        float acc = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float row = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) row = row + s[(size_t)t.yi[j] * W + t.xi[i]] * t.wx[i];
+            acc = acc + row * t.wy[j];
+        }
+        yout[((size_t)b * c + ch) * hw + (size_t)y * W + x] = acc;
+    }
+}
+
+__global__ void upsample_flow_kernel(const float* __restrict__ t, float* __restrict__ out, int nc, int h,
+                                     int w, float mul) {
+    const int H = 2 * h, W = 2 * w;
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)nc * H * W) return;
+    const int x = idx % W;
+    const int y = (idx / W) % H;
+    const int p = idx / ((size_t)W * H);
+    const float sy = H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.f;
+    const float sx = W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.f;
+    const float py = sy * (float)y, px = sx * (float)x;
+    const int y0 = (int)py, x0 = (int)px;
+    const int y1 = y0 + (y0 < h - 1 ? 1 : 0), x1 = x0 + (x0 < w - 1 ? 1 : 0);
+    const float ly1 = py - (float)y0, lx1 = px - (float)x0;
+    const float ly0 = 1.f - ly1, lx0 = 1.f - lx1;
+    const float* f = t + (size_t)p * h * w;
+    out[idx] = (ly0 * (lx0 * f[y0 * w + x0] + lx1 * f[y0 * w + x1]) +
+                ly1 * (lx0 * f[y1 * w + x0] + lx1 * f[y1 * w + x1])) * mul;
+}
+
+// ------------------------------------------------------------ map reshaping --
+// nn.Upsample(scale_factor=2, mode="bilinear"[, align_corners]) on NHWC48,
+// 12 threads per output pixel.  ATen upsample_bilinear2d source index:
+//   align_corners=False: src = max(0.5*(dst+0.5)-0.5, 0);  True: src = dst*(in-1)/(out-1)
+__global__ void upsample2x_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int h,
+                                  int w, int Hout, int Wout, int oy, int ox, int align) {
+    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t pix = gid / 12;
+    const int c4 = gid - pix * 12;
+    if (pix >= (size_t)B * Hout * Wout) return;
+    const int X = pix % Wout;
+    const int Y = (pix / Wout) % Hout;
+    const int b = pix / ((size_t)Wout * Hout);
+    const int y = Y - oy, x = X - ox;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if ((unsigned)y < (unsigned)(2 * h) && (unsigned)x < (unsigned)(2 * w)) {
+        float py, px;
+        if (align) {
+            const float sy = 2 * h > 1 ? (float)(h - 1) / (float)(2 * h - 1) : 0.f;
+            const float sx = 2 * w > 1 ? (float)(w - 1) / (float)(2 * w - 1) : 0.f;
+            py = sy * (float)y;
+            px = sx * (float)x;
+        } else {
+            py = fmaxf(0.5f * ((float)y + 0.5f) - 0.5f, 0.f);
+            px = fmaxf(0.5f * ((float)x + 0.5f) - 0.5f, 0.f);
+        }
+        const int y0 = (int)py, x0 = (int)px;
+        const int y1 = y0 + (y0 < h - 1 ? 1 : 0), x1 = x0 + (x0 < w - 1 ? 1 : 0);
+        const float ly1 = py - (float)y0, lx1 = px - (float)x0;
+        const float ly0 = 1.f - ly1, lx0 = 1.f - lx1;
+        const f32x4* s = reinterpret_cast<const f32x4*>(in) + (size_t)b * h * w * 12 + c4;
+        const f32x4 v00 = s[((size_t)y0 * w + x0) * 12], v01 = s[((size_t)y0 * w + x1) * 12];
+        const f32x4 v10 = s[((size_t)y1 * w + x0) * 12], v11 = s[((size_t)y1 * w + x1) * 12];
+        v = (v00 * lx0 + v01 * lx1) * ly0 + (v10 * lx0 + v11 * lx1) * ly1;
+    }
+    reinterpret_cast<f32x4*>(out)[gid] = v;
+}
+
+__global__ void maxpool2_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int H,
+                                int W) {
+    const int Ho = H / 2, Wo = W / 2;
+    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t pix = gid / 12;
+    const int c4 = gid - pix * 12;
+    if (pix >= (size_t)B * Ho * Wo) return;
+    const int x = pix % Wo;
+    const int y = (pix / Wo) % Ho;
+    const int b = pix / ((size_t)Wo * Ho);
+    const f32x4* s = reinterpret_cast<const f32x4*>(in) + (size_t)b * H * W * 12 + c4;
+    const f32x4 a = s[((size_t)(2 * y) * W + 2 * x) * 12], bb = s[((size_t)(2 * y) * W + 2 * x + 1) * 12];
+    const f32x4 c = s[((size_t)(2 * y + 1) * W + 2 * x) * 12],
+                d = s[((size_t)(2 * y + 1) * W + 2 * x + 1) * 12];
+    f32x4 v;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = fmaxf(fmaxf(a[r], bb[r]), fmaxf(c[r], d[r]));
+    reinterpret_cast<f32x4*>(out)[gid] = v;
+}
+
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int C,
+                                    int H, int W, int Cpad) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;   // over B*H*W*Cpad
+    const size_t hw = (size_t)H * W;
+    if (idx >= (size_t)B * hw * Cpad) return;
+    const int c = idx % Cpad;
+    const size_t p = (idx / Cpad) % hw;
+    const int b = idx / ((size_t)Cpad * hw);
+    out[idx] = c < C ? in[((size_t)b * C + c) * hw + p] : 0.f;
+}
+
+__global__ void nhwc_to_nchw_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int C,
+                                    int H, int W, int Cpad) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;   // over B*C*H*W
+    const size_t hw = (size_t)H * W;
+    if (idx >= (size_t)B * C * hw) return;
+    const size_t p = idx % hw;
+    const int c = (idx / hw) % C;
+    const int b = idx / ((size_t)C * hw);
+    out[idx] = in[((size_t)b * hw + p) * Cpad + c];
+}
+
+// PostConvs[1]: 1x1 conv 48 -> 3 (networks/unet.py:713-720)
+__global__ void conv1x1_out_kernel(const float* __restrict__ feat, const float* __restrict__ w,
+                                   const float* __restrict__ bias, float* __restrict__ out_nchw,
+                                   float* __restrict__ out_nhwc4, int B, int H, int W) {
+    __shared__ float ws[3 * 48 + 3];
+    if (threadIdx.x < 147) ws[threadIdx.x] = threadIdx.x < 144 ? w[threadIdx.x] : bias[threadIdx.x - 144];
+    __syncthreads();
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t hw = (size_t)H * W;
+    if (idx >= (size_t)B * hw) return;
+    const f32x4* f = reinterpret_cast<const f32x4*>(feat) + idx * 12;
+    float o0 = 0.f, o1 = 0.f, o2 = 0.f;
+#pragma unroll
+    for (int q = 0; q < 12; ++q) {
+        const f32x4 v = f[q];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            o0 += v[r] * ws[4 * q + r];
+            o1 += v[r] * ws[48 + 4 * q + r];
+            o2 += v[r] * ws[96 + 4 * q + r];
+        }
+    }
+    o0 += ws[144];
+    o1 += ws[145];
+    o2 += ws[146];
+    const size_t b = idx / hw, p = idx - b * hw;
+    if (out_nchw) {
+        out_nchw[(b * 3 + 0) * hw + p] = o0;
+        out_nchw[(b * 3 + 1) * hw + p] = o1;
+        out_nchw[(b * 3 + 2) * hw + p] = o2;
+    }
+    if (out_nhwc4) reinterpret_cast<f32x4*>(out_nhwc4)[idx] = f32x4{o0, o1, o2, 0.f};
+}
+
+// sum |a-b| and sum (a-b)^2 (models/recurrent_model.py:512-525, util/util.py:9-20)
+__global__ void loss_partial_kernel(const float* __restrict__ a, const float* __restrict__ b, int64_t n,
+                                    double* __restrict__ partial) {
+    double s1 = 0.0, s2 = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const float d = a[i] - b[i];
+        s1 += (double)fabsf(d);
+        s2 += (double)d * (double)d;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        s1 += __shfl_down(s1, o);
+        s2 += __shfl_down(s2, o);
+    }
+    __shared__ double sh[2][4];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) {
+        sh[0][wv] = s1;
+        sh[1][wv] = s2;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        partial[2 * blockIdx.x] = sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3];
+        partial[2 * blockIdx.x + 1] = sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3];
+    }
+}
+__global__ void loss_final_kernel(const double* __restrict__ partial, int nblk, double* __restrict__ res) {
+    double s1 = 0.0, s2 = 0.0;
+    for (int i = threadIdx.x; i < nblk; i += 64) {
+        s1 += partial[2 * i];
+        s2 += partial[2 * i + 1];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        s1 += __shfl_down(s1, o);
+        s2 += __shfl_down(s2, o);
+    }
+    if (threadIdx.x == 0) {
+        res[0] = s1;
+        res[1] = s2;
+    }
+}
+
+inline unsigned nblocks(size_t n, int bs) { return (unsigned)((n + bs - 1) / bs); }
+
+}  // namespace
+
+hipError_t launch_demosaic(const float* raw, float* green_scratch, float* out, int n, int h, int w,
+                           int64_t bstride, int pstride, int cstride, hipStream_t s) {
+    const size_t npix = (size_t)n * 4 * h * w;
+    if (!npix) return hipSuccess;
+    hipLaunchKernelGGL(ha_green_kernel, dim3(nblocks(npix, 256)), dim3(256), 0, s, raw, green_scratch, n, h, w);
+    hipLaunchKernelGGL(ha_rb_kernel, dim3(nblocks(npix, 256)), dim3(256), 0, s, raw, green_scratch, out, n, h,
+                       w, bstride, pstride, cstride);
+    return hipGetLastError();
+}
+
+hipError_t launch_warp3(const float* src4, const float* flow_raw, float* dst, int dpstride, int B, int H,
+                        int W, hipStream_t s) {
+    const size_t n = (size_t)B * H * W;
+    hipLaunchKernelGGL(warp3_kernel, dim3(nblocks(n, 256)), dim3(256), 0, s, src4, flow_raw, dst, dpstride, B,
+                       H, W);
+    return hipGetLastError();
+}
+
+hipError_t launch_warp48(const float* src, const float* flow_raw, float* dst, int B, int H, int W,
+                         hipStream_t s) {
+    const size_t n = (size_t)B * H * W * 12;
+    hipLaunchKernelGGL(warp48_kernel, dim3(nblocks(n, 192)), dim3(192), 0, s, src, flow_raw, dst, B, H, W);
+    return hipGetLastError();
+}
+
+hipError_t launch_warp_nchw(const float* x, const float* flow, float* y, int n, int c, int H, int W,
+                            hipStream_t s) {
+    const size_t np = (size_t)n * H * W;
+    if (!np) return hipSuccess;
+    hipLaunchKernelGGL(warp_nchw_kernel, dim3(nblocks(np, 256)), dim3(256), 0, s, x, flow, y, n, c, H, W);
+    return hipGetLastError();
+}
+
+hipError_t launch_upsample_flow(const float* t, float* out, int nc, int h, int w, float mul, hipStream_t s) {
+    const size_t n = (size_t)nc * 4 * h * w;
+    if (!n) return hipSuccess;
+    hipLaunchKernelGGL(upsample_flow_kernel, dim3(nblocks(n, 256)), dim3(256), 0, s, t, out, nc, h, w, mul);
+    return hipGetLastError();
+}
+
+hipError_t launch_upsample2x(const float* in, float* out, int B, int h, int w, int Hout, int Wout, int oy,
+                             int ox, bool align_corners, hipStream_t s) {
+    const size_t n = (size_t)B * Hout * Wout * 12;
+    hipLaunchKernelGGL(upsample2x_kernel, dim3(nblocks(n, 192)), dim3(192), 0, s, in, out, B, h, w, Hout, Wout,
+                       oy, ox, align_corners ? 1 : 0);
+    return hipGetLastError();
+}
+
+hipError_t launch_maxpool2(const float* in, float* out, int B, int H, int W, hipStream_t s) {
+    const size_t n = (size_t)B * (H / 2) * (W / 2) * 12;
+    if (!n) return hipSuccess;
+    hipLaunchKernelGGL(maxpool2_kernel, dim3(nblocks(n, 192)), dim3(192), 0, s, in, out, B, H, W);
+    return hipGetLastError();
+}
+
+hipError_t launch_nchw_to_nhwc(const float* in, float* out, int B, int C, int H, int W, int Cpad,
+                               hipStream_t s) {
+    const size_t n = (size_t)B * H * W * Cpad;
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(nblocks(n, 256)), dim3(256), 0, s, in, out, B, C, H, W, Cpad);
+    return hipGetLastError();
+}
+
+hipError_t launch_nhwc_to_nchw(const float* in, float* out, int B, int C, int H, int W, int Cpad,
+                               hipStream_t s) {
+    const size_t n = (size_t)B * C * H * W;
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(nblocks(n, 256)), dim3(256), 0, s, in, out, B, C, H, W, Cpad);
+    return hipGetLastError();
+}
+
+hipError_t launch_conv1x1_out(const float* feat, const float* w3x48, const float* b3, float* out_nchw,
+                              float* out_nhwc4, int B, int H, int W, hipStream_t s) {
+    const size_t n = (size_t)B * H * W;
+    hipLaunchKernelGGL(conv1x1_out_kernel, dim3(nblocks(n, 256)), dim3(256), 0, s, feat, w3x48, b3, out_nchw,
+                       out_nhwc4, B, H, W);
+    return hipGetLastError();
+}
+
+hipError_t launch_loss_reduce(const float* a, const float* b, int64_t n, double* partial, int nblk,
+                              double* result2, hipStream_t s) {
+    hipLaunchKernelGGL(loss_partial_kernel, dim3(nblk), dim3(256), 0, s, a, b, n, partial);
+    hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(64), 0, s, partial, nblk, result2);
+    return hipGetLastError();
+}

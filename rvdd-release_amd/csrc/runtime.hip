@@ -1,0 +1,763 @@
+// librvdd_hip.so -- C ABI (include/rvdd.h), handle, weight repacking, workspace
+// and the per-frame schedule of the recurrent denoise+demosaic path
+// (models/recurrent_model.py:105-135 set_input, :161-349 forward, test branch).
+#include "../../include/rvdd.h"
+#include "rvdd_internal.h"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct HostTensor {
+    std::vector<int64_t> shape;
+    std::vector<float> data;
+};
+
+struct Conv3 {            // one 3x3 conv layer, split per 48-channel source
+    int nsrc = 0;
+    int cin_real[2] = {0, 0};
+    int cin_pad[2] = {0, 0};
+    float* w[2] = {nullptr, nullptr};
+    float* bias = nullptr;
+};
+
+struct ProfClass {
+    std::string name;
+    int64_t launches = 0;
+    double ms = 0, flops = 0, bytes = 0;
+};
+struct ProfPending {
+    int cls;
+    hipEvent_t e0, e1;
+};
+
+struct Level {
+    int H = 0, W = 0;
+    float* t[3] = {nullptr, nullptr, nullptr};
+    float* skip = nullptr;
+    float* part = nullptr;
+};
+
+}  // namespace
+
+struct rvdd_handle {
+    rvdd_cfg cfg{};
+    std::string err;
+    bool finalized = false;
+    bool need_init = true;
+    std::map<std::string, HostTensor> staged;
+    std::vector<void*> allocs;
+
+    // weights
+    std::map<std::string, Conv3> conv3;
+    float* w_out = nullptr;   // [3][48]
+    float* b_out = nullptr;   // [3]
+    std::map<std::string, float*> dev_w;    // ConvNeXt tensors by key
+    std::vector<NextBlockW> next_blocks;
+
+    // workspace
+    Level lv[4];
+    float* netin = nullptr;      // NHWC16
+    float* lastden4 = nullptr;   // NHWC4
+    float* next4 = nullptr;      // NHWC4
+    float* green = nullptr;      // [B][H][W]
+    float* featw = nullptr;      // NHWC48 warped features
+    float* lastfeat = nullptr;   // NHWC48 recurrent features
+    double* loss_partial = nullptr;
+    double* loss_result = nullptr;
+    float* scratch = nullptr;
+    size_t scratch_bytes = 0;
+
+    // measurement
+    bool prof_on = false;
+    std::vector<ProfClass> prof;
+    std::vector<ProfPending> pending;
+    std::vector<hipEvent_t> event_pool;
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+
+    bool has_feat() const { return cfg.arch == RVDD_ARCH_CONVUNET_FEAT || cfg.arch == RVDD_ARCH_CONVNEXT_FEAT; }
+    bool is_next() const { return cfg.arch == RVDD_ARCH_CONVNEXT || cfg.arch == RVDD_ARCH_CONVNEXT_FEAT; }
+    int cin_real() const { return 3 * (2 + cfg.future); }
+};
+
+namespace {
+
+int fail(rvdd_t* h, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (h) h->err = buf; else g_create_error = buf;
+    return code;
+}
+
+#define HIPCHK(h, expr)                                                                     \
+    do {                                                                                    \
+        hipError_t e__ = (expr);                                                            \
+        if (e__ != hipSuccess)                                                              \
+            return fail((h), RVDD_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), \
+                        __FILE__, __LINE__);                                                \
+    } while (0)
+
+int dmalloc(rvdd_t* h, void** p, size_t bytes, bool zero = true) {
+    HIPCHK(h, hipMalloc(p, bytes ? bytes : 16));
+    h->allocs.push_back(*p);
+    if (zero) HIPCHK(h, hipMemset(*p, 0, bytes ? bytes : 16));
+    return RVDD_OK;
+}
+
+int upload(rvdd_t* h, float** dst, const std::vector<float>& v) {
+    int rc = dmalloc(h, reinterpret_cast<void**>(dst), v.size() * sizeof(float), false);
+    if (rc) return rc;
+    HIPCHK(h, hipMemcpy(*dst, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice));
+    return RVDD_OK;
+}
+
+// OIHW [48][cin_total][3][3], channels [c0, c0+cn) -> [tap][j][cout][g][i] with
+// channel = c0 + 16j + 4g + i (zero beyond cn): the A-fragment order of conv3x3.hip.
+std::vector<float> arrange_conv3x3(const HostTensor& t, int c0, int cn, int cin_pad) {
+    const int cin_total = (int)t.shape[1];
+    const int NJ = cin_pad / 16;
+    std::vector<float> out((size_t)9 * NJ * 48 * 16, 0.f);
+    for (int tap = 0; tap < 9; ++tap)
+        for (int j = 0; j < NJ; ++j)
+            for (int co = 0; co < 48; ++co)
+                for (int g = 0; g < 4; ++g)
+                    for (int i = 0; i < 4; ++i) {
+                        const int c = 16 * j + 4 * g + i;
+                        if (c >= cn) continue;
+                        out[(((size_t)(tap * NJ + j) * 48 + co) * 4 + g) * 4 + i] =
+                            t.data[(((size_t)co * cin_total + c0 + c) * 3 + tap / 3) * 3 + tap % 3];
+                    }
+    return out;
+}
+
+// ---- expected state_dict -------------------
+struct KeySpec {
+    std::string key;
+    std::vector<int64_t> shape;
+};
+
+std::vector<std::string> convunet_conv_names(bool feat) {
+    std::vector<std::string> n;
+    if (feat) n.push_back("preprocessing_layer");
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 2; ++j) n.push_back("EncoderConvs." + std::to_string(i) + ".blocks." + std::to_string(j) + ".0");
+    for (int i = 0; i < 3; ++i) n.push_back("EncoderDown." + std::to_string(i) + ".conv");
+    for (int i = 0; i < 2; ++i) n.push_back("bottleneck." + std::to_string(i) + ".0");
+    for (int i = 0; i < 3; ++i) n.push_back("DecoderUp." + std::to_string(i) + ".up.1");
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 2; ++j) n.push_back("DecoderConvs." + std::to_string(i) + ".blocks." + std::to_string(j) + ".0");
+    n.push_back("PostConvs.0.0");
+    return n;
+}
+
+int convunet_cin(const rvdd_t* h, const std::string& name) {
+    const bool feat = h->has_feat();
+    if (name == "preprocessing_layer") return h->cin_real();
+    if (name == "EncoderConvs.0.blocks.0.0") return feat ? 96 : h->cin_real();
+    if (name.rfind("DecoderConvs.", 0) == 0 && name.find(".blocks.0.0") != std::string::npos) return 96;
+    return 48;
+}
+
+std::vector<std::string> next_block_names(bool feat) {
+    std::vector<std::string> n;
+    if (feat) n.push_back("preprocessing_layer.blocks.0");
+    for (int i = 0; i < 4; ++i) {
+        n.push_back("encoder_convs." + std::to_string(i) + ".blocks.0");
+        n.push_back("encoder_convs." + std::to_string(i) + ".blocks.1");
+        if (i < 3) n.push_back("encoder_downs." + std::to_string(i) + ".postconv");
+    }
+    n.push_back("bottleneck.blocks.0");
+    n.push_back("bottleneck.blocks.1");
+    for (int i = 0; i < 3; ++i) {
+        n.push_back("decoder_ups." + std::to_string(i) + ".postconv");
+        n.push_back("decoder_convs." + std::to_string(i) + ".blocks.0");
+        n.push_back("decoder_convs." + std::to_string(i) + ".blocks.1");
+    }
+    n.push_back("postprocessing.0.blocks.0");
+    n.push_back("postprocessing.0.blocks.1");
+    return n;
+}
+
+int next_proj_cin(const rvdd_t* h, const std::string& blk) {
+    const bool feat = h->has_feat();
+    if (blk == "preprocessing_layer.blocks.0") return h->cin_real();
+    if (blk == "encoder_convs.0.blocks.0") return feat ? 96 : h->cin_real();
+    if (blk.rfind("decoder_convs.", 0) == 0 && blk.find(".blocks.0") != std::string::npos) return 96;
+    return 0;
+}
+
+std::vector<KeySpec> expected_keys(const rvdd_t* h) {
+    std::vector<KeySpec> k;
+    if (!h->is_next()) {
+        for (const auto& n : convunet_conv_names(h->has_feat())) {
+            k.push_back({n + ".weight", {48, convunet_cin(h, n), 3, 3}});
+            k.push_back({n + ".bias", {48}});
+        }
+        k.push_back({"PostConvs.1.weight", {3, 48, 1, 1}});
+        k.push_back({"PostConvs.1.bias", {3}});
+    } else {
+        for (const auto& b : next_block_names(h->has_feat())) {
+            const int pc = next_proj_cin(h, b);
+            if (pc) {
+                k.push_back({b + ".proj.weight", {48, pc, 1, 1}});
+                k.push_back({b + ".proj.bias", {48}});
+            }
+            k.push_back({b + ".block.0.weight", {48, 1, 7, 7}});
+            k.push_back({b + ".block.0.bias", {48}});
+            k.push_back({b + ".block.1.weight", {48}});
+            k.push_back({b + ".block.1.bias", {48}});
+            k.push_back({b + ".block.2.weight", {192, 48, 1, 1}});
+            k.push_back({b + ".block.2.bias", {192}});
+            k.push_back({b + ".block.4.weight", {48, 192, 1, 1}});
+            k.push_back({b + ".block.4.bias", {48}});
+            k.push_back({b + ".layerscale.layerscale", {48}});
+        }
+        k.push_back({"postprocessing.1.weight", {3, 48, 1, 1}});
+        k.push_back({"postprocessing.1.bias", {3}});
+    }
+    return k;
+}
+
+// ---- measurement -------------------------------------------------------------
+int prof_class(rvdd_t* h, const char* name) {
+    for (size_t i = 0; i < h->prof.size(); ++i)
+        if (h->prof[i].name == name) return (int)i;
+    h->prof.push_back(ProfClass{name});
+    return (int)h->prof.size() - 1;
+}
+
+hipEvent_t get_event(rvdd_t* h) {
+    if (!h->event_pool.empty()) {
+        hipEvent_t e = h->event_pool.back();
+        h->event_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+struct Scope {   // brackets one launch with events when profiling is on
+    rvdd_t* h;
+    hipStream_t s;
+    int cls = -1;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    Scope(rvdd_t* h_, hipStream_t s_, const char* name, double flops, double bytes) : h(h_), s(s_) {
+        if (!h->prof_on) return;
+        cls = prof_class(h, name);
+        h->prof[cls].flops += flops;
+        h->prof[cls].bytes += bytes;
+        h->prof[cls].launches += 1;
+        e0 = get_event(h);
+        e1 = get_event(h);
+        (void)hipEventRecord(e0, s);
+    }
+    ~Scope() {
+        if (cls < 0) return;
+        (void)hipEventRecord(e1, s);
+        h->pending.push_back({cls, e0, e1});
+    }
+};
+
+int prof_flush(rvdd_t* h) {
+    for (auto& p : h->pending) {
+        HIPCHK(h, hipEventSynchronize(p.e1));
+        float ms = 0.f;
+        HIPCHK(h, hipEventElapsedTime(&ms, p.e0, p.e1));
+        h->prof[p.cls].ms += ms;
+        h->event_pool.push_back(p.e0);
+        h->event_pool.push_back(p.e1);
+    }
+    h->pending.clear();
+    return RVDD_OK;
+}
+
+// ---- conv helper ---------------------------------------------------------------
+const char* conv_name(int cin, int epi, bool acc) {
+    static const char* names[2][4][2] = {
+        {{"conv3x3_kernel<16, 0, false>", "conv3x3_kernel<16, 0, true>"},
+         {"conv3x3_kernel<16, 1, false>", "conv3x3_kernel<16, 1, true>"},
+         {"conv3x3_kernel<16, 2, false>", "conv3x3_kernel<16, 2, true>"},
+         {"conv3x3_kernel<16, 3, false>", "conv3x3_kernel<16, 3, true>"}},
+        {{"conv3x3_kernel<48, 0, false>", "conv3x3_kernel<48, 0, true>"},
+         {"conv3x3_kernel<48, 1, false>", "conv3x3_kernel<48, 1, true>"},
+         {"conv3x3_kernel<48, 2, false>", "conv3x3_kernel<48, 2, true>"},
+         {"conv3x3_kernel<48, 3, false>", "conv3x3_kernel<48, 3, true>"}}};
+    return names[cin == 48][epi][acc];
+}
+
+struct ConvCall {
+    const float* in = nullptr;
+    int src = 0;             // which weight slice of the layer
+    const float* acc_in = nullptr;
+    bool with_bias = true;   // informational: bias is used iff acc_in == nullptr
+    int epi = EPI_RELU;
+    const float* res1 = nullptr;
+    const float* res2 = nullptr;
+    float* out = nullptr;
+    int H = 0, W = 0;        // conv domain
+    int Hout = 0, Wout = 0, oy = 0, ox = 0;
+};
+
+int run_conv(rvdd_t* h, const Conv3& L, const ConvCall& c, hipStream_t s) {
+    ConvArgs a{};
+    a.in = c.in;
+    a.w = L.w[c.src];
+    a.bias = L.bias;
+    a.acc_in = c.acc_in;
+    a.res1 = c.res1;
+    a.res2 = c.res2;
+    a.out = c.out;
+    a.B = h->cfg.batch;
+    a.H = c.H;
+    a.W = c.W;
+    if (c.epi == EPI_POOL) {
+        a.Hout = c.H / 2;
+        a.Wout = c.W / 2;
+    } else {
+        a.Hout = c.Hout ? c.Hout : c.H;
+        a.Wout = c.Wout ? c.Wout : c.W;
+    }
+    a.oy = c.oy;
+    a.ox = c.ox;
+    a.tiles_x = (c.W + 15) / 16;
+    a.tiles_y = (c.H + 7) / 8;
+    a.ntiles = a.B * a.tiles_x * a.tiles_y;
+    const int cin = L.cin_pad[c.src];
+    const double px = (double)a.B * c.H * c.W;
+    const double flops = 2.0 * 9.0 * L.cin_real[c.src] * 48.0 * px;
+    double bytes = px * 4.0 * (L.cin_real[c.src] + (c.epi == EPI_POOL ? 12.0 : 48.0));
+    if (c.acc_in) bytes += px * 192.0;
+    if (c.epi == EPI_RELU_ADD2) bytes += px * 384.0;
+    Scope sc(h, s, conv_name(cin, c.epi, c.acc_in != nullptr), flops, bytes);
+    HIPCHK(h, launch_conv3x3(a, cin, c.epi, s));
+    return RVDD_OK;
+}
+
+#define RC(expr)               \
+    do {                       \
+        int rc__ = (expr);     \
+        if (rc__) return rc__; \
+    } while (0)
+
+// networks/unet.py:544-588 as specialised by UNet_FixedFeatures[_feat] (:595-825).
+int run_convunet(rvdd_t* h, const float* netin, const float* featw, float* feat_dst, float* out_nchw,
+                 float* out_nhwc4, hipStream_t s) {
+    const bool feat = h->has_feat();
+    const int B = h->cfg.batch;
+    Level* lv = h->lv;
+    auto L = [&](const std::string& n) -> const Conv3& { return h->conv3.at(n); };
+    auto conv = [&](const std::string& name, const float* in, float* out, int lvl, int epi) {
+        ConvCall c;
+        c.in = in; c.out = out; c.H = lv[lvl].H; c.W = lv[lvl].W; c.epi = epi;
+        return run_conv(h, L(name), c, s);
+    };
+    // two-source (virtual concat) conv: pass 1 leaves bias + sum over source A in `part`
+    auto conv2 = [&](const std::string& name, const float* inA, const float* inB, float* out, int lvl) {
+        ConvCall c;
+        c.in = inA; c.src = 0; c.out = lv[lvl].part; c.H = lv[lvl].H; c.W = lv[lvl].W; c.epi = EPI_NONE;
+        RC(run_conv(h, L(name), c, s));
+        c.in = inB; c.src = 1; c.acc_in = lv[lvl].part; c.out = out; c.epi = EPI_RELU;
+        return run_conv(h, L(name), c, s);
+    };
+
+    // ---- encoder
+    if (feat) {
+        RC(conv("preprocessing_layer", netin, lv[0].t[0], 0, EPI_NONE));            // :742 (no activation)
+        RC(conv2("EncoderConvs.0.blocks.0.0", lv[0].t[0], featw, lv[0].t[1], 0));  // cat[y, old_features] :743
+    } else {
+        RC(conv("EncoderConvs.0.blocks.0.0", netin, lv[0].t[1], 0, EPI_RELU));
+    }
+    RC(conv("EncoderConvs.0.blocks.1.0", lv[0].t[1], lv[0].skip, 0, EPI_RELU));
+    for (int i = 0; i < 3; ++i) {
+        const std::string e = "EncoderConvs." + std::to_string(i + 1);
+        RC(conv("EncoderDown." + std::to_string(i) + ".conv", lv[i].skip, lv[i + 1].t[0], i, EPI_POOL));  // :207-208
+        RC(conv(e + ".blocks.0.0", lv[i + 1].t[0], lv[i + 1].t[1], i + 1, EPI_RELU));
+        RC(conv(e + ".blocks.1.0", lv[i + 1].t[1], i + 1 < 3 ? lv[i + 1].skip : lv[3].t[2], i + 1, EPI_RELU));
+    }
+    // ---- bottleneck: d = e3 + d1 + d2 (:561-567)
+    float* e3 = lv[3].t[2];
+    RC(conv("bottleneck.0.0", e3, lv[3].t[0], 3, EPI_RELU));
+    {
+        ConvCall c;
+        c.in = lv[3].t[0]; c.out = lv[3].t[1]; c.H = lv[3].H; c.W = lv[3].W;
+        c.epi = EPI_RELU_ADD2; c.res1 = e3; c.res2 = lv[3].t[0];
+        RC(run_conv(h, L("bottleneck.1.0"), c, s));
+    }
+    const float* d = lv[3].t[1];
+    // ---- decoder (:570-579)
+    for (int i = 0; i < 3; ++i) {
+        const int lo = 3 - i, hi = 2 - i;
+        const int uh = 2 * lv[lo].H, uw = 2 * lv[lo].W;      // size after nn.Upsample(x2)
+        {
+            Scope sc(h, s, "upsample2x_kernel", 0.0, (double)B * uh * uw * 192.0 * 1.25);
+            HIPCHK(h, launch_upsample2x(d, lv[hi].t[0], B, lv[lo].H, lv[lo].W, uh, uw, 0, 0, false, s));
+        }
+        // conv + ReLU at the upsampled size, written into a map of the skip's size
+        // (zero_pad_features, :151-170; identity when sizes agree)
+        ConvCall c;
+        c.in = lv[hi].t[0]; c.out = lv[hi].t[1]; c.H = uh; c.W = uw; c.epi = EPI_RELU;
+        c.Hout = lv[hi].H; c.Wout = lv[hi].W;
+        c.oy = (lv[hi].H - uh) / 2; c.ox = (lv[hi].W - uw) / 2;
+        if (uh != lv[hi].H || uw != lv[hi].W)
+            HIPCHK(h, hipMemsetAsync(lv[hi].t[1], 0, (size_t)B * lv[hi].H * lv[hi].W * kF * sizeof(float), s));
+        RC(run_conv(h, L("DecoderUp." + std::to_string(i) + ".up.1"), c, s));
+        const std::string dc = "DecoderConvs." + std::to_string(i);
+        RC(conv2(dc + ".blocks.0.0", lv[hi].skip, lv[hi].t[1], lv[hi].t[0], hi));   // cat(skip, dec) :541
+        RC(conv(dc + ".blocks.1.0", lv[hi].t[0], lv[hi].t[1], hi, EPI_RELU));
+        d = lv[hi].t[1];
+    }
+    // ---- post: hooked 48-ch map = next frame's features (:808-812), then 1x1 -> 3
+    float* fdst = feat_dst ? feat_dst : lv[0].t[2];
+    RC(conv("PostConvs.0.0", d, fdst, 0, EPI_RELU));
+    {
+        const double px = (double)B * h->cfg.height * h->cfg.width;
+        Scope sc(h, s, "conv1x1_out_kernel", 2.0 * 48 * 3 * px, px * (192.0 + 12.0 + 16.0));
+        HIPCHK(h, launch_conv1x1_out(fdst, h->w_out, h->b_out, out_nchw, out_nhwc4, B, h->cfg.height,
+                                     h->cfg.width, s));
+    }
+    return RVDD_OK;
+}
+
+int run_net(rvdd_t* h, const float* netin, const float* featw, float* feat_dst, float* out_nchw,
+            float* out_nhwc4, hipStream_t s);
+
+int ensure_scratch(rvdd_t* h, size_t bytes) {
+    if (h->scratch_bytes >= bytes) return RVDD_OK;
+    if (h->scratch) {
+        HIPCHK(h, hipDeviceSynchronize());
+        HIPCHK(h, hipFree(h->scratch));
+        h->scratch = nullptr;
+        h->scratch_bytes = 0;
+    }
+    HIPCHK(h, hipMalloc(reinterpret_cast<void**>(&h->scratch), bytes));
+    h->scratch_bytes = bytes;
+    return RVDD_OK;
+}
+
+}  // namespace
+
+#include "runtime_next.inc"
+
+namespace {
+int run_net(rvdd_t* h, const float* netin, const float* featw, float* feat_dst, float* out_nchw,
+            float* out_nhwc4, hipStream_t s) {
+    return h->is_next() ? run_convnext(h, netin, featw, feat_dst, out_nchw, out_nhwc4, s)
+                        : run_convunet(h, netin, featw, feat_dst, out_nchw, out_nhwc4, s);
+}
+}  // namespace
+
+// =============================================================== C ABI =====
+extern "C" {
+
+const char* rvdd_version(void) { return "rvdd-hip 0.1 (gfx950)"; }
+
+const char* rvdd_last_error(const rvdd_t* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int rvdd_create(const rvdd_cfg* cfg, rvdd_t** out) {
+    if (!cfg || !out) return fail(nullptr, RVDD_ERR_ARG, "rvdd_create: null argument");
+    *out = nullptr;
+    if (cfg->arch < 0 || cfg->arch > 3) return fail(nullptr, RVDD_ERR_ARG, "rvdd_create: unknown arch %d", cfg->arch);
+    if (cfg->future < 0 || cfg->future > 1) return fail(nullptr, RVDD_ERR_ARG, "rvdd_create: future must be 0 or 1");
+    if (cfg->batch < 1) return fail(nullptr, RVDD_ERR_ARG, "rvdd_create: batch must be >= 1");
+    if (cfg->height < 16 || cfg->width < 16 || (cfg->height & 1) || (cfg->width & 1))
+        return fail(nullptr, RVDD_ERR_ARG, "rvdd_create: frame size %dx%d must be even and >= 16", cfg->height, cfg->width);
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return fail(nullptr, RVDD_ERR_HIP, "rvdd_create: no HIP device available (%s); this runtime has no CPU fallback",
+                    hipGetErrorString(e));
+    if (cfg->device < 0 || cfg->device >= ndev)
+        return fail(nullptr, RVDD_ERR_ARG, "rvdd_create: device %d out of range (0..%d)", cfg->device, ndev - 1);
+    e = hipSetDevice(cfg->device);
+    if (e != hipSuccess) return fail(nullptr, RVDD_ERR_HIP, "hipSetDevice: %s", hipGetErrorString(e));
+
+    rvdd_t* h = new rvdd_handle();
+    h->cfg = *cfg;
+    const int B = cfg->batch, H = cfg->height, W = cfg->width;
+    int rc = RVDD_OK;
+    auto A = [&](float** p, size_t floats) {
+        if (rc == RVDD_OK) rc = dmalloc(h, reinterpret_cast<void**>(p), floats * sizeof(float));
+    };
+    int lh = H, lw = W;
+    for (int l = 0; l < 4; ++l) {
+        h->lv[l].H = lh;
+        h->lv[l].W = lw;
+        const size_t n = (size_t)B * lh * lw * kF;
+        for (int k = 0; k < 3; ++k) A(&h->lv[l].t[k], n);
+        A(&h->lv[l].skip, n);
+        A(&h->lv[l].part, n);
+        lh /= 2;
+        lw /= 2;
+    }
+    const size_t npix = (size_t)B * H * W;
+    A(&h->netin, npix * kNetInC);
+    A(&h->lastden4, npix * 4);
+    A(&h->next4, npix * 4);
+    A(&h->green, npix);
+    if (h->has_feat()) {
+        A(&h->featw, npix * kF);
+        A(&h->lastfeat, npix * kF);
+    }
+    if (rc == RVDD_OK) rc = dmalloc(h, reinterpret_cast<void**>(&h->loss_partial), 2 * 1024 * sizeof(double));
+    if (rc == RVDD_OK) rc = dmalloc(h, reinterpret_cast<void**>(&h->loss_result), 2 * sizeof(double));
+    if (rc != RVDD_OK) {
+        g_create_error = h->err;
+        rvdd_destroy(h);
+        return rc;
+    }
+    (void)hipEventCreate(&h->t0);
+    (void)hipEventCreate(&h->t1);
+    *out = h;
+    return RVDD_OK;
+}
+
+void rvdd_destroy(rvdd_t* h) {
+    if (!h) return;
+    (void)hipDeviceSynchronize();
+    for (void* p : h->allocs) (void)hipFree(p);
+    if (h->scratch) (void)hipFree(h->scratch);
+    for (auto& p : h->pending) {
+        (void)hipEventDestroy(p.e0);
+        (void)hipEventDestroy(p.e1);
+    }
+    for (auto e : h->event_pool) (void)hipEventDestroy(e);
+    if (h->t0) (void)hipEventDestroy(h->t0);
+    if (h->t1) (void)hipEventDestroy(h->t1);
+    delete h;
+}
+
+int rvdd_set_weight(rvdd_t* h, const char* key, const float* host, const int64_t* shape, int32_t ndim) {
+    if (!h || !key || !host || !shape || ndim < 1 || ndim > 4) return fail(h, RVDD_ERR_ARG, "rvdd_set_weight: bad argument");
+    if (h->finalized) return fail(h, RVDD_ERR_STATE, "rvdd_set_weight: weights already finalized");
+    const auto exp = expected_keys(h);
+    const KeySpec* spec = nullptr;
+    for (const auto& k : exp)
+        if (k.key == key) spec = &k;
+    if (!spec) return fail(h, RVDD_ERR_WEIGHT, "unexpected state_dict key '%s' for this architecture", key);
+    std::vector<int64_t> shp(shape, shape + ndim);
+    if (shp != spec->shape) {
+        std::string got, want;
+        for (auto v : shp) got += std::to_string(v) + ",";
+        for (auto v : spec->shape) want += std::to_string(v) + ",";
+        return fail(h, RVDD_ERR_WEIGHT, "state_dict key '%s' has shape [%s] but [%s] is expected", key, got.c_str(), want.c_str());
+    }
+    size_t n = 1;
+    for (auto v : shp) n *= (size_t)v;
+    HostTensor t;
+    t.shape = shp;
+    t.data.assign(host, host + n);
+    h->staged[key] = std::move(t);
+    return RVDD_OK;
+}
+
+int rvdd_finalize_weights(rvdd_t* h) {
+    if (!h) return RVDD_ERR_ARG;
+    if (h->finalized) return RVDD_OK;
+    for (const auto& k : expected_keys(h))
+        if (!h->staged.count(k.key)) return fail(h, RVDD_ERR_WEIGHT, "missing state_dict key '%s'", k.key.c_str());
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    if (!h->is_next()) {
+        for (const auto& n : convunet_conv_names(h->has_feat())) {
+            const HostTensor& wt = h->staged.at(n + ".weight");
+            Conv3 L;
+            const int cin = (int)wt.shape[1];
+            if (cin == 96) {
+                L.nsrc = 2;
+                for (int sidx = 0; sidx < 2; ++sidx) {
+                    L.cin_real[sidx] = 48;
+                    L.cin_pad[sidx] = 48;
+                    RC(upload(h, &L.w[sidx], arrange_conv3x3(wt, 48 * sidx, 48, 48)));
+                }
+            } else {
+                L.nsrc = 1;
+                L.cin_real[0] = cin;
+                L.cin_pad[0] = cin == 48 ? 48 : kNetInC;
+                RC(upload(h, &L.w[0], arrange_conv3x3(wt, 0, cin, L.cin_pad[0])));
+            }
+            RC(upload(h, &L.bias, h->staged.at(n + ".bias").data));
+            h->conv3[n] = L;
+        }
+        RC(upload(h, &h->w_out, h->staged.at("PostConvs.1.weight").data));
+        RC(upload(h, &h->b_out, h->staged.at("PostConvs.1.bias").data));
+    } else {
+        RC(finalize_convnext(h));
+    }
+    h->staged.clear();
+    h->finalized = true;
+    return RVDD_OK;
+}
+
+int rvdd_reset(rvdd_t* h) {
+    if (!h) return RVDD_ERR_ARG;
+    h->need_init = true;
+    return RVDD_OK;
+}
+
+int rvdd_step(rvdd_t* h, const float* raw_prev, const float* raw_cur, const float* raw_next,
+              const float* flow_prev, const float* flow_next, float* out_rgb, void* stream) {
+    if (!h) return RVDD_ERR_ARG;
+    if (!h->finalized) return fail(h, RVDD_ERR_STATE, "rvdd_step: weights not finalized");
+    if (!raw_cur || !flow_prev || !out_rgb) return fail(h, RVDD_ERR_ARG, "rvdd_step: raw_cur, flow_prev and out_rgb are required");
+    if (h->need_init && !raw_prev) return fail(h, RVDD_ERR_ARG, "rvdd_step: raw_prev is required on the first step of a video");
+    if (h->cfg.future && (!raw_next || !flow_next)) return fail(h, RVDD_ERR_ARG, "rvdd_step: raw_next and flow_next are required when future=1");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int B = h->cfg.batch, H = h->cfg.height, W = h->cfg.width;
+    const size_t npix = (size_t)B * H * W;
+    if (h->need_init) {
+        // lastden = n[:, :3] (demosaiced previous noisy frame), features = 0
+        // (models/recurrent_model.py:233-245)
+        HIPCHK(h, launch_demosaic(raw_prev, h->green, h->lastden4, B, H / 2, W / 2, (int64_t)H * W * 4, 4, 1, s));
+        if (h->has_feat()) HIPCHK(h, hipMemsetAsync(h->lastfeat, 0, npix * kF * sizeof(float), s));
+        h->need_init = false;
+    }
+    {
+        Scope sc(h, s, "demosaic(ha_green+ha_rb)", 0.0, npix * 16.0);
+        HIPCHK(h, launch_demosaic(raw_cur, h->green, h->netin + 3, B, H / 2, W / 2, (int64_t)H * W * kNetInC, kNetInC, 1, s));
+    }
+    {
+        Scope sc(h, s, "warp3_kernel", 0.0, npix * 32.0);
+        HIPCHK(h, launch_warp3(h->lastden4, flow_prev, h->netin + 0, kNetInC, B, H, W, s));
+    }
+    if (h->cfg.future) {
+        HIPCHK(h, launch_demosaic(raw_next, h->green, h->next4, B, H / 2, W / 2, (int64_t)H * W * 4, 4, 1, s));
+        HIPCHK(h, launch_warp3(h->next4, flow_next, h->netin + 6, kNetInC, B, H, W, s));
+    }
+    if (h->has_feat()) {
+        Scope sc(h, s, "warp48_kernel", 0.0, npix * (384.0 + 2.0));
+        HIPCHK(h, launch_warp48(h->lastfeat, flow_prev, h->featw, B, H, W, s));
+    }
+    return run_net(h, h->netin, h->featw, h->lastfeat, out_rgb, h->lastden4, s);
+}
+
+int rvdd_get_state(rvdd_t* h, float* lastden, float* lastfeat, void* stream) {
+    if (!h) return RVDD_ERR_ARG;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int B = h->cfg.batch, H = h->cfg.height, W = h->cfg.width;
+    if (lastden) HIPCHK(h, launch_nhwc_to_nchw(h->lastden4, lastden, B, 3, H, W, 4, s));
+    if (lastfeat) {
+        if (!h->has_feat()) return fail(h, RVDD_ERR_ARG, "rvdd_get_state: this architecture has no recurrent features");
+        HIPCHK(h, launch_nhwc_to_nchw(h->lastfeat, lastfeat, B, kF, H, W, kF, s));
+    }
+    return RVDD_OK;
+}
+
+int rvdd_set_state(rvdd_t* h, const float* lastden, const float* lastfeat, void* stream) {
+    if (!h) return RVDD_ERR_ARG;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int B = h->cfg.batch, H = h->cfg.height, W = h->cfg.width;
+    if (lastden) {
+        HIPCHK(h, launch_nchw_to_nhwc(lastden, h->lastden4, B, 3, H, W, 4, s));
+        h->need_init = false;
+    }
+    if (lastfeat) {
+        if (!h->has_feat()) return fail(h, RVDD_ERR_ARG, "rvdd_set_state: this architecture has no recurrent features");
+        HIPCHK(h, launch_nchw_to_nhwc(lastfeat, h->lastfeat, B, kF, H, W, kF, s));
+    }
+    return RVDD_OK;
+}
+
+int rvdd_psnr_l1(rvdd_t* h, const float* den, const float* gt, int64_t count, float* out2, void* stream) {
+    if (!h || !den || !gt || !out2 || count <= 0) return fail(h, RVDD_ERR_ARG, "rvdd_psnr_l1: bad argument");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    int nblk = (int)((count + 256 * 16 - 1) / (256 * 16));
+    if (nblk > 1024) nblk = 1024;
+    HIPCHK(h, launch_loss_reduce(den, gt, count, h->loss_partial, nblk, h->loss_result, s));
+    double r[2];
+    HIPCHK(h, hipMemcpyAsync(r, h->loss_result, sizeof r, hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipStreamSynchronize(s));
+    out2[0] = (float)(100.0 * r[0] / (double)count);
+    out2[1] = (float)(10.0 * std::log10(4.0 / (r[1] / (double)count)));
+    return RVDD_OK;
+}
+
+int rvdd_unet_forward(rvdd_t* h, const float* x, const float* feat_in, float* out, float* feat_out, void* stream) {
+    if (!h) return RVDD_ERR_ARG;
+    if (!h->finalized) return fail(h, RVDD_ERR_STATE, "rvdd_unet_forward: weights not finalized");
+    if (!x || !out) return fail(h, RVDD_ERR_ARG, "rvdd_unet_forward: x and out are required");
+    if (h->has_feat() && !feat_in)
+        return fail(h, RVDD_ERR_STATE, "Old features is None, please call get_rec_nil_features first.");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int B = h->cfg.batch, H = h->cfg.height, W = h->cfg.width;
+    HIPCHK(h, launch_nchw_to_nhwc(x, h->netin, B, h->cin_real(), H, W, kNetInC, s));
+    if (h->has_feat()) HIPCHK(h, launch_nchw_to_nhwc(feat_in, h->featw, B, kF, H, W, kF, s));
+    RC(run_net(h, h->netin, h->featw, h->lv[0].t[2], out, nullptr, s));
+    if (h->has_feat() && feat_out) HIPCHK(h, launch_nhwc_to_nchw(h->lv[0].t[2], feat_out, B, kF, H, W, kF, s));
+    return RVDD_OK;
+}
+
+int rvdd_demosaic_ha(rvdd_t* h, const float* raw, int32_t n, int32_t hh, int32_t ww, float* rgb, void* stream) {
+    if (!h || !raw || !rgb || n < 0 || hh < 1 || ww < 1) return fail(h, RVDD_ERR_ARG, "rvdd_demosaic_ha: bad argument");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    RC(ensure_scratch(h, (size_t)n * 4 * hh * ww * sizeof(float)));
+    const int64_t hw = (int64_t)4 * hh * ww;
+    HIPCHK(h, launch_demosaic(raw, h->scratch, rgb, n, hh, ww, 3 * hw, 1, (int)hw, s));
+    return RVDD_OK;
+}
+
+int rvdd_warp_bicubic(rvdd_t* h, const float* x, const float* flow, int32_t n, int32_t c, int32_t H, int32_t W,
+                      float* y, void* stream) {
+    if (!h || !x || !flow || !y || n < 0 || c < 1 || H < 2 || W < 2) return fail(h, RVDD_ERR_ARG, "rvdd_warp_bicubic: bad argument");
+    HIPCHK(h, launch_warp_nchw(x, flow, y, n, c, H, W, static_cast<hipStream_t>(stream)));
+    return RVDD_OK;
+}
+
+int rvdd_upsample_factor_2(rvdd_t* h, const float* t, int32_t n, int32_t c, int32_t hh, int32_t ww,
+                           float multiply_by, float* out, void* stream) {
+    if (!h || !t || !out || n < 0 || c < 1 || hh < 1 || ww < 1) return fail(h, RVDD_ERR_ARG, "rvdd_upsample_factor_2: bad argument");
+    HIPCHK(h, launch_upsample_flow(t, out, n * c, hh, ww, multiply_by, static_cast<hipStream_t>(stream)));
+    return RVDD_OK;
+}
+
+int rvdd_profile_enable(rvdd_t* h, int32_t on) {
+    if (!h) return RVDD_ERR_ARG;
+    RC(prof_flush(h));
+    if (on) for (auto& p : h->prof) { p.launches = 0; p.ms = p.flops = p.bytes = 0; }
+    h->prof_on = on != 0;
+    return RVDD_OK;
+}
+
+int rvdd_profile_count(const rvdd_t* h) { return h ? (int)h->prof.size() : 0; }
+
+int rvdd_profile_read(rvdd_t* h, int32_t idx, char* name, int32_t name_cap, int64_t* launches,
+                      double* total_ms, double* flops, double* bytes) {
+    if (!h || idx < 0 || idx >= (int)h->prof.size()) return fail(h, RVDD_ERR_ARG, "rvdd_profile_read: bad index");
+    RC(prof_flush(h));
+    const ProfClass& p = h->prof[idx];
+    if (name && name_cap > 0) {
+        std::strncpy(name, p.name.c_str(), name_cap - 1);
+        name[name_cap - 1] = 0;
+    }
+    if (launches) *launches = p.launches;
+    if (total_ms) *total_ms = p.ms;
+    if (flops) *flops = p.flops;
+    if (bytes) *bytes = p.bytes;
+    return RVDD_OK;
+}
+
+int rvdd_timer_start(rvdd_t* h, void* stream) {
+    if (!h) return RVDD_ERR_ARG;
+    HIPCHK(h, hipEventRecord(h->t0, static_cast<hipStream_t>(stream)));
+    return RVDD_OK;
+}
+
+int rvdd_timer_stop_ms(rvdd_t* h, void* stream, float* ms) {
+    if (!h || !ms) return RVDD_ERR_ARG;
+    HIPCHK(h, hipEventRecord(h->t1, static_cast<hipStream_t>(stream)));
+    HIPCHK(h, hipEventSynchronize(h->t1));
+    HIPCHK(h, hipEventElapsedTime(ms, h->t0, h->t1));
+    return RVDD_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,91 @@
+// Internal declarations shared by the HIP translation units of librvdd_hip.so.
+// Activation maps live in HBM as NHWC fp32 with C = 48 (192 B per pixel, three
+// 64-B lines); the network input is NHWC with C padded to 16; 3-channel
+// frames that are gathered by the bicubic warp are NHWC with C padded to 4.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kF = 48;        // feature channels everywhere (filters=48)
+constexpr int kNetInC = 16;   // padded channel count of the network input map
+
+// ---------------------------------------------------------------- conv3x3 --
+enum ConvEpi { EPI_NONE = 0, EPI_RELU = 1, EPI_POOL = 2, EPI_RELU_ADD2 = 3 };
+
+struct ConvArgs {
+    const float* in;      // NHWC [B][H][W][CIN]
+    const float* w;       // arranged [9][CIN/16][48][16] (see arrange_conv3x3 in runtime.hip)
+    const float* bias;    // [48]   (ignored when acc_in != nullptr)
+    const float* acc_in;  // NHWC48 [B][H][W] partial sums to start from, or nullptr
+    const float* res1;    // EPI_RELU_ADD2: out = relu(conv) + res1 + res2
+    const float* res2;
+    float* out;           // NHWC48 [B][Hout][Wout]
+    int B, H, W;          // conv domain (input size = conv output size)
+    int Hout, Wout;       // size of the map `out` points to
+    int oy, ox;           // placement of the conv output inside it (zero_pad_features)
+    int tiles_x, tiles_y, ntiles;
+};
+
+// cin = 16 or 48.  Returns hipGetLastError().
+hipError_t launch_conv3x3(const ConvArgs& a, int cin, int epi, hipStream_t s);
+size_t conv3x3_weight_floats(int cin);
+
+// -------------------------------------------------------------- pre-stages --
+// Hamilton-Adams: raw [n][4][h][w] -> green plane scratch [n][2h][2w] -> RGB
+// written at out[b*bstride + (y*W+x)*pstride + c*cstride].
+hipError_t launch_demosaic(const float* raw, float* green_scratch, float* out, int n, int h, int w,
+                           int64_t bstride, int pstride, int cstride, hipStream_t s);
+
+// bicubic backward warp with the raw-resolution flow (x2 bilinear upsample,
+// align_corners=True, times 2, fused).  src NHWC4 -> dst[(b*H*W + p)*dpstride + c], c<3.
+hipError_t launch_warp3(const float* src4, const float* flow_raw, float* dst, int dpstride, int B,
+                        int H, int W, hipStream_t s);
+// src NHWC48 -> dst NHWC48.
+hipError_t launch_warp48(const float* src, const float* flow_raw, float* dst, int B, int H, int W,
+                         hipStream_t s);
+// generic NCHW warp with a full-resolution flow (util.flow_utils.warp).
+hipError_t launch_warp_nchw(const float* x, const float* flow, float* y, int n, int c, int H, int W,
+                            hipStream_t s);
+hipError_t launch_upsample_flow(const float* t, float* out, int nc, int h, int w, float mul,
+                                hipStream_t s);
+
+// ---------------------------------------------------------- map reshaping --
+// bilinear x2 of a NHWC48 map [B][h][w] into [B][Hout][Wout] at offset (oy,ox);
+// pixels outside the 2h x 2w window are zero.  align_corners selects
+// nn.Upsample(align_corners=...) semantics.
+hipError_t launch_upsample2x(const float* in, float* out, int B, int h, int w, int Hout, int Wout,
+                             int oy, int ox, bool align_corners, hipStream_t s);
+hipError_t launch_maxpool2(const float* in, float* out, int B, int H, int W, hipStream_t s);
+hipError_t launch_nchw_to_nhwc(const float* in, float* out, int B, int C, int H, int W, int Cpad,
+                               hipStream_t s);
+hipError_t launch_nhwc_to_nchw(const float* in, float* out, int B, int C, int H, int W, int Cpad,
+                               hipStream_t s);
+// final 1x1 conv 48->3: feat NHWC48 -> out NCHW [B][3][H][W] (+ NHWC4 copy for the next warp)
+hipError_t launch_conv1x1_out(const float* feat, const float* w3x48, const float* b3, float* out_nchw,
+                              float* out_nhwc4, int B, int H, int W, hipStream_t s);
+// partial[2*nblk] doubles scratch; result2 device floats {sum|d|, sum d^2} as doubles -> host math
+hipError_t launch_loss_reduce(const float* a, const float* b, int64_t n, double* partial, int nblk,
+                              double* result2, hipStream_t s);
+
+// -------------------------------------------------------------- ConvNeXt ---
+struct NextBlockW {          // device pointers, one ConvBlock (networks/new_unet.py:74-103)
+    const float* proj_w;     // [CinP][48] (k-major) or nullptr
+    const float* proj_b;     // [48]
+    const float* dw_w;       // [49][48]  (tap-major)
+    const float* dw_b;       // [48]
+    const float* ln_w;       // [48]
+    const float* ln_b;       // [48]
+    const float* fc1_w;      // arranged for MFMA, see runtime.hip
+    const float* fc1_b;      // [192]
+    const float* fc2_w;
+    const float* fc2_b;      // [48]
+    const float* ls;         // [48]
+};
+// x NHWC48 (already projected) -> out NHWC48
+hipError_t launch_next_block(const float* x, float* tmp_ln, float* out, const NextBlockW& w, int B,
+                             int H, int W, hipStream_t s);
+// 1x1 projection: in1 NHWC[c1] (+ in2 NHWC[c2]) -> out NHWC48
+hipError_t launch_proj1x1(const float* in1, int c1, const float* in2, int c2, const float* w,
+                          const float* b, float* out, int64_t npix, hipStream_t s);

@@ -1,0 +1,195 @@
+"""Thin object wrapper over one ``rvdd_t`` handle.
+
+PyTorch-ROCm is plumbing here: it owns device memory (``tensor.data_ptr()``
+is what crosses the C ABI) and the HIP stream; all arithmetic is in
+``librvdd_hip.so``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional, Tuple
+
+import torch
+
+from . import _lib
+
+ARCH_BY_NAME = {
+    "convunet": _lib.ARCH_CONVUNET,
+    "convunet+feat": _lib.ARCH_CONVUNET_FEAT,
+    "next": _lib.ARCH_CONVNEXT,
+    "next+feat": _lib.ARCH_CONVNEXT_FEAT,
+}
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _chk_dev(t: torch.Tensor, shape: Tuple[int, ...], name: str) -> torch.Tensor:
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must be a GPU tensor (rvdd has no CPU path)")
+    if tuple(t.shape) != tuple(shape):
+        raise RuntimeError(f"{name} has shape {tuple(t.shape)}, expected {tuple(shape)}")
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"{name} must be float32")
+    return t if t.is_contiguous() else t.contiguous()
+
+
+class RvddRuntime:
+    """One handle = one device, one (arch, future, B, H, W) configuration."""
+
+    def __init__(self, arch: str, future: int, batch: int, height: int, width: int, device: int = 0):
+        self.lib = _lib.load()
+        self.arch = arch
+        self.future = int(future)
+        self.B, self.H, self.W = int(batch), int(height), int(width)
+        self.device = int(device)
+        self.feat = arch.endswith("+feat")
+        cfg = _lib.RvddCfg(ARCH_BY_NAME[arch], self.future, self.B, self.H, self.W, self.device)
+        h = C.c_void_p()
+        rc = self.lib.rvdd_create(C.byref(cfg), C.byref(h))
+        if rc != 0:
+            raise RuntimeError(f"rvdd_create failed ({rc}): {self.lib.rvdd_last_error(None).decode()}")
+        self.h = h
+        self._tdev = torch.device("cuda", self.device)
+
+    # -- helpers ----------------------------------------------------------
+    def _check(self, rc: int, what: str):
+        if rc != 0:
+            raise RuntimeError(f"{what} failed ({rc}): {self.lib.rvdd_last_error(self.h).decode()}")
+
+    def _stream(self) -> int:
+        return torch.cuda.current_stream(self._tdev).cuda_stream
+
+    def close(self):
+        if getattr(self, "h", None) is not None and self.h.value:
+            self.lib.rvdd_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- weights (BaseModel.load_networks, models/base_model.py:173-196) ---
+    def load_state_dict(self, sd: Dict[str, torch.Tensor]):
+        for k, v in sd.items():
+            t = v.detach().to("cpu", torch.float32).contiguous()
+            shape = (C.c_int64 * t.dim())(*t.shape)
+            self._check(self.lib.rvdd_set_weight(self.h, k.encode(), t.data_ptr(), shape, t.dim()),
+                        f"rvdd_set_weight({k})")
+        self._check(self.lib.rvdd_finalize_weights(self.h), "rvdd_finalize_weights")
+
+    # -- hot path -----------------------------------------------------------
+    def reset(self):
+        self._check(self.lib.rvdd_reset(self.h), "rvdd_reset")
+
+    def step(self, raw_prev, raw_cur, raw_next, flow_prev, flow_next, out=None) -> torch.Tensor:
+        B, H, W = self.B, self.H, self.W
+        rs, fs = (B, 4, H // 2, W // 2), (B, 2, H // 2, W // 2)
+        raw_cur = _chk_dev(raw_cur, rs, "raw_cur")
+        flow_prev = _chk_dev(flow_prev, fs, "flow_prev")
+        raw_prev = None if raw_prev is None else _chk_dev(raw_prev, rs, "raw_prev")
+        raw_next = None if raw_next is None else _chk_dev(raw_next, rs, "raw_next")
+        flow_next = None if flow_next is None else _chk_dev(flow_next, fs, "flow_next")
+        if out is None:
+            out = torch.empty(B, 3, H, W, dtype=torch.float32, device=self._tdev)
+        else:
+            _chk_dev(out, (B, 3, H, W), "out")
+            assert out.is_contiguous()
+        self._check(self.lib.rvdd_step(self.h, _ptr(raw_prev), _ptr(raw_cur), _ptr(raw_next),
+                                       _ptr(flow_prev), _ptr(flow_next), _ptr(out), self._stream()),
+                    "rvdd_step")
+        return out
+
+    def get_state(self, want_feat: bool = True):
+        B, H, W = self.B, self.H, self.W
+        den = torch.empty(B, 3, H, W, dtype=torch.float32, device=self._tdev)
+        feat = torch.empty(B, 48, H, W, dtype=torch.float32, device=self._tdev) if (self.feat and want_feat) else None
+        self._check(self.lib.rvdd_get_state(self.h, _ptr(den), _ptr(feat), self._stream()), "rvdd_get_state")
+        return den, feat
+
+    def set_state(self, lastden=None, lastfeat=None):
+        B, H, W = self.B, self.H, self.W
+        if lastden is not None:
+            lastden = _chk_dev(lastden, (B, 3, H, W), "lastden")
+        if lastfeat is not None:
+            lastfeat = _chk_dev(lastfeat, (B, 48, H, W), "lastfeat")
+        self._check(self.lib.rvdd_set_state(self.h, _ptr(lastden), _ptr(lastfeat), self._stream()),
+                    "rvdd_set_state")
+
+    def psnr_l1(self, den: torch.Tensor, gt: torch.Tensor) -> Tuple[float, float]:
+        """-> (L1*100, PSNR) as compute_losses (models/recurrent_model.py:512-525)."""
+        den = _chk_dev(den, den.shape, "den")
+        gt = _chk_dev(gt, den.shape, "gt")
+        out = (C.c_float * 2)()
+        self._check(self.lib.rvdd_psnr_l1(self.h, _ptr(den), _ptr(gt), den.numel(), out, self._stream()),
+                    "rvdd_psnr_l1")
+        return float(out[0]), float(out[1])
+
+    # -- single ops -----------------------------------------------------------
+    def unet_forward(self, x, feat_in=None):
+        B, H, W = self.B, self.H, self.W
+        x = _chk_dev(x, (B, 3 * (2 + self.future), H, W), "x")
+        if feat_in is not None:
+            feat_in = _chk_dev(feat_in, (B, 48, H, W), "feat_in")
+        out = torch.empty(B, 3, H, W, dtype=torch.float32, device=self._tdev)
+        fo = torch.empty(B, 48, H, W, dtype=torch.float32, device=self._tdev) if self.feat else None
+        self._check(self.lib.rvdd_unet_forward(self.h, _ptr(x), _ptr(feat_in), _ptr(out), _ptr(fo),
+                                               self._stream()), "rvdd_unet_forward")
+        return out, fo
+
+    def demosaic(self, raw: torch.Tensor) -> torch.Tensor:
+        n, c, h, w = raw.shape
+        raw = _chk_dev(raw, raw.shape, "raw")
+        assert c % 4 == 0
+        k = n * (c // 4)
+        out = torch.empty(n, 3 * (c // 4), 2 * h, 2 * w, dtype=torch.float32, device=raw.device)
+        self._check(self.lib.rvdd_demosaic_ha(self.h, _ptr(raw), k, h, w, _ptr(out), self._stream()),
+                    "rvdd_demosaic_ha")
+        return out
+
+    def warp(self, x: torch.Tensor, flow: torch.Tensor) -> torch.Tensor:
+        n, c, H, W = x.shape
+        x = _chk_dev(x, x.shape, "x")
+        flow = _chk_dev(flow, (n, 2, H, W), "flow")
+        y = torch.empty_like(x)
+        self._check(self.lib.rvdd_warp_bicubic(self.h, _ptr(x), _ptr(flow), n, c, H, W, _ptr(y),
+                                               self._stream()), "rvdd_warp_bicubic")
+        return y
+
+    def upsample_factor_2(self, t: torch.Tensor, multiply_by: float = 1.0) -> torch.Tensor:
+        *rem, c, h, w = t.shape
+        t = _chk_dev(t, t.shape, "t")
+        n = 1
+        for r in rem:
+            n *= r
+        out = torch.empty(*rem, c, 2 * h, 2 * w, dtype=torch.float32, device=t.device)
+        self._check(self.lib.rvdd_upsample_factor_2(self.h, _ptr(t), n, c, h, w, float(multiply_by),
+                                                    _ptr(out), self._stream()), "rvdd_upsample_factor_2")
+        return out
+
+    # -- measurement ------------------------------------------------------------
+    def profile_enable(self, on: bool):
+        self._check(self.lib.rvdd_profile_enable(self.h, 1 if on else 0), "rvdd_profile_enable")
+
+    def profile_read(self):
+        out = []
+        for i in range(self.lib.rvdd_profile_count(self.h)):
+            name = C.create_string_buffer(128)
+            n = C.c_int64()
+            ms, fl, by = C.c_double(), C.c_double(), C.c_double()
+            self._check(self.lib.rvdd_profile_read(self.h, i, name, 128, C.byref(n), C.byref(ms),
+                                                   C.byref(fl), C.byref(by)), "rvdd_profile_read")
+            out.append(dict(name=name.value.decode(), launches=n.value, ms=ms.value, flops=fl.value,
+                            bytes=by.value))
+        return out
+
+    def timer_start(self):
+        self._check(self.lib.rvdd_timer_start(self.h, self._stream()), "rvdd_timer_start")
+
+    def timer_stop_ms(self) -> float:
+        ms = C.c_float()
+        self._check(self.lib.rvdd_timer_stop_ms(self.h, self._stream(), C.byref(ms)), "rvdd_timer_stop_ms")
+        return float(ms.value)
