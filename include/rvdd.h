@@ -144,6 +144,11 @@ int rvdd_profile_read(rvdd_t* h, int32_t idx, char* name, int32_t name_cap, int6
 int rvdd_timer_start(rvdd_t* h, void* stream);
 int rvdd_timer_stop_ms(rvdd_t* h, void* stream, float* ms);   /* synchronises */
 
+/* Kernel A/B hook: time `iters` back-to-back launches of the 48->48 3x3 conv +
+ * ReLU (the dominant kernel) on the handle's own level-`level` maps with code
+ * variant `variant`; *ms = mean milliseconds per launch.  Synchronises. */
+int rvdd_debug_conv_bench(rvdd_t* h, int32_t variant, int32_t level, int32_t iters, float* ms, void* stream);
+
 const char* rvdd_version(void);
 
 #ifdef __cplusplus

@@ -45,6 +45,7 @@ _PROTOS = {
                                     C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "rvdd_timer_start": (C.c_int, [_P, _P]),
     "rvdd_timer_stop_ms": (C.c_int, [_P, _P, C.POINTER(C.c_float)]),
+    "rvdd_debug_conv_bench": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_float), _P]),
     "rvdd_version": (C.c_char_p, []),
 }
 

@@ -16,8 +16,11 @@
 // covers the 40-cycle dependent latency of the 32-cycle MFMA.  The filter bank
 // (9*CIN*48 floats, 81 KiB for CIN=48) is staged into LDS ONCE per workgroup
 // and the workgroup then walks a grid-stride list of tiles (persistent grid,
-// <= one workgroup per CU), so per tile only the 10x18xCIN input halo tile
-// moves.
+// <= one workgroup per CU).  Per tile only the 10x18xCIN input halo tile moves:
+// it is fetched by LDS-DMA (buffer_load_dwordx4 ... lds) into the other half
+// of a double buffer while the MFMAs run on the current one; out-of-image
+// pixels (padding=1 and ragged edges) are given an out-of-range buffer offset,
+// which the hardware range check turns into zeros.
 //
 // K ordering: for a tap (ky,kx) and a 16-channel chunk j, lane group g=l>>4
 // reads channels 16j+4g..+3 of its pixel with ONE ds_read_b128; MFMA number i
@@ -25,6 +28,7 @@
 // 16j+4g+i.  The weights are pre-arranged on the host (arrange_conv3x3,
 // runtime.hip) as [tap][j][cout][g][i] so that the matching A fragment is one
 // ds_read_b128 too and a wave's read covers a contiguous 1 KiB (conflict-free).
+// Fragments for group n+1 are read while the 24 MFMAs of group n issue.
 #include "rvdd_internal.h"
 
 namespace {
@@ -34,53 +38,95 @@ constexpr int TH = 8, TW = 16, IH = TH + 2, IW = TW + 2;
 template <int CIN>
 struct Geo {
     static constexpr int NJ = CIN / 16;
+    static constexpr int C4 = CIN / 4;
     static constexpr int W_FLOATS = 9 * NJ * 48 * 16;
     static constexpr int I_FLOATS = IH * IW * CIN;
-    static constexpr size_t LDS_BYTES = (size_t)(W_FLOATS + I_FLOATS) * sizeof(float);
+    static constexpr int NCHUNK = IH * IW * C4;               // 16-B pieces of one halo tile
+    static constexpr int NINST = (NCHUNK + 63) / 64;           // wave-wide DMA instructions per tile
+    static constexpr int KPW = (NINST + 3) / 4;                // ... per wave
+    static constexpr int W_NINST = W_FLOATS / 256;             // weights: whole KiB pieces
+    static constexpr size_t LDS_BYTES = (size_t)(W_FLOATS + 2 * I_FLOATS) * sizeof(float);
 };
 
-template <int CIN, int EPI, bool ACC_IN>
+typedef __attribute__((address_space(3))) void lds_void;
+
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, float* lds_wave_base, unsigned voff) {
+    // one 16-B piece per lane: LDS[lds_wave_base + 16*lane] <- buffer[voff]  (0 when voff is out of range)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void*)lds_wave_base, 16, voff, 0, 0, 0);
+}
+
+template <int CIN, int EPI, bool ACC_IN, int VARIANT>
 __global__ __launch_bounds__(256, 1) void conv3x3_kernel(ConvArgs a) {
     using G = Geo<CIN>;
     constexpr int NJ = G::NJ;
+    constexpr int NG = 9 * NJ;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Wl = smem;
-    float* Il = smem + G::W_FLOATS;
+    float* Ibuf = smem + G::W_FLOATS;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lr = lane & 15;
     const int g = lane >> 4;
-
-    // filter bank -> LDS (linear copy; the host already arranged it)
-    for (int q = tid; q < G::W_FLOATS / 4; q += 256)
-        reinterpret_cast<f32x4*>(Wl)[q] = reinterpret_cast<const f32x4*>(a.w)[q];
-
     const int tiles_per_img = a.tiles_x * a.tiles_y;
-    for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+
+    // ---- filter bank -> LDS by DMA (linear copy; the host already arranged it)
+    {
+        __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, G::W_FLOATS * 4, 0x00020000);
+        for (int k = wave; k < G::W_NINST; k += 4) dma16(wr, Wl + k * 256, (unsigned)(k * 1024 + lane * 16));
+    }
+
+    // ---- per-lane description of its DMA pieces (tile independent)
+    int rel[G::KPW];   // byte offset of the piece relative to the tile's (-1,-1) corner
+    int iyx[G::KPW];   // (iy << 8) | ix, or -1 when the piece does not exist
+#pragma unroll
+    for (int k = 0; k < G::KPW; ++k) {
+        const int q = (k * 4 + wave) * 64 + lane;
+        const int px = q / G::C4;
+        const int c4 = q - px * G::C4;
+        const int iy = px / IW;
+        const int ix = px - iy * IW;
+        rel[k] = ((iy * a.W + ix) * CIN + c4 * 4) * 4;
+        iyx[k] = q < G::NCHUNK ? ((iy << 8) | ix) : -1;
+    }
+
+    auto issue_tile = [&](int tile, float* dst) {
+        const int b = tile / tiles_per_img;
+        const int rr = tile - b * tiles_per_img;
+        const int ty = rr / a.tiles_x;
+        const int tx = rr - ty * a.tiles_x;
+        const int y0 = ty * TH - 1, x0 = tx * TW - 1;
+        __amdgpu_buffer_rsrc_t ir = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(a.in + (size_t)b * a.H * a.W * CIN), 0, a.H * a.W * CIN * 4, 0x00020000);
+        const int base = (y0 * a.W + x0) * CIN * 4;
+#pragma unroll
+        for (int k = 0; k < G::KPW; ++k) {
+            if (iyx[k] >= 0) {
+                const int gy = y0 + (iyx[k] >> 8), gx = x0 + (iyx[k] & 255);
+                const bool ok = (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+                dma16(ir, dst + (k * 4 + wave) * 256, ok ? (unsigned)(base + rel[k]) : 0x80000000u);
+            }
+        }
+    };
+
+    int tile = blockIdx.x;
+    if (tile < a.ntiles) issue_tile(tile, Ibuf);
+    int cur = 0;
+
+    for (; tile < a.ntiles; tile += gridDim.x) {
         const int b = tile / tiles_per_img;
         const int rr = tile - b * tiles_per_img;
         const int ty = rr / a.tiles_x;
         const int tx = rr - ty * a.tiles_x;
         const int y0 = ty * TH, x0 = tx * TW;
-        const float* inb = a.in + (size_t)b * a.H * a.W * CIN;
+        const float* Il = Ibuf + cur * G::I_FLOATS;
 
-        __syncthreads();   // previous tile's fragment reads done (and Wl visible on the first pass)
-        // halo tile -> LDS, zero outside the image (padding=1 and ragged edges)
-        constexpr int C4 = CIN / 4;
-        for (int q = tid; q < IH * IW * C4; q += 256) {
-            const int px = q / C4;
-            const int c4 = q - px * C4;
-            const int iy = px / IW;
-            const int ix = px - iy * IW;
-            const int gy = y0 - 1 + iy, gx = x0 - 1 + ix;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if ((unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W)
-                v = *reinterpret_cast<const f32x4*>(inb + ((size_t)gy * a.W + gx) * CIN + c4 * 4);
-            *reinterpret_cast<f32x4*>(Il + px * CIN + c4 * 4) = v;
-        }
+        // this tile's DMA (issued one iteration ago) has landed for every wave, and every
+        // wave is done reading the other buffer
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        if (tile + (int)gridDim.x < a.ntiles) issue_tile(tile + gridDim.x, Ibuf + (cur ^ 1) * G::I_FLOATS);
 
         // ---- accumulators: [cout block m][row n]
         f32x4 acc[3][2];
@@ -104,26 +150,43 @@ __global__ __launch_bounds__(256, 1) void conv3x3_kernel(ConvArgs a) {
 
         const float* wbase = Wl + lr * 16 + g * 4;
         const float* ibase = Il + ((2 * wave) * IW + lr) * CIN + g * 4;
+        f32x4 wa[2][3], xb[2][2];
+        auto ld = [&](int grp, int slot) {
+            const int tap = grp / NJ, j = grp - tap * NJ;
+            const int dy = tap / 3, dx = tap - 3 * dy;
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int dy = tap / 3, dx = tap % 3;
+            for (int m = 0; m < 3; ++m)
+                wa[slot][m] = *reinterpret_cast<const f32x4*>(wbase + ((tap * NJ + j) * 48 + 16 * m) * 16);
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                f32x4 wa[3], xb[2];
+            for (int n = 0; n < 2; ++n)
+                xb[slot][n] = *reinterpret_cast<const f32x4*>(ibase + ((n + dy) * IW + dx) * CIN + 16 * j);
+        };
+        ld(0, 0);
+        if constexpr (VARIANT == 2) __builtin_amdgcn_sched_group_barrier(0x100, 5, 0);
+#pragma unroll
+        for (int grp = 0; grp < NG; ++grp) {
+            const int s = grp & 1;
+            if (grp + 1 < NG) ld(grp + 1, s ^ 1);
+            // pin the order [reads of group n+1] [24 MFMAs of group n]: left alone, hipcc sinks the
+            // reads next to their first use and exposes the LDS latency once per group (-5 % at 720p)
+            if constexpr (VARIANT == 0) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int m = 0; m < 3; ++m)
-                    wa[m] = *reinterpret_cast<const f32x4*>(wbase + ((tap * NJ + j) * 48 + 16 * m) * 16);
 #pragma unroll
-                for (int n = 0; n < 2; ++n)
-                    xb[n] = *reinterpret_cast<const f32x4*>(ibase + ((n + dy) * IW + dx) * CIN + 16 * j);
+                    for (int n = 0; n < 2; ++n)
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[s][m][i], xb[s][n][i], acc[m][n], 0,
+                                                                         0, 0);
+            if constexpr (VARIANT == 0) __builtin_amdgcn_sched_barrier(0);
+            if constexpr (VARIANT == 2) {
+                // spread the next group's five fragment reads between this group's MFMAs
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int m = 0; m < 3; ++m)
-#pragma unroll
-                        for (int n = 0; n < 2; ++n)
-                            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[m][i], xb[n][i],
-                                                                             acc[m][n], 0, 0, 0);
+                for (int k = 0; k < 5; ++k) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
             }
         }
 
@@ -172,13 +235,16 @@ __global__ __launch_bounds__(256, 1) void conv3x3_kernel(ConvArgs a) {
                 }
             }
         }
+        cur ^= 1;
     }
 }
 
-template <int CIN, int EPI, bool ACC_IN>
-hipError_t launch_t(const ConvArgs& a, hipStream_t s) {
+int g_variant = 0;   // A/B switch for the measurement hook (rvdd_debug_conv_bench)
+
+template <int CIN, int EPI, bool ACC_IN, int VARIANT>
+hipError_t launch_v(const ConvArgs& a, hipStream_t s) {
     static bool attr_done = false;
-    auto kern = conv3x3_kernel<CIN, EPI, ACC_IN>;
+    auto kern = conv3x3_kernel<CIN, EPI, ACC_IN, VARIANT>;
     constexpr size_t lds = Geo<CIN>::LDS_BYTES;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -192,6 +258,15 @@ hipError_t launch_t(const ConvArgs& a, hipStream_t s) {
     const int grid = a.ntiles < cus ? a.ntiles : cus;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, a);
     return hipGetLastError();
+}
+
+template <int CIN, int EPI, bool ACC_IN>
+hipError_t launch_t(const ConvArgs& a, hipStream_t s) {
+    if constexpr (CIN == 48 && EPI == EPI_RELU && !ACC_IN) {
+        if (g_variant == 1) return launch_v<CIN, EPI, ACC_IN, 1>(a, s);
+        if (g_variant == 2) return launch_v<CIN, EPI, ACC_IN, 2>(a, s);
+    }
+    return launch_v<CIN, EPI, ACC_IN, 0>(a, s);
 }
 
 template <int CIN>
@@ -212,10 +287,13 @@ hipError_t launch_c(const ConvArgs& a, int epi, hipStream_t s) {
 
 }  // namespace
 
+void conv3x3_set_variant(int v) { g_variant = v; }
+
 size_t conv3x3_weight_floats(int cin) { return (size_t)9 * (cin / 16) * 48 * 16; }
 
 hipError_t launch_conv3x3(const ConvArgs& a, int cin, int epi, hipStream_t s) {
     if (a.ntiles <= 0) return hipSuccess;
+    if ((size_t)a.H * a.W * cin * 4 >= 0x80000000ull) return hipErrorInvalidValue;   // 32-bit buffer offsets
     if (cin == 48) return launch_c<48>(a, epi, s);
     if (cin == 16) return launch_c<16>(a, epi, s);
     return hipErrorInvalidValue;

@@ -746,6 +746,31 @@ int rvdd_profile_read(rvdd_t* h, int32_t idx, char* name, int32_t name_cap, int6
     return RVDD_OK;
 }
 
+int rvdd_debug_conv_bench(rvdd_t* h, int32_t variant, int32_t level, int32_t iters, float* ms, void* stream) {
+    if (!h || !ms || level < 0 || level > 3 || iters < 1) return fail(h, RVDD_ERR_ARG, "rvdd_debug_conv_bench: bad argument");
+    if (!h->finalized || h->is_next()) return fail(h, RVDD_ERR_STATE, "rvdd_debug_conv_bench: needs a finalized convunet handle");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const bool was = h->prof_on;
+    h->prof_on = false;
+    conv3x3_set_variant(variant);
+    ConvCall c;
+    c.in = h->lv[level].t[0]; c.out = h->lv[level].t[1]; c.H = h->lv[level].H; c.W = h->lv[level].W; c.epi = EPI_RELU;
+    const Conv3& L = h->conv3.at("EncoderConvs.1.blocks.1.0");
+    int rc = run_conv(h, L, c, s);   // warm-up (also sets the function attribute)
+    if (rc == RVDD_OK) {
+        (void)hipEventRecord(h->t0, s);
+        for (int i = 0; i < iters && rc == RVDD_OK; ++i) rc = run_conv(h, L, c, s);
+        (void)hipEventRecord(h->t1, s);
+        (void)hipEventSynchronize(h->t1);
+        float t = 0.f;
+        (void)hipEventElapsedTime(&t, h->t0, h->t1);
+        *ms = t / iters;
+    }
+    conv3x3_set_variant(0);
+    h->prof_on = was;
+    return rc;
+}
+
 int rvdd_timer_start(rvdd_t* h, void* stream) {
     if (!h) return RVDD_ERR_ARG;
     HIPCHK(h, hipEventRecord(h->t0, static_cast<hipStream_t>(stream)));

@@ -31,6 +31,7 @@ struct ConvArgs {
 // cin = 16 or 48.  Returns hipGetLastError().
 hipError_t launch_conv3x3(const ConvArgs& a, int cin, int epi, hipStream_t s);
 size_t conv3x3_weight_floats(int cin);
+void conv3x3_set_variant(int v);   // A/B switch used by rvdd_debug_conv_bench only
 
 // -------------------------------------------------------------- pre-stages --
 // Hamilton-Adams: raw [n][4][h][w] -> green plane scratch [n][2h][2w] -> RGB

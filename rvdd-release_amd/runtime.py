@@ -186,6 +186,12 @@ class RvddRuntime:
                             bytes=by.value))
         return out
 
+    def debug_conv_bench(self, variant: int, level: int = 0, iters: int = 20) -> float:
+        ms = C.c_float()
+        self._check(self.lib.rvdd_debug_conv_bench(self.h, variant, level, iters, C.byref(ms), self._stream()),
+                    "rvdd_debug_conv_bench")
+        return float(ms.value)
+
     def timer_start(self):
         self._check(self.lib.rvdd_timer_start(self.h, self._stream()), "rvdd_timer_start")
 
