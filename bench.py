@@ -45,7 +45,7 @@ DESCR = {
 }
 FP32_PEAK_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md, chip table (vector = matrix f32)
 DOMINANT = {"convunet": "conv3x3_kernel<48, 1, false>", "convunet+feat": "conv3x3_kernel<48, 1, false>",
-            "next": "next_mlp_kernel", "next+feat": "next_mlp_kernel"}
+            "next": "mlp_kernel", "next+feat": "mlp_kernel"}
 
 
 def main():

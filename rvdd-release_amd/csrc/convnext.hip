@@ -1,0 +1,398 @@
+// ConvNeXt ConvBlock (networks/new_unet.py:74-103) on gfx950:
+//   x -> [proj 1x1 when Cin != 48] -> r = dwconv7x7 -> LayerNorm_C -> 1x1 48->192
+//     -> GELU(erf) -> 1x1 192->48 ; out = x + layerscale * r
+//
+// Three kernels, all NHWC fp32:
+//   proj1x1_kernel  : 1x1 projection (9|6 -> 48 from the padded 16-channel network
+//                     input, or 96 -> 48 from two 48-channel maps = virtual concat)
+//                     on f32 MFMA with the whole weight matrix held in registers.
+//   dwln_kernel     : depth-wise 7x7 (+bias) and the per-pixel channel LayerNorm
+//                     (biased variance, eps 1e-6, :12-28) from an LDS halo tile.
+//   mlp_kernel      : 48->192 (+bias) -> exact GELU -> 192->48 (+bias), layerscale,
+//                     residual.  Both GEMMs run on v_mfma_f32_16x16x4_f32 in the
+//                     orientation D[channel][pixel]; the accumulators of the first
+//                     GEMM (lane = pixel, 4 consecutive hidden channels per register
+//                     quad) ARE the B fragments of the second one, so the 192-channel
+//                     hidden map never leaves the register file (the reference writes
+//                     and re-reads it: 708 MB per block at 720p).
+//
+// Lane <-> data map shared by all three (the MFMA B-operand map): lane l owns pixel
+// l&15 of its 16-pixel group and, in every 16-channel chunk j, channels 16j+4g..+3
+// with g = l>>4.
+#include "rvdd_internal.h"
+
+namespace {
+
+typedef __attribute__((address_space(3))) void lds_void;
+
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, float* lds_wave_base, unsigned voff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void*)lds_wave_base, 16, voff, 0, 0, 0);
+}
+
+// --------------------------------------------------------------- proj 1x1 --
+// w arranged [j][m][lr][g][i] = W[16m+lr][c(j,g,i)], j over the chunks of in1 then in2.
+template <int C1, int C2>
+__global__ __launch_bounds__(256) void proj1x1_kernel(const float* __restrict__ in1,
+                                                      const float* __restrict__ in2,
+                                                      const float* __restrict__ w,
+                                                      const float* __restrict__ bias,
+                                                      float* __restrict__ out, long npix) {
+    constexpr int NJ1 = C1 / 16, NJ2 = C2 / 16, NJ = NJ1 + NJ2;
+    const int lane = threadIdx.x & 63;
+    const int lr = lane & 15, g = lane >> 4;
+    f32x4 wa[NJ][3];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int m = 0; m < 3; ++m)
+            wa[j][m] = *reinterpret_cast<const f32x4*>(w + (((size_t)(j * 3 + m) * 16 + lr) * 4 + g) * 4);
+    f32x4 bv[3];
+#pragma unroll
+    for (int m = 0; m < 3; ++m) bv[m] = *reinterpret_cast<const f32x4*>(bias + 16 * m + 4 * g);
+
+    const long ngroups = (npix + 15) / 16;
+    const long wave_global = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const long nwaves = ((long)gridDim.x * blockDim.x) >> 6;
+    for (long grp = wave_global; grp < ngroups; grp += nwaves) {
+        const long pix = grp * 16 + lr;
+        const long pc = pix < npix ? pix : npix - 1;
+        f32x4 xb[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ1; ++j) xb[j] = *reinterpret_cast<const f32x4*>(in1 + pc * C1 + 16 * j + 4 * g);
+#pragma unroll
+        for (int j = 0; j < NJ2; ++j)
+            xb[NJ1 + j] = *reinterpret_cast<const f32x4*>(in2 + pc * C2 + 16 * j + 4 * g);
+        f32x4 acc[3] = {bv[0], bv[1], bv[2]};
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int m = 0; m < 3; ++m)
+                    acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[j][m][i], xb[j][i], acc[m], 0, 0, 0);
+        if (pix < npix) {
+#pragma unroll
+            for (int m = 0; m < 3; ++m) *reinterpret_cast<f32x4*>(out + pix * kF + 16 * m + 4 * g) = acc[m];
+        }
+    }
+}
+
+// ------------------------------------------------------------ dw 7x7 + LN --
+constexpr int DT_H = 8, DT_W = 16, DI_H = DT_H + 6, DI_W = DT_W + 6;
+constexpr int D_TILE_FLOATS = DI_H * DI_W * kF;          // 14784
+constexpr int D_W_FLOATS = 49 * kF;                       // 2352
+constexpr int D_NCHUNK = DI_H * DI_W * 12;                // 3696 16-B pieces
+constexpr size_t D_LDS_BYTES = (size_t)(D_TILE_FLOATS + D_W_FLOATS) * 4;
+
+// 512 threads: thread t -> pixel t>>2 of the 8x16 tile, g = t&3 (channels 16j+4g..+3, j=0..2)
+__global__ __launch_bounds__(512) void dwln_kernel(const float* __restrict__ x, const float* __restrict__ dw_w,
+                                                   const float* __restrict__ dw_b,
+                                                   const float* __restrict__ ln_w,
+                                                   const float* __restrict__ ln_b, float* __restrict__ out,
+                                                   int B, int H, int W, int tiles_x, int tiles_y) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Tl = smem;
+    float* Wl = smem + D_TILE_FLOATS;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tile = blockIdx.x;
+    const int tiles_per_img = tiles_x * tiles_y;
+    const int b = tile / tiles_per_img;
+    const int rr = tile - b * tiles_per_img;
+    const int ty = rr / tiles_x, tx = rr - ty * tiles_x;
+    const int y0 = ty * DT_H, x0 = tx * DT_W;
+
+    // halo tile (pad 3, zeros outside the image) by LDS-DMA
+    {
+        __amdgpu_buffer_rsrc_t ir = __builtin_amdgcn_make_buffer_rsrc((void*)(x + (size_t)b * H * W * kF), 0,
+                                                                      H * W * kF * 4, 0x00020000);
+        for (int k = wave; k * 64 < D_NCHUNK; k += 8) {
+            const int q = k * 64 + lane;
+            if (q < D_NCHUNK) {
+                const int px = q / 12, c4 = q - px * 12;
+                const int iy = px / DI_W, ix = px - iy * DI_W;
+                const int gy = y0 - 3 + iy, gx = x0 - 3 + ix;
+                const bool ok = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+                dma16(ir, Tl + k * 256, ok ? (unsigned)(((gy * W + gx) * kF + c4 * 4) * 4) : 0x80000000u);
+            }
+        }
+    }
+    for (int q = tid; q < D_W_FLOATS / 4; q += 512)
+        reinterpret_cast<f32x4*>(Wl)[q] = reinterpret_cast<const f32x4*>(dw_w)[q];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    const int p = tid >> 2, g = tid & 3;
+    const int py = p / DT_W, pxl = p - py * DT_W;
+    f32x4 acc[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) acc[j] = *reinterpret_cast<const f32x4*>(dw_b + 16 * j + 4 * g);
+    const float* tb = Tl + (py * DI_W + pxl) * kF + 4 * g;
+    const float* wb = Wl + 4 * g;
+#pragma unroll
+    for (int ky = 0; ky < 7; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 7; ++kx)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(tb + (ky * DI_W + kx) * kF + 16 * j);
+                const f32x4 wv = *reinterpret_cast<const f32x4*>(wb + (ky * 7 + kx) * kF + 16 * j);
+                acc[j] = acc[j] + v * wv;
+            }
+    // LayerNorm over the 48 channels of the pixel: 12 here, the rest in lanes t^1, t^2, t^3
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) s += (acc[j][0] + acc[j][1]) + (acc[j][2] + acc[j][3]);
+    s += __shfl_xor(s, 1);
+    s += __shfl_xor(s, 2);
+    const float u = s / 48.f;
+    float v2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float d = acc[j][r] - u;
+            v2 += d * d;
+        }
+    v2 += __shfl_xor(v2, 1);
+    v2 += __shfl_xor(v2, 2);
+    const float den = sqrtf(v2 / 48.f + 1e-6f);
+    const int y = y0 + py, xx = x0 + pxl;
+    if (y < H && xx < W) {
+        float* o = out + (((size_t)b * H + y) * W + xx) * kF + 4 * g;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const f32x4 lw = *reinterpret_cast<const f32x4*>(ln_w + 16 * j + 4 * g);
+            const f32x4 lb = *reinterpret_cast<const f32x4*>(ln_b + 16 * j + 4 * g);
+            f32x4 r;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) r[k] = lw[k] * ((acc[j][k] - u) / den) + lb[k];
+            *reinterpret_cast<f32x4*>(o + 16 * j) = r;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------- MLP --
+// LDS: fc1 arranged [j(3)][m(12)][lr][g][i] = W1[16m+lr][16j+4g+i]            (9216 floats)
+//      fc2 arranged [m(12)][mo(3)][lr][g][r] = W2[16mo+lr][16m+4g+r]          (9216 floats)
+constexpr int M_W_FLOATS = 192 * 48;
+constexpr size_t M_LDS_BYTES = (size_t)2 * M_W_FLOATS * 4;
+constexpr int M_NPB = 1;                       // 16-pixel groups per wave iteration
+
+// erf with <1 ulp error (max rel. error 8.6e-8 against math.erf on [-6,6], checked on the
+// host): a degree-6 odd polynomial below 0.9277 and 1-exp(poly) above, evaluated branch-free.
+// It replaces ocml's erff, whose inlined expansion 48x per lane spilled 260+ registers here.
+__device__ __forceinline__ float erf_f32(float a) {
+    const float t = fabsf(a), s = a * a;
+    float r = fmaf(-1.72853470e-5f, t, 3.83197126e-4f);
+    const float u = fmaf(-3.88396438e-3f, t, 2.42546219e-2f);
+    r = fmaf(r, s, u);
+    r = fmaf(r, t, -1.06777877e-1f);
+    r = fmaf(r, t, -6.34846687e-1f);
+    r = fmaf(r, t, -1.28717512e-1f);
+    r = fmaf(r, t, -t);
+    r = copysignf(1.0f - __expf(r), a);
+    float q = -5.96761703e-4f;
+    q = fmaf(q, s, 4.99119423e-3f);
+    q = fmaf(q, s, -2.67681349e-2f);
+    q = fmaf(q, s, 1.12819925e-1f);
+    q = fmaf(q, s, -3.76125336e-1f);
+    q = fmaf(q, s, 1.28379166e-1f);
+    q = fmaf(q, a, a);
+    return t > 0.927734375f ? r : q;
+}
+// nn.GELU() default = exact erf form (networks/new_unet.py:94)
+__device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.f + erf_f32(v * 0.70710678118654752440f)); }
+
+__global__ __launch_bounds__(256, 2) void mlp_kernel(const float* __restrict__ ln, const float* __restrict__ x,
+                                                     const float* __restrict__ fc1_w,
+                                                     const float* __restrict__ fc1_b,
+                                                     const float* __restrict__ fc2_w,
+                                                     const float* __restrict__ fc2_b,
+                                                     const float* __restrict__ ls, float* __restrict__ out,
+                                                     long npix) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* W1 = smem;
+    float* W2 = smem + M_W_FLOATS;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 15, g = lane >> 4;
+    {
+        __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc((void*)fc1_w, 0, M_W_FLOATS * 4, 0x00020000);
+        __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc((void*)fc2_w, 0, M_W_FLOATS * 4, 0x00020000);
+        for (int k = wave; k < M_W_FLOATS / 256; k += 4) {
+            dma16(r1, W1 + k * 256, (unsigned)(k * 1024 + lane * 16));
+            dma16(r2, W2 + k * 256, (unsigned)(k * 1024 + lane * 16));
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    const float* w1b = W1 + lr * 16 + g * 4;
+    const float* w2b = W2 + lr * 16 + g * 4;
+    const long nblk = (npix + 16 * M_NPB - 1) / (16 * M_NPB);
+    const long wave_global = (long)blockIdx.x * 4 + wave;
+    const long nwaves = (long)gridDim.x * 4;
+    for (long blk = wave_global; blk < nblk; blk += nwaves) {
+        long pix[M_NPB];
+        f32x4 xb[M_NPB][3];
+#pragma unroll
+        for (int n = 0; n < M_NPB; ++n) {
+            pix[n] = (blk * M_NPB + n) * 16 + lr;
+            const long pc = pix[n] < npix ? pix[n] : npix - 1;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) xb[n][j] = *reinterpret_cast<const f32x4*>(ln + pc * kF + 16 * j + 4 * g);
+        }
+        // ---- fc1 + bias + GELU: hid[m][n][r] = hidden channel 16m+4g+r of pixel lr of group n.
+        // Two hidden blocks at a time: two independent accumulator chains per pixel group cover
+        // the 40-cycle dependent latency of the 32-cycle MFMA.
+        f32x4 hid[12][M_NPB];
+#pragma unroll
+        for (int m = 0; m < 12; m += 2) {
+            const f32x4 b1a = *reinterpret_cast<const f32x4*>(fc1_b + 16 * m + 4 * g);
+            const f32x4 b1b = *reinterpret_cast<const f32x4*>(fc1_b + 16 * (m + 1) + 4 * g);
+#pragma unroll
+            for (int n = 0; n < M_NPB; ++n) {
+                hid[m][n] = b1a;
+                hid[m + 1][n] = b1b;
+            }
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const f32x4 wa0 = *reinterpret_cast<const f32x4*>(w1b + (j * 12 + m) * 256);
+                const f32x4 wa1 = *reinterpret_cast<const f32x4*>(w1b + (j * 12 + m + 1) * 256);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int n = 0; n < M_NPB; ++n) {
+                        hid[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa0[i], xb[n][j][i], hid[m][n], 0, 0, 0);
+                        hid[m + 1][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa1[i], xb[n][j][i], hid[m + 1][n], 0, 0, 0);
+                    }
+            }
+#pragma unroll
+            for (int n = 0; n < M_NPB; ++n)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    hid[m][n][r] = gelu_erf(hid[m][n][r]);
+                    hid[m + 1][n][r] = gelu_erf(hid[m + 1][n][r]);
+                }
+            __builtin_amdgcn_sched_barrier(0);   // keep hipcc from hoisting every fragment read (it spills)
+        }
+        // ---- fc2: the hidden accumulators are the B fragments (k-slot g of step (m,r) = 16m+4g+r)
+        f32x4 acc[3][M_NPB];
+#pragma unroll
+        for (int mo = 0; mo < 3; ++mo) {
+            const f32x4 b2 = *reinterpret_cast<const f32x4*>(fc2_b + 16 * mo + 4 * g);
+#pragma unroll
+            for (int n = 0; n < M_NPB; ++n) acc[mo][n] = b2;
+        }
+#pragma unroll
+        for (int m = 0; m < 12; ++m)
+#pragma unroll
+            for (int mo = 0; mo < 3; ++mo) {
+                const f32x4 wa = *reinterpret_cast<const f32x4*>(w2b + (m * 3 + mo) * 256);
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int n = 0; n < M_NPB; ++n)
+                        acc[mo][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[r], hid[m][n][r], acc[mo][n], 0, 0, 0);
+                if (mo == 2) __builtin_amdgcn_sched_barrier(0);
+            }
+        // ---- out = x + layerscale * r
+#pragma unroll
+        for (int n = 0; n < M_NPB; ++n) {
+            if (pix[n] < npix) {
+#pragma unroll
+                for (int mo = 0; mo < 3; ++mo) {
+                    const size_t o = (size_t)pix[n] * kF + 16 * mo + 4 * g;
+                    const f32x4 xv = *reinterpret_cast<const f32x4*>(x + o);
+                    const f32x4 lv = *reinterpret_cast<const f32x4*>(ls + 16 * mo + 4 * g);
+                    *reinterpret_cast<f32x4*>(out + o) = xv + lv * acc[mo][n];
+                }
+            }
+        }
+    }
+}
+
+// zero_pad_features (networks/new_unet.py:56-66): src [B][h][w] -> dst [B][H][W] at (oy,ox), zeros elsewhere
+__global__ void pad_copy_kernel(const float* __restrict__ src, float* __restrict__ dst, int B, int h, int w,
+                                int H, int W, int oy, int ox) {
+    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t pix = gid / 12;
+    const int c4 = gid - pix * 12;
+    if (pix >= (size_t)B * H * W) return;
+    const int X = pix % W, Y = (pix / W) % H, b = pix / ((size_t)W * H);
+    const int y = Y - oy, xx = X - ox;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if ((unsigned)y < (unsigned)h && (unsigned)xx < (unsigned)w)
+        v = reinterpret_cast<const f32x4*>(src)[(((size_t)b * h + y) * w + xx) * 12 + c4];
+    reinterpret_cast<f32x4*>(dst)[gid] = v;
+}
+
+int num_cus() {
+    int dev = 0, cus = 256;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    return cus;
+}
+
+}  // namespace
+
+hipError_t launch_proj1x1(const float* in1, int c1, const float* in2, int c2, const float* w, const float* b,
+                          float* out, int64_t npix, hipStream_t s) {
+    if (npix <= 0) return hipSuccess;
+    const long ngroups = (npix + 15) / 16;
+    long blocks = (ngroups + 3) / 4;
+    const long cap = (long)num_cus() * 8;
+    if (blocks > cap) blocks = cap;
+    if (c1 == 16 && c2 == 0)
+        hipLaunchKernelGGL((proj1x1_kernel<16, 0>), dim3((unsigned)blocks), dim3(256), 0, s, in1, in2, w, b, out, (long)npix);
+    else if (c1 == 48 && c2 == 48)
+        hipLaunchKernelGGL((proj1x1_kernel<48, 48>), dim3((unsigned)blocks), dim3(256), 0, s, in1, in2, w, b, out, (long)npix);
+    else
+        return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+hipError_t launch_next_dwln(const float* x, float* ln_out, const NextBlockW& w, int B, int H, int W, hipStream_t s) {
+    static bool attr = false;
+    if (!attr) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(dwln_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)D_LDS_BYTES);
+        if (e != hipSuccess) return e;
+        attr = true;
+    }
+    if ((size_t)H * W * kF * 4 >= 0x80000000ull) return hipErrorInvalidValue;
+    const int tx = (W + DT_W - 1) / DT_W, ty = (H + DT_H - 1) / DT_H;
+    hipLaunchKernelGGL(dwln_kernel, dim3(B * tx * ty), dim3(512), D_LDS_BYTES, s, x, w.dw_w, w.dw_b, w.ln_w, w.ln_b,
+                       ln_out, B, H, W, tx, ty);
+    return hipGetLastError();
+}
+
+hipError_t launch_next_mlp(const float* ln, const float* x, float* out, const NextBlockW& w, int64_t npix,
+                           hipStream_t s) {
+    static bool attr = false;
+    if (!attr) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)M_LDS_BYTES);
+        if (e != hipSuccess) return e;
+        attr = true;
+    }
+    if (npix <= 0) return hipSuccess;
+    const long nblk = (npix + 16 * M_NPB - 1) / (16 * M_NPB);
+    long blocks = (nblk + 3) / 4;
+    const long cap = (long)num_cus() * 2;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(mlp_kernel, dim3((unsigned)blocks), dim3(256), M_LDS_BYTES, s, ln, x, w.fc1_w, w.fc1_b, w.fc2_w,
+                       w.fc2_b, w.ls, out, (long)npix);
+    return hipGetLastError();
+}
+
+hipError_t launch_pad_copy(const float* src, float* dst, int B, int h, int w, int H, int W, int oy, int ox,
+                           hipStream_t s) {
+    const size_t n = (size_t)B * H * W * 12;
+    hipLaunchKernelGGL(pad_copy_kernel, dim3((unsigned)((n + 191) / 192)), dim3(192), 0, s, src, dst, B, h, w, H, W,
+                       oy, ox);
+    return hipGetLastError();
+}

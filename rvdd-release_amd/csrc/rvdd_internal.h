@@ -84,9 +84,14 @@ struct NextBlockW {          // device pointers, one ConvBlock (networks/new_une
     const float* fc2_b;      // [48]
     const float* ls;         // [48]
 };
-// x NHWC48 (already projected) -> out NHWC48
-hipError_t launch_next_block(const float* x, float* tmp_ln, float* out, const NextBlockW& w, int B,
-                             int H, int W, hipStream_t s);
-// 1x1 projection: in1 NHWC[c1] (+ in2 NHWC[c2]) -> out NHWC48
+// one ConvBlock = dwln (x -> LayerNorm(dwconv7x7(x))) then mlp (ln, x -> x + ls * MLP(ln)); x NHWC48
+hipError_t launch_next_dwln(const float* x, float* ln_out, const NextBlockW& w, int B, int H, int W,
+                            hipStream_t s);
+hipError_t launch_next_mlp(const float* ln, const float* x, float* out, const NextBlockW& w, int64_t npix,
+                           hipStream_t s);
+// 1x1 projection on MFMA: in1 NHWC[c1] (+ in2 NHWC[c2]) -> out NHWC48; (c1,c2) = (16,0) or (48,48)
 hipError_t launch_proj1x1(const float* in1, int c1, const float* in2, int c2, const float* w,
                           const float* b, float* out, int64_t npix, hipStream_t s);
+// zero_pad_features: src [B][h][w] -> dst [B][H][W] at (oy,ox), zeros elsewhere (NHWC48)
+hipError_t launch_pad_copy(const float* src, float* dst, int B, int h, int w, int H, int W, int oy, int ox,
+                           hipStream_t s);
