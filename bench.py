@@ -61,23 +61,19 @@ def main():
     args = ap.parse_args()
 
     from safetensors.torch import load_file
-    from rvdd_release_amd import synth
+    from rvdd_release_amd import shard, synth
     from rvdd_release_amd.runtime import RvddRuntime
 
     arch, stem, fut, iso, H, W, T, gflop_frame = CONFIGS[args.config]
     if args.frames:
         T = args.frames
-    rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={os.environ.get('WORLD_SIZE', '1')}: "
+                         "launch with torch.distributed.run")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+    rank, local_rank, world, dist = shard.init_distributed("nccl", dev)    # nccl = RCCL on ROCm
 
     B = args.batch
     sd = load_file(os.path.join(REPO, "weights", stem + ".safetensors"))
@@ -86,8 +82,8 @@ def main():
 
     # ---- synthetic inputs, resident in HBM, [T,B,...] so that a time slice is contiguous
     cfg_id = int(args.config[1])
-    seqs = [synth.make_sequence(T, H, W, iso=iso, seed=1000 * cfg_id + rank * B + b, device=str(dev))
-            for b in range(B)]
+    my_seqs = shard.shard_sequences(B * world, rank, world)   # weak scaling: B sequences per GPU
+    seqs = [synth.make_sequence(T, H, W, iso=iso, seed=1000 * cfg_id + sid, device=str(dev)) for sid in my_seqs]
     raw = torch.stack([s.raw for s in seqs], 1).contiguous()
     fprev = torch.stack([s.flow_prev for s in seqs], 1).contiguous()
     fnext = torch.stack([s.flow_next for s in seqs], 1).contiguous()
@@ -102,10 +98,7 @@ def main():
                     fnext[t] if fut else None, out=outs[t - 1])
 
     def barrier():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
+        shard.barrier(dist, dev)
 
     for _ in range(args.warmup):
         one_step()
@@ -122,21 +115,13 @@ def main():
     prof = rt.profile_read() if not args.no_kernel_events else []
     rt.profile_enable(False)
 
-    elapsed = torch.tensor([wall], dtype=torch.float64, device=dev)
-    if dist is not None:
-        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
-    elapsed = float(elapsed.item())
+    elapsed = shard.max_over_ranks(wall, dist, dev)
     frames_total = args.steps * n_out * B * world
     fps = frames_total / elapsed
 
     # ---- task PSNR of every output frame of the last step (outside the timed region)
-    psnr = torch.tensor([rt.psnr_l1(outs[k], gt[k + 1])[1] for k in range(n_out)], dtype=torch.float64, device=dev)
-    if dist is not None:
-        allp = [torch.empty_like(psnr) for _ in range(world)]
-        dist.all_gather(allp, psnr)                           # the one collate collective
-        psnr_mean = float(torch.stack(allp).mean().item())
-    else:
-        psnr_mean = float(psnr.mean().item())
+    psnr = torch.tensor([[rt.psnr_l1(outs[k], gt[k + 1])[1] for k in range(n_out)]], dtype=torch.float64, device=dev)
+    psnr_mean = float(shard.gather_metrics(psnr, dist).mean().item())    # the one collate collective
 
     if rank != 0:
         if dist is not None:
@@ -169,6 +154,9 @@ def main():
             cores = len(os.sched_getaffinity(0))
         except Exception:
             pass
+        # a 1-GPU box grants a 16-CPU share of a larger host: more threads than the share only
+        # oversubscribe it (256 threads measured 40x slower than 16)
+        cores = int(os.environ.get("RVDD_CPU_THREADS", min(cores, 16)))
         torch.set_num_threads(cores)
         orc = O.RecurrentOracle(sd, future=fut)
         r0, p0, n0 = raw[:, 0].cpu(), fprev[:, 0].cpu(), fnext[:, 0].cpu()

@@ -1,0 +1,69 @@
+"""Multi-GPU sharding of the recurrent path: one process per GPU, sequences
+partitioned statically, no exchange while frames are computed.
+
+The reference has no distributed code at all (its only parallelism is a
+single-process ``torch.nn.DataParallel`` wrapper that is a no-op at
+validation batch size, networks/__init__.py:110-113), so this is new, not a
+translation: independent video sequences share nothing but the read-only
+weights, the recurrence is strictly inside a sequence
+(models/recurrent_model.py:233-345), hence the only collectives are the
+barrier / max that bracket a timed region and ONE all-gather that collates the
+per-frame metrics afterwards (RCCL over xGMI on the GPU box, gloo in the CPU
+tests -- same code).
+"""
+from __future__ import annotations
+
+import os
+from typing import List, Optional, Tuple
+
+import torch
+
+
+def init_distributed(backend: Optional[str] = None, device: Optional[torch.device] = None):
+    """-> (rank, local_rank, world, dist_module_or_None).  Reads the
+    torch.distributed.run environment; a single process needs no group."""
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world == 1:
+        return rank, local_rank, world, None
+    import torch.distributed as dist
+    if not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if (device is not None and device.type == "cuda") else "gloo"
+        kw = {"device_id": device} if (backend == "nccl" and device is not None) else {}
+        dist.init_process_group(backend, **kw)
+    return rank, local_rank, world, dist
+
+
+def shard_sequences(n_total: int, rank: int, world: int) -> range:
+    """Static block partition ``sequence s -> rank s // ceil(n/world)``."""
+    per = -(-n_total // world)
+    lo = min(rank * per, n_total)
+    return range(lo, min(lo + per, n_total))
+
+
+def barrier(dist, device: Optional[torch.device] = None):
+    if device is not None and device.type == "cuda":
+        torch.cuda.synchronize(device)
+    if dist is not None:
+        dist.barrier()
+    if device is not None and device.type == "cuda":
+        torch.cuda.synchronize(device)
+
+
+def max_over_ranks(value: float, dist, device: Optional[torch.device] = None) -> float:
+    t = torch.tensor([value], dtype=torch.float64, device=device if device is not None else "cpu")
+    if dist is not None:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def gather_metrics(local: torch.Tensor, dist) -> torch.Tensor:
+    """The one collate collective: [n_local, ...] per rank -> [world*n_local, ...]
+    in rank (= sequence) order.  Every rank must pass the same shape."""
+    if dist is None:
+        return local
+    parts: List[torch.Tensor] = [torch.empty_like(local) for _ in range(dist.get_world_size())]
+    dist.all_gather(parts, local.contiguous())
+    return torch.cat(parts, 0)

@@ -1,0 +1,74 @@
+"""The C-ABI library: it loads, exports exactly what include/rvdd.h declares, and
+fails loudly (no CPU fallback) when there is no GPU.  No compute calls here."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import pytest
+import torch
+
+from conftest import REPO
+
+HEADER = os.path.join(REPO, "include", "rvdd.h")
+
+
+def declared_functions():
+    txt = open(HEADER).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(rvdd_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_header_and_binding_agree():
+    from rvdd_release_amd import _lib
+    assert declared_functions() == _lib.exported_symbols()
+
+
+def test_library_exports_every_declared_symbol():
+    from rvdd_release_amd import _lib
+    lib = _lib.load()
+    for name in declared_functions():
+        assert hasattr(lib, name), name
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    exported = set(re.findall(r"\sT\s+(rvdd_[a-z0-9_]+)", out))
+    assert exported == set(declared_functions())
+    assert b"gfx950" in lib.rvdd_version()
+
+
+def test_library_carries_gfx950_code_object():
+    from rvdd_release_amd import _lib
+    blob = open(_lib.LIB_PATH, "rb").read()
+    assert b"amdgcn-amd-amdhsa--gfx950" in blob
+    assert b"conv3x3_kernel" in blob and b"warp48_kernel" in blob and b"mlp_kernel" in blob
+
+
+def test_create_validates_arguments():
+    from rvdd_release_amd import _lib
+    lib = _lib.load()
+    h = C.c_void_p()
+    for bad in (_lib.RvddCfg(7, 0, 1, 64, 64, 0), _lib.RvddCfg(0, 2, 1, 64, 64, 0), _lib.RvddCfg(0, 0, 0, 64, 64, 0),
+                _lib.RvddCfg(0, 0, 1, 63, 64, 0), _lib.RvddCfg(0, 0, 1, 8, 64, 0)):
+        assert lib.rvdd_create(C.byref(bad), C.byref(h)) == -1          # RVDD_ERR_ARG
+        assert lib.rvdd_last_error(None)
+        assert not h.value
+    assert lib.rvdd_create(None, C.byref(h)) == -1
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode")
+def test_no_gpu_fails_loudly_no_cpu_fallback():
+    from rvdd_release_amd.runtime import RvddRuntime
+    with pytest.raises(RuntimeError, match="no HIP device available.*no CPU fallback"):
+        RvddRuntime("convunet", 0, 1, 64, 64, 0)
+    from rvdd_release_amd.util.flow_utils import warp
+    with pytest.raises(RuntimeError, match="GPU tensors only"):
+        warp(torch.zeros(1, 3, 16, 16), torch.zeros(1, 2, 16, 16), "bicubic")
+
+
+def test_product_never_imports_the_oracle():
+    """The oracle is test infrastructure: nothing under rvdd-release_amd/ may reference it."""
+    root = os.path.join(REPO, "rvdd-release_amd")
+    for dp, _, files in os.walk(root):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".inc")):
+                src = open(os.path.join(dp, f)).read()
+                assert "rvdd_oracle" not in src and "oracle/" not in src, os.path.join(dp, f)
