@@ -58,6 +58,9 @@ def main():
     ap.add_argument("--frames", type=int, default=0, help="override frames per sequence")
     ap.add_argument("--cpu-frames", type=int, default=3, help="frames of the CPU-oracle sample (0 = skip)")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket kernels with HIP events")
+    ap.add_argument("--all-kernel-events", action="store_true",
+                    help="diagnostic: bracket EVERY launch of every kernel (costs ~6 %% of the frame rate); "
+                         "default brackets every 4th launch of the dominant kernel only")
     args = ap.parse_args()
 
     from safetensors.torch import load_file
@@ -104,6 +107,10 @@ def main():
         one_step()
     barrier()
     if not args.no_kernel_events:
+        if args.all_kernel_events:
+            rt.profile_select(None, 1)
+        else:
+            rt.profile_select(DOMINANT[arch], 4)
         rt.profile_enable(True)
     t0 = time.perf_counter()
     rt.timer_start()
@@ -135,14 +142,24 @@ def main():
         if p["launches"]:
             kernels[p["name"]] = dict(launches=p["launches"], avg_us=1e3 * p["ms"] / p["launches"],
                                       total_ms=p["ms"], tflops=(p["flops"] / (p["ms"] * 1e9)) if p["ms"] else 0.0,
-                                      gbps=(p["bytes"] / (p["ms"] * 1e6)) if p["ms"] else 0.0)
+                                      gbps=(p["bytes"] / (p["ms"] * 1e6)) if p["ms"] else 0.0,
+                                      bytes_per_launch=p["bytes"] / p["launches"])
     dom = DOMINANT[arch]
     if dom in kernels:
         k = kernels[dom]
+        # HBM bytes per launch from the PMC passes (tools/gpu_profile.sh + tools/pmc_summary.py); counters
+        # cannot be read from inside this process, so the last committed measurement is quoted
+        traffic = None
+        try:
+            tj = json.load(open(os.path.join(REPO, "profiles", "traffic.json")))
+            traffic = tj[args.config]["kernels"].get(dom)
+        except Exception:
+            pass
         roofline = {"bound": "mfma", "kernel": dom, "achieved": round(k["tflops"], 2), "peak": FP32_PEAK_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(k["tflops"] / FP32_PEAK_TFLOPS, 4), "traffic": None,
+                    "unit": "TFLOP/s", "frac": round(k["tflops"] / FP32_PEAK_TFLOPS, 4), "traffic": traffic,
+                    "algorithmic_bytes_per_launch": round(k["bytes_per_launch"]),
                     "launches": k["launches"], "avg_launch_us": round(k["avg_us"], 2),
-                    "share_of_gpu_time": round(k["total_ms"] / sum(v["total_ms"] for v in kernels.values()), 4)}
+                    "events": "every launch" if args.all_kernel_events else "every 4th launch"}
 
     # ---- CPU baseline: the oracle on this host's cores, bounded sample, sequence 0
     cpu = None

@@ -136,6 +136,10 @@ int rvdd_upsample_factor_2(rvdd_t* h, const float* t, int32_t n, int32_t c, int3
  * number of launches, the summed duration (ms) and the summed algorithmic
  * FLOPs and bytes since the last rvdd_profile_enable(h, 1). */
 int rvdd_profile_enable(rvdd_t* h, int32_t on);
+/* Restrict the bracketing to one kernel class (NULL = all) and to every
+ * `stride`-th launch of a class: an event pair costs a few microseconds of
+ * queue bubble, so a headline run samples the dominant kernel only. */
+int rvdd_profile_select(rvdd_t* h, const char* kernel_class, int32_t stride);
 int rvdd_profile_count(const rvdd_t* h);
 int rvdd_profile_read(rvdd_t* h, int32_t idx, char* name, int32_t name_cap, int64_t* launches,
                       double* total_ms, double* flops, double* bytes);

@@ -110,8 +110,24 @@ __global__ __launch_bounds__(256, 1) void conv3x3_kernel(ConvArgs a) {
         }
     };
 
+    // bias is tile invariant
+    f32x4 bv[3];
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {
+        if constexpr (ACC_IN) bv[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+        else bv[m] = *reinterpret_cast<const f32x4*>(a.bias + 16 * m + 4 * g);
+    }
+
+    // Every wave issues exactly NS output stores per tile (buffer stores; lanes outside the
+    // image get an out-of-range offset and are dropped by the range check), so that the wait
+    // for the NEXT tile's DMA can be a counted vmcnt(NS) that leaves the stores in flight.
+    constexpr int NS = EPI == EPI_POOL ? 3 : 6;
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
     int tile = blockIdx.x;
-    if (tile < a.ntiles) issue_tile(tile, Ibuf);
+    issue_tile(tile, Ibuf);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
     int cur = 0;
 
     for (; tile < a.ntiles; tile += gridDim.x) {
@@ -122,13 +138,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_kernel(ConvArgs a) {
         const int y0 = ty * TH, x0 = tx * TW;
         const float* Il = Ibuf + cur * G::I_FLOATS;
 
-        // this tile's DMA (issued one iteration ago) has landed for every wave, and every
-        // wave is done reading the other buffer
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tile + (int)gridDim.x < a.ntiles) issue_tile(tile + gridDim.x, Ibuf + (cur ^ 1) * G::I_FLOATS);
-
-        // ---- accumulators: [cout block m][row n]
+        // ---- accumulators: [cout block m][row n].  Partial-sum loads go out BEFORE the next
+        // tile's DMA so that waiting for them does not wait for the DMA (vmcnt is in order).
         f32x4 acc[3][2];
         const int yA = y0 + 2 * wave;       // rows yA, yA+1
         const int xA = x0 + lr;
@@ -143,10 +154,13 @@ __global__ __launch_bounds__(256, 1) void conv3x3_kernel(ConvArgs a) {
                             a.acc_in + (((size_t)b * a.H + yA + n) * a.W + xA) * kF + 16 * m + 4 * g);
                     acc[m][n] = v;
                 } else {
-                    acc[m][n] = *reinterpret_cast<const f32x4*>(a.bias + 16 * m + 4 * g);
+                    acc[m][n] = bv[m];
                 }
             }
         }
+        if constexpr (ACC_IN) __builtin_amdgcn_sched_barrier(0);
+        // every wave is past the barrier that ended the previous tile: the other buffer is free
+        if (tile + (int)gridDim.x < a.ntiles) issue_tile(tile + gridDim.x, Ibuf + (cur ^ 1) * G::I_FLOATS);
 
         const float* wbase = Wl + lr * 16 + g * 4;
         const float* ibase = Il + ((2 * wave) * IW + lr) * CIN + g * 4;
@@ -191,11 +205,15 @@ __global__ __launch_bounds__(256, 1) void conv3x3_kernel(ConvArgs a) {
         }
 
         // ---- epilogue
+        __amdgpu_buffer_rsrc_t orr = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(a.out + (size_t)b * a.Hout * a.Wout * kF), 0, a.Hout * a.Wout * kF * 4, 0x00020000);
         if constexpr (EPI == EPI_POOL) {
             // MaxPool2d(2) of the (un-activated) conv output: rows 2w,2w+1 are the
             // two accumulators of this lane, columns pair up across lanes l, l^1.
             const int py = (y0 >> 1) + wave;
             const int px = (x0 >> 1) + (lr >> 1);
+            const bool ok = (lr & 1) == 0 && py < a.Hout && px < a.Wout;
+            const unsigned obase = ok ? (unsigned)(((py * a.Wout + px) * kF + 4 * g) * 4) : 0x80000000u;
 #pragma unroll
             for (int m = 0; m < 3; ++m) {
                 f32x4 v;
@@ -205,36 +223,38 @@ __global__ __launch_bounds__(256, 1) void conv3x3_kernel(ConvArgs a) {
                     float o = __shfl_xor(t, 1);
                     v[r] = fmaxf(t, o);
                 }
-                if ((lr & 1) == 0 && py < a.Hout && px < a.Wout)
-                    *reinterpret_cast<f32x4*>(a.out + (((size_t)b * a.Hout + py) * a.Wout + px) * kF +
-                                              16 * m + 4 * g) = v;
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), orr, obase + 64 * m, 0, 0);
             }
         } else {
 #pragma unroll
             for (int n = 0; n < 2; ++n) {
                 const int y = yA + n;
-                if (y < a.H && xA < a.W) {
+                const bool ok = y < a.H && xA < a.W;
+                const unsigned obase =
+                    ok ? (unsigned)((((y + a.oy) * a.Wout + xA + a.ox) * kF + 4 * g) * 4) : 0x80000000u;
 #pragma unroll
-                    for (int m = 0; m < 3; ++m) {
-                        f32x4 v = acc[m][n];
-                        if constexpr (EPI == EPI_RELU || EPI == EPI_RELU_ADD2) {
+                for (int m = 0; m < 3; ++m) {
+                    f32x4 v = acc[m][n];
+                    if constexpr (EPI == EPI_RELU || EPI == EPI_RELU_ADD2) {
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
-                        }
-                        if constexpr (EPI == EPI_RELU_ADD2) {
-                            const size_t o = (((size_t)b * a.H + y) * a.W + xA) * kF + 16 * m + 4 * g;
-                            const f32x4 r1 = *reinterpret_cast<const f32x4*>(a.res1 + o);
-                            const f32x4 r2 = *reinterpret_cast<const f32x4*>(a.res2 + o);
-                            // s = e3 + d1 + d2 in the reference's order (unet.py:563-566)
-                            v = (r1 + r2) + v;
-                        }
-                        *reinterpret_cast<f32x4*>(
-                            a.out + (((size_t)b * a.Hout + y + a.oy) * a.Wout + xA + a.ox) * kF + 16 * m +
-                            4 * g) = v;
+                        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
                     }
+                    if constexpr (EPI == EPI_RELU_ADD2) {
+                        const size_t o = ok ? (((size_t)b * a.H + y) * a.W + xA) * kF + 16 * m + 4 * g : 0;
+                        const f32x4 r1 = *reinterpret_cast<const f32x4*>(a.res1 + o);
+                        const f32x4 r2 = *reinterpret_cast<const f32x4*>(a.res2 + o);
+                        // s = e3 + d1 + d2 in the reference's order (unet.py:563-566)
+                        v = (r1 + r2) + v;
+                    }
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), orr, obase + 64 * m, 0, 0);
                 }
             }
         }
+        // the next tile's DMA (older than the NS stores just issued) has landed for this wave;
+        // after the barrier it has landed for every wave and every wave is done reading `cur`
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NS) : "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
         cur ^= 1;
     }
 }

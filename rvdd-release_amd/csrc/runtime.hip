@@ -31,6 +31,7 @@ struct Conv3 {            // one 3x3 conv layer, split per 48-channel source
 
 struct ProfClass {
     std::string name;
+    int64_t seen = 0;
     int64_t launches = 0;
     double ms = 0, flops = 0, bytes = 0;
 };
@@ -78,6 +79,8 @@ struct rvdd_handle {
 
     // measurement
     bool prof_on = false;
+    std::string prof_filter;      // empty = every kernel class
+    int prof_stride = 1;          // bracket every prof_stride-th launch of a class
     std::vector<ProfClass> prof;
     std::vector<ProfPending> pending;
     std::vector<hipEvent_t> event_pool;
@@ -255,7 +258,10 @@ struct Scope {   // brackets one launch with events when profiling is on
     hipEvent_t e0 = nullptr, e1 = nullptr;
     Scope(rvdd_t* h_, hipStream_t s_, const char* name, double flops, double bytes) : h(h_), s(s_) {
         if (!h->prof_on) return;
-        cls = prof_class(h, name);
+        if (!h->prof_filter.empty() && h->prof_filter != name) return;
+        const int c = prof_class(h, name);
+        if (h->prof[c].seen++ % h->prof_stride) return;
+        cls = c;
         h->prof[cls].flops += flops;
         h->prof[cls].bytes += bytes;
         h->prof[cls].launches += 1;
@@ -723,8 +729,15 @@ int rvdd_upsample_factor_2(rvdd_t* h, const float* t, int32_t n, int32_t c, int3
 int rvdd_profile_enable(rvdd_t* h, int32_t on) {
     if (!h) return RVDD_ERR_ARG;
     RC(prof_flush(h));
-    if (on) for (auto& p : h->prof) { p.launches = 0; p.ms = p.flops = p.bytes = 0; }
+    if (on) for (auto& p : h->prof) { p.seen = p.launches = 0; p.ms = p.flops = p.bytes = 0; }
     h->prof_on = on != 0;
+    return RVDD_OK;
+}
+
+int rvdd_profile_select(rvdd_t* h, const char* kernel_class, int32_t stride) {
+    if (!h || stride < 1) return fail(h, RVDD_ERR_ARG, "rvdd_profile_select: bad argument");
+    h->prof_filter = kernel_class ? kernel_class : "";
+    h->prof_stride = stride;
     return RVDD_OK;
 }
 

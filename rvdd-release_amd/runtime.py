@@ -174,6 +174,10 @@ class RvddRuntime:
     def profile_enable(self, on: bool):
         self._check(self.lib.rvdd_profile_enable(self.h, 1 if on else 0), "rvdd_profile_enable")
 
+    def profile_select(self, kernel_class=None, stride: int = 1):
+        self._check(self.lib.rvdd_profile_select(self.h, None if kernel_class is None else kernel_class.encode(),
+                                                 stride), "rvdd_profile_select")
+
     def profile_read(self):
         out = []
         for i in range(self.lib.rvdd_profile_count(self.h)):
