@@ -44,8 +44,8 @@ DESCR = {
     "C4": "recurrent ConvNeXtUnet+feat+future ISO3200 1280x720 30-frame sequences",
 }
 FP32_PEAK_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md, chip table (vector = matrix f32)
-DOMINANT = {"convunet": "conv3x3_kernel<48, 1, false>", "convunet+feat": "conv3x3_kernel<48, 1, false>",
-            "next": "mlp_kernel", "next+feat": "mlp_kernel"}
+_CONV = "conv3x3_kernel<48, 1, false>" if os.environ.get("RVDD_CONV") == "direct" else "wino3x3_kernel<1, false>"
+DOMINANT = {"convunet": _CONV, "convunet+feat": _CONV, "next": "mlp_kernel", "next+feat": "mlp_kernel"}
 
 
 def main():

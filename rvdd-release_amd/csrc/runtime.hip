@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -26,6 +27,7 @@ struct Conv3 {            // one 3x3 conv layer, split per 48-channel source
     int cin_real[2] = {0, 0};
     int cin_pad[2] = {0, 0};
     float* w[2] = {nullptr, nullptr};
+    float* wu[2] = {nullptr, nullptr};   // Winograd F(2x2,3x3) transformed bank (48-channel sources only)
     float* bias = nullptr;
 };
 
@@ -54,6 +56,7 @@ struct rvdd_handle {
     std::string err;
     bool finalized = false;
     bool need_init = true;
+    bool use_wino = true;         // 48->48 3x3 convs: Winograd F(2x2,3x3) (RVDD_CONV=direct selects the direct kernel)
     std::map<std::string, HostTensor> staged;
     std::vector<void*> allocs;
 
@@ -141,6 +144,27 @@ std::vector<float> arrange_conv3x3(const HostTensor& t, int c0, int cn, int cin_
                         out[(((size_t)(tap * NJ + j) * 48 + co) * 4 + g) * 4 + i] =
                             t.data[(((size_t)co * cin_total + c0 + c) * 3 + tap / 3) * 3 + tap % 3];
                     }
+    return out;
+}
+
+// OIHW [48][cin_total][3][3], channels [c0, c0+48) -> U = G g G^T per (cout, cin), stored
+// [pos 16][j 3][m 3][cout&15][g 4][i 4] with channel = c0 + 16j+4g+i: the A-fragment order of wino3x3.hip.
+std::vector<float> arrange_wino3x3(const HostTensor& t, int c0) {
+    const int cin_total = (int)t.shape[1];
+    static const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
+    std::vector<float> out((size_t)16 * 3 * 3 * 256, 0.f);
+    for (int co = 0; co < 48; ++co)
+        for (int c = 0; c < 48; ++c) {
+            const float* gk = &t.data[((size_t)co * cin_total + c0 + c) * 9];
+            double tmp[4][3], u[4][4];
+            for (int i = 0; i < 4; ++i)
+                for (int k = 0; k < 3; ++k) tmp[i][k] = G[i][0] * gk[k] + G[i][1] * gk[3 + k] + G[i][2] * gk[6 + k];
+            for (int i = 0; i < 4; ++i)
+                for (int k = 0; k < 4; ++k) u[i][k] = tmp[i][0] * G[k][0] + tmp[i][1] * G[k][1] + tmp[i][2] * G[k][2];
+            const int j = c / 16, g = (c % 16) / 4, ii = c % 4, m = co / 16, lr = co % 16;
+            for (int pos = 0; pos < 16; ++pos)
+                out[((((size_t)(pos * 3 + j) * 3 + m) * 16 + lr) * 4 + g) * 4 + ii] = (float)u[pos / 4][pos % 4];
+        }
     return out;
 }
 
@@ -303,6 +327,14 @@ const char* conv_name(int cin, int epi, bool acc) {
     return names[cin == 48][epi][acc];
 }
 
+const char* wino_name(int epi, bool acc) {
+    static const char* names[4][2] = {{"wino3x3_kernel<0, false>", "wino3x3_kernel<0, true>"},
+                                      {"wino3x3_kernel<1, false>", "wino3x3_kernel<1, true>"},
+                                      {"wino3x3_kernel<2, false>", "wino3x3_kernel<2, true>"},
+                                      {"wino3x3_kernel<3, false>", "wino3x3_kernel<3, true>"}};
+    return names[epi][acc];
+}
+
 struct ConvCall {
     const float* in = nullptr;
     int src = 0;             // which weight slice of the layer
@@ -346,6 +378,12 @@ int run_conv(rvdd_t* h, const Conv3& L, const ConvCall& c, hipStream_t s) {
     double bytes = px * 4.0 * (L.cin_real[c.src] + (c.epi == EPI_POOL ? 12.0 : 48.0));
     if (c.acc_in) bytes += px * 192.0;
     if (c.epi == EPI_RELU_ADD2) bytes += px * 384.0;
+    if (h->use_wino && cin == 48 && L.wu[c.src]) {
+        a.w = L.wu[c.src];
+        Scope sc(h, s, wino_name(c.epi, c.acc_in != nullptr), flops, bytes);
+        HIPCHK(h, launch_wino3x3(a, c.epi, s));
+        return RVDD_OK;
+    }
     Scope sc(h, s, conv_name(cin, c.epi, c.acc_in != nullptr), flops, bytes);
     HIPCHK(h, launch_conv3x3(a, cin, c.epi, s));
     return RVDD_OK;
@@ -491,6 +529,7 @@ int rvdd_create(const rvdd_cfg* cfg, rvdd_t** out) {
 
     rvdd_t* h = new rvdd_handle();
     h->cfg = *cfg;
+    if (const char* cv = std::getenv("RVDD_CONV")) h->use_wino = std::strcmp(cv, "direct") != 0;
     const int B = cfg->batch, H = cfg->height, W = cfg->width;
     int rc = RVDD_OK;
     auto A = [&](float** p, size_t floats) {
@@ -585,12 +624,14 @@ int rvdd_finalize_weights(rvdd_t* h) {
                     L.cin_real[sidx] = 48;
                     L.cin_pad[sidx] = 48;
                     RC(upload(h, &L.w[sidx], arrange_conv3x3(wt, 48 * sidx, 48, 48)));
+                    RC(upload(h, &L.wu[sidx], arrange_wino3x3(wt, 48 * sidx)));
                 }
             } else {
                 L.nsrc = 1;
                 L.cin_real[0] = cin;
                 L.cin_pad[0] = cin == 48 ? 48 : kNetInC;
                 RC(upload(h, &L.w[0], arrange_conv3x3(wt, 0, cin, L.cin_pad[0])));
+                if (cin == 48) RC(upload(h, &L.wu[0], arrange_wino3x3(wt, 0)));
             }
             RC(upload(h, &L.bias, h->staged.at(n + ".bias").data));
             h->conv3[n] = L;
@@ -763,9 +804,10 @@ int rvdd_debug_conv_bench(rvdd_t* h, int32_t variant, int32_t level, int32_t ite
     if (!h || !ms || level < 0 || level > 3 || iters < 1) return fail(h, RVDD_ERR_ARG, "rvdd_debug_conv_bench: bad argument");
     if (!h->finalized || h->is_next()) return fail(h, RVDD_ERR_STATE, "rvdd_debug_conv_bench: needs a finalized convunet handle");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const bool was = h->prof_on;
+    const bool was = h->prof_on, was_wino = h->use_wino;
     h->prof_on = false;
-    conv3x3_set_variant(variant);
+    h->use_wino = variant == 3;            // variant 3 = Winograd kernel, 0..2 = direct kernel variants
+    conv3x3_set_variant(variant == 3 ? 0 : variant);
     ConvCall c;
     c.in = h->lv[level].t[0]; c.out = h->lv[level].t[1]; c.H = h->lv[level].H; c.W = h->lv[level].W; c.epi = EPI_RELU;
     const Conv3& L = h->conv3.at("EncoderConvs.1.blocks.1.0");
@@ -781,6 +823,7 @@ int rvdd_debug_conv_bench(rvdd_t* h, int32_t variant, int32_t level, int32_t ite
     }
     conv3x3_set_variant(0);
     h->prof_on = was;
+    h->use_wino = was_wino;
     return rc;
 }
 

@@ -31,6 +31,9 @@ struct ConvArgs {
 // cin = 16 or 48.  Returns hipGetLastError().
 hipError_t launch_conv3x3(const ConvArgs& a, int cin, int epi, hipStream_t s);
 size_t conv3x3_weight_floats(int cin);
+// Winograd F(2x2,3x3) variant for 48 -> 48 layers; a.w = bank arranged by arrange_wino3x3 (runtime.hip)
+hipError_t launch_wino3x3(const ConvArgs& a, int epi, hipStream_t s);
+size_t wino3x3_weight_floats();
 void conv3x3_set_variant(int v);   // A/B switch used by rvdd_debug_conv_bench only
 
 // -------------------------------------------------------------- pre-stages --

@@ -1,0 +1,300 @@
+// 3x3 convolution 48 -> 48 (padding 1) as Winograd F(2x2,3x3) on the exact-f32
+// matrix cores: Y = A^T [ (G g G^T) .* (B^T d B) ] A, the element-wise product
+// summed over input channels being 16 independent [48 x 48] x [48 x tiles] GEMMs
+// on v_mfma_f32_16x16x4_f32.  2.25x fewer MFMAs than the direct implicit GEMM of
+// conv3x3.hip (36 instead of 81 per 16 output pixels and 48 couts), same
+// networks/unet.py layers, same epilogues.
+//
+// Lane <-> data map (the MFMA B/D map again): lane l of a wave owns output tile
+// (2x2 pixels) number l&15 of the wave's row of 16 tiles and, per 16-channel chunk
+// j, input channels 16j+4g..+3 (g = l>>4); after the GEMMs it owns output channels
+// 16m+4g..+3 of that tile for the three cout blocks m.
+//  * The 4x4 input patch of a tile is read straight from HBM/L2 into registers
+//    (16 buffer loads of 16 B per chunk; out-of-image pixels get an out-of-range
+//    offset = hardware zero fill = padding 1) and transformed IN REGISTERS: there is no
+//    LDS tile and therefore no barrier inside the tile loop -- the four waves of a
+//    workgroup run independently after the filter bank is resident.
+//  * The transformed filter bank U (16 positions x 48 x 48 floats = 144 KiB) is
+//    DMA'd to LDS once per (persistent) workgroup, pre-arranged on the host as
+//    [pos][j][m][cout&15][g][i] so that an A fragment is one conflict-free
+//    ds_read_b128 per four MFMAs.
+//  * Per wave and unit (16 tiles = 2x32 pixels): 3 chunks x 16 positions x 3 cout
+//    blocks x 4 k-steps = 576 MFMAs on 48 accumulators (192 VGPRs); the patch of the
+//    next chunk / next unit is in flight while the current one is multiplied.
+#include "rvdd_internal.h"
+
+namespace {
+
+constexpr int U_FLOATS = 16 * 3 * 3 * 256;        // 36864 floats = 147456 B
+constexpr size_t U_LDS_BYTES = (size_t)U_FLOATS * 4;
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void lds_void;
+
+__device__ __forceinline__ f32x4 bload(__amdgpu_buffer_rsrc_t r, unsigned off) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
+}
+__device__ __forceinline__ void bstore(__amdgpu_buffer_rsrc_t r, unsigned off, f32x4 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, off, 0, 0);
+}
+
+// B^T d B in place on a 4x4 patch of float4 (p[y*4+x])
+__device__ __forceinline__ void input_transform(f32x4 (&p)[16]) {
+#pragma unroll
+    for (int x = 0; x < 4; ++x) {
+        const f32x4 d0 = p[x], d1 = p[4 + x], d2 = p[8 + x], d3 = p[12 + x];
+        p[x] = d0 - d2;
+        p[4 + x] = d1 + d2;
+        p[8 + x] = d2 - d1;
+        p[12 + x] = d1 - d3;
+    }
+#pragma unroll
+    for (int y = 0; y < 4; ++y) {
+        const f32x4 t0 = p[4 * y], t1 = p[4 * y + 1], t2 = p[4 * y + 2], t3 = p[4 * y + 3];
+        p[4 * y] = t0 - t2;
+        p[4 * y + 1] = t1 + t2;
+        p[4 * y + 2] = t2 - t1;
+        p[4 * y + 3] = t1 - t3;
+    }
+}
+
+struct UnitPos {
+    int b, ty, tx;
+};
+
+template <int EPI, bool ACC_IN>
+__global__ __launch_bounds__(256, 1) void wino3x3_kernel(ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float U[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 15;
+    const int g = lane >> 4;
+
+    {   // transformed filter bank -> LDS (linear copy of the host arrangement)
+        __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, U_FLOATS * 4, 0x00020000);
+        for (int k = wave; k < U_FLOATS / 256; k += 4)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lds_void*)(U + k * 256), 16, (unsigned)(k * 1024 + lane * 16),
+                                                     0, 0, 0);
+    }
+    f32x4 bv[3];
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {
+        if constexpr (ACC_IN) bv[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+        else bv[m] = *reinterpret_cast<const f32x4*>(a.bias + 16 * m + 4 * g);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    const int units_per_img = a.tiles_x * a.tiles_y;
+    const unsigned in_bytes = (unsigned)(a.H * a.W * kF * 4);
+    const unsigned out_bytes = (unsigned)(a.Hout * a.Wout * kF * 4);
+
+    // byte offsets of the 16 patch pixels of this lane's tile (channel chunk 0), or out-of-range
+    unsigned off[16];
+    auto locate = [&](int unit, UnitPos& u) {
+        u.b = unit / units_per_img;
+        const int rr = unit - u.b * units_per_img;
+        const int uy = rr / a.tiles_x;
+        const int ux = rr - uy * a.tiles_x;
+        u.ty = uy * 4 + wave;
+        u.tx = ux * 16 + lr;
+    };
+    auto offsets = [&](const UnitPos& u) {
+        const int y0 = 2 * u.ty - 1, x0 = 2 * u.tx - 1;
+#pragma unroll
+        for (int dy = 0; dy < 4; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 4; ++dx) {
+                const int y = y0 + dy, x = x0 + dx;
+                const bool ok = (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;
+                off[dy * 4 + dx] = ok ? (unsigned)(((y * a.W + x) * kF + 4 * g) * 4) : 0x80000000u;
+            }
+    };
+    auto load_patch = [&](f32x4 (&p)[16], __amdgpu_buffer_rsrc_t r, int j) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) p[k] = bload(r, off[k] + 64 * j);
+    };
+
+    const float* ub = U + lr * 16 + g * 4;
+    f32x4 p0[16], p1[16];
+    f32x4 acc[16][3];
+    auto mfma_chunk = [&](const f32x4 (&v)[16], int j, bool first) {
+#pragma unroll
+        for (int pos = 0; pos < 16; ++pos)
+#pragma unroll
+            for (int m = 0; m < 3; ++m) {
+                const f32x4 wa = *reinterpret_cast<const f32x4*>(ub + ((pos * 3 + j) * 3 + m) * 256);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const f32x4 c = (first && i == 0) ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[pos][m];
+                    acc[pos][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[i], v[pos][i], c, 0, 0, 0);
+                }
+            }
+    };
+
+    int unit = blockIdx.x;
+    UnitPos cur;
+    locate(unit, cur);
+    offsets(cur);
+    __amdgpu_buffer_rsrc_t ir =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(a.in + (size_t)cur.b * a.H * a.W * kF), 0, in_bytes, 0x00020000);
+    load_patch(p0, ir, 0);
+
+#pragma unroll 1
+    for (; unit < a.ntiles; unit += gridDim.x) {
+        // ---- partial sums / residuals of this unit go out first (consumed in the epilogue)
+        const int oyp = 2 * cur.ty, oxp = 2 * cur.tx;          // first output pixel of the tile
+        f32x4 pin[ACC_IN ? 12 : 1];
+        if constexpr (ACC_IN) {
+            __amdgpu_buffer_rsrc_t pr = __builtin_amdgcn_make_buffer_rsrc(
+                (void*)(a.acc_in + (size_t)cur.b * a.H * a.W * kF), 0, in_bytes, 0x00020000);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int y = oyp + (q >> 1), x = oxp + (q & 1);
+                const unsigned o = (y < a.H && x < a.W) ? (unsigned)(((y * a.W + x) * kF + 4 * g) * 4) : 0x80000000u;
+#pragma unroll
+                for (int m = 0; m < 3; ++m) pin[q * 3 + m] = bload(pr, o + 64 * m);
+            }
+        }
+        // ---- chunk 0: p0 is in flight; fetch chunk 1 into p1
+        load_patch(p1, ir, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        input_transform(p0);
+        mfma_chunk(p0, 0, true);
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- chunk 1: fetch chunk 2 into p0
+        load_patch(p0, ir, 2);
+        __builtin_amdgcn_sched_barrier(0);
+        input_transform(p1);
+        mfma_chunk(p1, 1, false);
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- chunk 2: fetch chunk 0 of the NEXT unit into p1
+        const UnitPos done = cur;
+        const int next = unit + gridDim.x;
+        if (next < a.ntiles) {
+            locate(next, cur);
+            offsets(cur);
+            ir = __builtin_amdgcn_make_buffer_rsrc((void*)(a.in + (size_t)cur.b * a.H * a.W * kF), 0, in_bytes,
+                                                   0x00020000);
+            load_patch(p1, ir, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        input_transform(p0);
+        mfma_chunk(p0, 2, false);
+        __builtin_amdgcn_sched_barrier(0);
+
+        // ---- output transform A^T M A, epilogue, stores
+        __amdgpu_buffer_rsrc_t orr = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(a.out + (size_t)done.b * a.Hout * a.Wout * kF), 0, out_bytes, 0x00020000);
+        const int oy = 2 * done.ty, ox = 2 * done.tx;
+        f32x4 res[EPI == EPI_RELU_ADD2 ? 24 : 1];
+        if constexpr (EPI == EPI_RELU_ADD2) {
+            __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(
+                (void*)(a.res1 + (size_t)done.b * a.H * a.W * kF), 0, in_bytes, 0x00020000);
+            __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc(
+                (void*)(a.res2 + (size_t)done.b * a.H * a.W * kF), 0, in_bytes, 0x00020000);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int y = oy + (q >> 1), x = ox + (q & 1);
+                const unsigned o = (y < a.H && x < a.W) ? (unsigned)(((y * a.W + x) * kF + 4 * g) * 4) : 0x80000000u;
+#pragma unroll
+                for (int m = 0; m < 3; ++m) {
+                    res[(q * 3 + m) * 2] = bload(r1, o + 64 * m);
+                    res[(q * 3 + m) * 2 + 1] = bload(r2, o + 64 * m);
+                }
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < 3; ++m) {
+            f32x4 s0[4], s1[4];
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+                s0[x] = (acc[x][m] + acc[4 + x][m]) + acc[8 + x][m];
+                s1[x] = (acc[4 + x][m] - acc[8 + x][m]) - acc[12 + x][m];
+            }
+            f32x4 y[4];   // q = 2*row + col
+            y[0] = (s0[0] + s0[1]) + s0[2];
+            y[1] = (s0[1] - s0[2]) - s0[3];
+            y[2] = (s1[0] + s1[1]) + s1[2];
+            y[3] = (s1[1] - s1[2]) - s1[3];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                y[q] = y[q] + bv[m];
+                if constexpr (ACC_IN) y[q] = y[q] + pin[q * 3 + m];
+            }
+            if constexpr (EPI == EPI_POOL) {
+                // MaxPool2d(2) of the un-activated conv output = max over the tile's 2x2 pixels
+                f32x4 v;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = fmaxf(fmaxf(y[0][r], y[1][r]), fmaxf(y[2][r], y[3][r]));
+                const bool ok = done.ty < a.Hout && done.tx < a.Wout;
+                bstore(orr, ok ? (unsigned)(((done.ty * a.Wout + done.tx) * kF + 16 * m + 4 * g) * 4) : 0x80000000u, v);
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    f32x4 v = y[q];
+                    if constexpr (EPI == EPI_RELU || EPI == EPI_RELU_ADD2) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+                    }
+                    if constexpr (EPI == EPI_RELU_ADD2)
+                        v = (res[(q * 3 + m) * 2] + res[(q * 3 + m) * 2 + 1]) + v;   // e3 + d1 + d2 (unet.py:563-566)
+                    const int yy = oy + (q >> 1), xx = ox + (q & 1);
+                    const bool ok = yy < a.H && xx < a.W;
+                    bstore(orr,
+                           ok ? (unsigned)((((yy + a.oy) * a.Wout + xx + a.ox) * kF + 16 * m + 4 * g) * 4)
+                              : 0x80000000u,
+                           v);
+                }
+            }
+        }
+        // hand the prefetched patch over (p1 -> p0): the loop body is not unrolled, so the
+        // ping-pong parity is restored with 64 moves per unit (~1 % of the unit's cycles)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) p0[k] = p1[k];
+    }
+}
+
+template <int EPI, bool ACC_IN>
+hipError_t launch_w(const ConvArgs& a0, hipStream_t s) {
+    static bool attr_done = false;
+    auto kern = wino3x3_kernel<EPI, ACC_IN>;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)U_LDS_BYTES);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    ConvArgs a = a0;
+    a.tiles_x = (a.W + 31) / 32;     // unit = 4 tile rows x 16 tile columns = 8 x 32 output pixels
+    a.tiles_y = (a.H + 7) / 8;
+    a.ntiles = a.B * a.tiles_x * a.tiles_y;
+    int dev = 0, cus = 256;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const int grid = a.ntiles < cus ? a.ntiles : cus;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), U_LDS_BYTES, s, a);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+size_t wino3x3_weight_floats() { return U_FLOATS; }
+
+hipError_t launch_wino3x3(const ConvArgs& a, int epi, hipStream_t s) {
+    if (a.ntiles <= 0) return hipSuccess;
+    if ((size_t)a.H * a.W * kF * 4 >= 0x80000000ull || (size_t)a.Hout * a.Wout * kF * 4 >= 0x80000000ull)
+        return hipErrorInvalidValue;
+    const bool acc = a.acc_in != nullptr;
+    switch (epi) {
+        case EPI_NONE:
+            return acc ? launch_w<EPI_NONE, true>(a, s) : launch_w<EPI_NONE, false>(a, s);
+        case EPI_RELU:
+            return acc ? launch_w<EPI_RELU, true>(a, s) : launch_w<EPI_RELU, false>(a, s);
+        case EPI_POOL:
+            return acc ? hipErrorInvalidValue : launch_w<EPI_POOL, false>(a, s);
+        case EPI_RELU_ADD2:
+            return acc ? hipErrorInvalidValue : launch_w<EPI_RELU_ADD2, false>(a, s);
+    }
+    return hipErrorInvalidValue;
+}
