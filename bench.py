@@ -54,7 +54,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", default="C2", choices=sorted(CONFIGS))
-    ap.add_argument("--batch", type=int, default=2, help="sequences advanced in lockstep per GPU")
+    ap.add_argument("--batch", type=int, default=4, help="sequences advanced in lockstep per GPU")
     ap.add_argument("--frames", type=int, default=0, help="override frames per sequence")
     ap.add_argument("--cpu-frames", type=int, default=3, help="frames of the CPU-oracle sample (0 = skip)")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket kernels with HIP events")

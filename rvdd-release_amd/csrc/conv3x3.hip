@@ -92,9 +92,11 @@ __global__ __launch_bounds__(256, 1) void conv3x3_kernel(ConvArgs a) {
     }
 
     auto issue_tile = [&](int tile, float* dst) {
-        const int b = tile / tiles_per_img;
+        // integer division runs on the VALU: mark the results wave-uniform so that the buffer
+        // descriptor stays in SGPRs (no waterfall loop around each DMA)
+        const int b = __builtin_amdgcn_readfirstlane(tile / tiles_per_img);
         const int rr = tile - b * tiles_per_img;
-        const int ty = rr / a.tiles_x;
+        const int ty = __builtin_amdgcn_readfirstlane(rr / a.tiles_x);
         const int tx = rr - ty * a.tiles_x;
         const int y0 = ty * TH - 1, x0 = tx * TW - 1;
         __amdgpu_buffer_rsrc_t ir = __builtin_amdgcn_make_buffer_rsrc(
@@ -131,9 +133,9 @@ __global__ __launch_bounds__(256, 1) void conv3x3_kernel(ConvArgs a) {
     int cur = 0;
 
     for (; tile < a.ntiles; tile += gridDim.x) {
-        const int b = tile / tiles_per_img;
+        const int b = __builtin_amdgcn_readfirstlane(tile / tiles_per_img);
         const int rr = tile - b * tiles_per_img;
-        const int ty = rr / a.tiles_x;
+        const int ty = __builtin_amdgcn_readfirstlane(rr / a.tiles_x);
         const int tx = rr - ty * a.tiles_x;
         const int y0 = ty * TH, x0 = tx * TW;
         const float* Il = Ibuf + cur * G::I_FLOATS;

@@ -56,6 +56,7 @@ struct rvdd_handle {
     std::string err;
     bool finalized = false;
     bool need_init = true;
+    bool force_wino = false;      // measurement hook: Winograd at every size
     bool use_wino = true;         // 48->48 3x3 convs: Winograd F(2x2,3x3) (RVDD_CONV=direct selects the direct kernel)
     std::map<std::string, HostTensor> staged;
     std::vector<void*> allocs;
@@ -378,7 +379,10 @@ int run_conv(rvdd_t* h, const Conv3& L, const ConvCall& c, hipStream_t s) {
     double bytes = px * 4.0 * (L.cin_real[c.src] + (c.epi == EPI_POOL ? 12.0 : 48.0));
     if (c.acc_in) bytes += px * 192.0;
     if (c.epi == EPI_RELU_ADD2) bytes += px * 384.0;
-    if (h->use_wino && cin == 48 && L.wu[c.src]) {
+    // Winograd needs enough 8x32-pixel units to fill the chip (its 144 KiB filter bank is loaded once
+    // per workgroup); the 1/8-resolution level of a single 720p sequence (60 units) runs faster direct
+    const int wino_units = a.B * ((c.W + 31) / 32) * ((c.H + 7) / 8);
+    if (h->use_wino && cin == 48 && L.wu[c.src] && (wino_units >= 200 || h->force_wino)) {
         a.w = L.wu[c.src];
         Scope sc(h, s, wino_name(c.epi, c.acc_in != nullptr), flops, bytes);
         HIPCHK(h, launch_wino3x3(a, c.epi, s));
@@ -806,7 +810,7 @@ int rvdd_debug_conv_bench(rvdd_t* h, int32_t variant, int32_t level, int32_t ite
     hipStream_t s = static_cast<hipStream_t>(stream);
     const bool was = h->prof_on, was_wino = h->use_wino;
     h->prof_on = false;
-    h->use_wino = variant == 3;            // variant 3 = Winograd kernel, 0..2 = direct kernel variants
+    h->use_wino = h->force_wino = variant == 3;   // variant 3 = Winograd kernel, 0..2 = direct kernel variants
     conv3x3_set_variant(variant == 3 ? 0 : variant);
     ConvCall c;
     c.in = h->lv[level].t[0]; c.out = h->lv[level].t[1]; c.H = h->lv[level].H; c.W = h->lv[level].W; c.epi = EPI_RELU;
@@ -824,6 +828,7 @@ int rvdd_debug_conv_bench(rvdd_t* h, int32_t variant, int32_t level, int32_t ite
     conv3x3_set_variant(0);
     h->prof_on = was;
     h->use_wino = was_wino;
+    h->force_wino = false;
     return rc;
 }
 

@@ -23,6 +23,8 @@
 //    next chunk / next unit is in flight while the current one is multiplied.
 #include "rvdd_internal.h"
 
+#include <type_traits>
+
 namespace {
 
 constexpr int U_FLOATS = 16 * 3 * 3 * 256;        // 36864 floats = 147456 B
@@ -37,18 +39,18 @@ __device__ __forceinline__ void bstore(__amdgpu_buffer_rsrc_t r, unsigned off, f
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, off, 0, 0);
 }
 
-// B^T d B in place on a 4x4 patch of float4 (p[y*4+x])
-__device__ __forceinline__ void input_transform(f32x4 (&p)[16]) {
-#pragma unroll
-    for (int x = 0; x < 4; ++x) {
+// B^T d B in place on a 4x4 patch of float4 (p[y*4+x]), in 8 slices so that the caller can
+// spread it between MFMA groups: slices 0..3 = column pass (x = slice), 4..7 = row pass.
+__device__ __forceinline__ void transform_slice(f32x4 (&p)[16], int sl) {
+    if (sl < 4) {
+        const int x = sl;
         const f32x4 d0 = p[x], d1 = p[4 + x], d2 = p[8 + x], d3 = p[12 + x];
         p[x] = d0 - d2;
         p[4 + x] = d1 + d2;
         p[8 + x] = d2 - d1;
         p[12 + x] = d1 - d3;
-    }
-#pragma unroll
-    for (int y = 0; y < 4; ++y) {
+    } else {
+        const int y = sl - 4;
         const f32x4 t0 = p[4 * y], t1 = p[4 * y + 1], t2 = p[4 * y + 2], t3 = p[4 * y + 3];
         p[4 * y] = t0 - t2;
         p[4 * y + 1] = t1 + t2;
@@ -88,124 +90,137 @@ __global__ __launch_bounds__(256, 1) void wino3x3_kernel(ConvArgs a) {
     const int units_per_img = a.tiles_x * a.tiles_y;
     const unsigned in_bytes = (unsigned)(a.H * a.W * kF * 4);
     const unsigned out_bytes = (unsigned)(a.Hout * a.Wout * kF * 4);
+    const int row_bytes = a.W * kF * 4;
 
-    // byte offsets of the 16 patch pixels of this lane's tile (channel chunk 0), or out-of-range
-    unsigned off[16];
     auto locate = [&](int unit, UnitPos& u) {
-        u.b = unit / units_per_img;
+        // integer division runs on the VALU: tell hipcc the results are wave-uniform, or every
+        // buffer descriptor built from them is wrapped in a waterfall loop
+        u.b = __builtin_amdgcn_readfirstlane(unit / units_per_img);
         const int rr = unit - u.b * units_per_img;
-        const int uy = rr / a.tiles_x;
+        const int uy = __builtin_amdgcn_readfirstlane(rr / a.tiles_x);
         const int ux = rr - uy * a.tiles_x;
         u.ty = uy * 4 + wave;
         u.tx = ux * 16 + lr;
     };
-    auto offsets = [&](const UnitPos& u) {
+    // the 16 patch pixels of a tile: 16 buffer loads of 16 B; pixels outside the image get an
+    // out-of-range offset (hardware zero fill = padding 1).  Offsets are recomputed per load
+    // (a few VALU ops) instead of being kept in 16 registers.
+    auto load_patch = [&](f32x4 (&p)[16], const UnitPos& u, int j) {
+        __amdgpu_buffer_rsrc_t r =
+            __builtin_amdgcn_make_buffer_rsrc((void*)(a.in + (size_t)u.b * a.H * a.W * kF), 0, in_bytes, 0x00020000);
         const int y0 = 2 * u.ty - 1, x0 = 2 * u.tx - 1;
+        const int base = (y0 * a.W + x0) * (kF * 4) + (16 * j + 4 * g) * 4;
+        // branch-free validity: an invalid row / column adds 2^30 to the offset, which pushes it
+        // past num_records (< 2^31) whatever the (possibly negative) base is
+        int ro[4], co[4];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            ro[d] = (unsigned)(y0 + d) < (unsigned)a.H ? d * row_bytes : 0x40000000;
+            co[d] = (unsigned)(x0 + d) < (unsigned)a.W ? d * (kF * 4) : 0x40000000;
+        }
 #pragma unroll
         for (int dy = 0; dy < 4; ++dy)
 #pragma unroll
-            for (int dx = 0; dx < 4; ++dx) {
-                const int y = y0 + dy, x = x0 + dx;
-                const bool ok = (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;
-                off[dy * 4 + dx] = ok ? (unsigned)(((y * a.W + x) * kF + 4 * g) * 4) : 0x80000000u;
-            }
-    };
-    auto load_patch = [&](f32x4 (&p)[16], __amdgpu_buffer_rsrc_t r, int j) {
-#pragma unroll
-        for (int k = 0; k < 16; ++k) p[k] = bload(r, off[k] + 64 * j);
+            for (int dx = 0; dx < 4; ++dx) p[dy * 4 + dx] = bload(r, (unsigned)(base + ro[dy] + co[dx]));
     };
 
     const float* ub = U + lr * 16 + g * 4;
-    f32x4 p0[16], p1[16];
+    f32x4 pb[2][16];      // ping-pong patch buffers (raw patch -> transformed in place)
     f32x4 acc[16][3];
-    auto mfma_chunk = [&](const f32x4 (&v)[16], int j, bool first) {
+    auto ldsA = [&](int j, int pos, int m) {
+        return *reinterpret_cast<const f32x4*>(ub + ((pos * 3 + j) * 3 + m) * 256);
+    };
+
+    // One pipeline stage = chunk J of the current unit: 16 steps (positions) of 3 A fragments and
+    // 12 MFMAs on the transformed patch pb[X], issued k-step-major / cout-block-minor so that
+    // consecutive MFMAs hit three different accumulators (the 16x16x4 MFMA has a 40-cycle
+    // dependent latency against a 32-cycle issue interval).  At the start of the stage the raw
+    // patch of the NEXT chunk is requested into the other buffer; it is transformed in 8 slices
+    // spread over steps 8..15 (VALU under the MFMAs); the fragments of step s+1 are read at step
+    // s.  sched_barrier pins this order (hipcc otherwise sinks each fragment read next to its
+    // first use and exposes one LDS latency per fragment).
+    auto stage = [&](auto JC, auto XC, bool first, const UnitPos& ld_u, int ld_j) {
+        constexpr int J = decltype(JC)::value;
+        constexpr int X = decltype(XC)::value;
+        constexpr int Y = 1 - X;
+        load_patch(pb[Y], ld_u, ld_j);
+        f32x4 wq[2][3];
 #pragma unroll
-        for (int pos = 0; pos < 16; ++pos)
+        for (int m = 0; m < 3; ++m) wq[0][m] = ldsA(J, 0, m);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int m = 0; m < 3; ++m) {
-                const f32x4 wa = *reinterpret_cast<const f32x4*>(ub + ((pos * 3 + j) * 3 + m) * 256);
+        for (int pos = 0; pos < 16; ++pos) {
+            if (pos + 1 < 16) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const f32x4 c = (first && i == 0) ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[pos][m];
-                    acc[pos][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[i], v[pos][i], c, 0, 0, 0);
-                }
+                for (int m = 0; m < 3; ++m) wq[(pos + 1) & 1][m] = ldsA(J, pos + 1, m);
             }
+            if (pos >= 8) transform_slice(pb[Y], pos - 8);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int m = 0; m < 3; ++m) {
+                    const f32x4 c = (first && i == 0) ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[pos][m];
+                    acc[pos][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[pos & 1][m][i], pb[X][pos][i], c, 0, 0, 0);
+                }
+            __builtin_amdgcn_sched_barrier(0);
+        }
     };
 
     int unit = blockIdx.x;
-    UnitPos cur;
+    UnitPos cur, nxt;
     locate(unit, cur);
-    offsets(cur);
-    __amdgpu_buffer_rsrc_t ir =
-        __builtin_amdgcn_make_buffer_rsrc((void*)(a.in + (size_t)cur.b * a.H * a.W * kF), 0, in_bytes, 0x00020000);
-    load_patch(p0, ir, 0);
+    load_patch(pb[0], cur, 0);
+#pragma unroll
+    for (int sl = 0; sl < 8; ++sl) transform_slice(pb[0], sl);
 
-#pragma unroll 1
-    for (; unit < a.ntiles; unit += gridDim.x) {
-        // ---- partial sums / residuals of this unit go out first (consumed in the epilogue)
-        const int oyp = 2 * cur.ty, oxp = 2 * cur.tx;          // first output pixel of the tile
-        f32x4 pin[ACC_IN ? 12 : 1];
-        if constexpr (ACC_IN) {
-            __amdgpu_buffer_rsrc_t pr = __builtin_amdgcn_make_buffer_rsrc(
-                (void*)(a.acc_in + (size_t)cur.b * a.H * a.W * kF), 0, in_bytes, 0x00020000);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int y = oyp + (q >> 1), x = oxp + (q & 1);
-                const unsigned o = (y < a.H && x < a.W) ? (unsigned)(((y * a.W + x) * kF + 4 * g) * 4) : 0x80000000u;
-#pragma unroll
-                for (int m = 0; m < 3; ++m) pin[q * 3 + m] = bload(pr, o + 64 * m);
-            }
-        }
-        // ---- chunk 0: p0 is in flight; fetch chunk 1 into p1
-        load_patch(p1, ir, 1);
-        __builtin_amdgcn_sched_barrier(0);
-        input_transform(p0);
-        mfma_chunk(p0, 0, true);
-        __builtin_amdgcn_sched_barrier(0);
-        // ---- chunk 1: fetch chunk 2 into p0
-        load_patch(p0, ir, 2);
-        __builtin_amdgcn_sched_barrier(0);
-        input_transform(p1);
-        mfma_chunk(p1, 1, false);
-        __builtin_amdgcn_sched_barrier(0);
-        // ---- chunk 2: fetch chunk 0 of the NEXT unit into p1
-        const UnitPos done = cur;
-        const int next = unit + gridDim.x;
-        if (next < a.ntiles) {
-            locate(next, cur);
-            offsets(cur);
-            ir = __builtin_amdgcn_make_buffer_rsrc((void*)(a.in + (size_t)cur.b * a.H * a.W * kF), 0, in_bytes,
-                                                   0x00020000);
-            load_patch(p1, ir, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        input_transform(p0);
-        mfma_chunk(p0, 2, false);
-        __builtin_amdgcn_sched_barrier(0);
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+
+    // one unit; PC = buffer that holds its transformed chunk 0 (the parity flips every unit)
+    auto run_unit = [&](auto PC) {
+        constexpr int P = decltype(PC)::value;
+        using XP = std::integral_constant<int, P>;
+        using XQ = std::integral_constant<int, 1 - P>;
+        locate(unit + gridDim.x, nxt);       // past the end: every pixel out of range -> zeros, stores dropped
+        if (unit + (int)gridDim.x >= a.ntiles) nxt.ty = 1 << 20;
+        stage(I0{}, XP{}, true, cur, 1);
+        stage(I1{}, XQ{}, false, cur, 2);
+        stage(I2{}, XP{}, false, nxt, 0);
 
         // ---- output transform A^T M A, epilogue, stores
         __amdgpu_buffer_rsrc_t orr = __builtin_amdgcn_make_buffer_rsrc(
-            (void*)(a.out + (size_t)done.b * a.Hout * a.Wout * kF), 0, out_bytes, 0x00020000);
-        const int oy = 2 * done.ty, ox = 2 * done.tx;
-        f32x4 res[EPI == EPI_RELU_ADD2 ? 24 : 1];
-        if constexpr (EPI == EPI_RELU_ADD2) {
-            __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(
-                (void*)(a.res1 + (size_t)done.b * a.H * a.W * kF), 0, in_bytes, 0x00020000);
-            __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc(
-                (void*)(a.res2 + (size_t)done.b * a.H * a.W * kF), 0, in_bytes, 0x00020000);
+            (void*)(a.out + (size_t)cur.b * a.Hout * a.Wout * kF), 0, out_bytes, 0x00020000);
+        __amdgpu_buffer_rsrc_t pr = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)((ACC_IN ? a.acc_in : a.in) + (size_t)cur.b * a.H * a.W * kF), 0, in_bytes, 0x00020000);
+        __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)((EPI == EPI_RELU_ADD2 ? a.res1 : a.in) + (size_t)cur.b * a.H * a.W * kF), 0, in_bytes, 0x00020000);
+        __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)((EPI == EPI_RELU_ADD2 ? a.res2 : a.in) + (size_t)cur.b * a.H * a.W * kF), 0, in_bytes, 0x00020000);
+        const int oy = 2 * cur.ty, ox = 2 * cur.tx;
+        unsigned po[4], so[4];     // per output pixel q = 2*row+col: offsets in the input-size map / in `out`
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int y = oy + (q >> 1), x = ox + (q & 1);
-                const unsigned o = (y < a.H && x < a.W) ? (unsigned)(((y * a.W + x) * kF + 4 * g) * 4) : 0x80000000u;
-#pragma unroll
-                for (int m = 0; m < 3; ++m) {
-                    res[(q * 3 + m) * 2] = bload(r1, o + 64 * m);
-                    res[(q * 3 + m) * 2 + 1] = bload(r2, o + 64 * m);
-                }
-            }
+        for (int q = 0; q < 4; ++q) {
+            const int yy = oy + (q >> 1), xx = ox + (q & 1);
+            const bool ok = yy < a.H && xx < a.W;
+            po[q] = ok ? (unsigned)(((yy * a.W + xx) * kF + 4 * g) * 4) : 0x80000000u;
+            so[q] = ok ? (unsigned)((((yy + a.oy) * a.Wout + xx + a.ox) * kF + 4 * g) * 4) : 0x80000000u;
         }
 #pragma unroll
         for (int m = 0; m < 3; ++m) {
+            f32x4 pin[4], ra[4], rb[4];
+            if constexpr (ACC_IN) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) pin[q] = bload(pr, po[q] + 64 * m);
+            }
+            if constexpr (EPI == EPI_RELU_ADD2) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    ra[q] = bload(r1, po[q] + 64 * m);
+                    rb[q] = bload(r2, po[q] + 64 * m);
+                }
+            }
             f32x4 s0[4], s1[4];
 #pragma unroll
             for (int x = 0; x < 4; ++x) {
@@ -220,15 +235,15 @@ __global__ __launch_bounds__(256, 1) void wino3x3_kernel(ConvArgs a) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 y[q] = y[q] + bv[m];
-                if constexpr (ACC_IN) y[q] = y[q] + pin[q * 3 + m];
+                if constexpr (ACC_IN) y[q] = y[q] + pin[q];
             }
             if constexpr (EPI == EPI_POOL) {
                 // MaxPool2d(2) of the un-activated conv output = max over the tile's 2x2 pixels
                 f32x4 v;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = fmaxf(fmaxf(y[0][r], y[1][r]), fmaxf(y[2][r], y[3][r]));
-                const bool ok = done.ty < a.Hout && done.tx < a.Wout;
-                bstore(orr, ok ? (unsigned)(((done.ty * a.Wout + done.tx) * kF + 16 * m + 4 * g) * 4) : 0x80000000u, v);
+                const bool ok = cur.ty < a.Hout && cur.tx < a.Wout;
+                bstore(orr, ok ? (unsigned)(((cur.ty * a.Wout + cur.tx) * kF + 16 * m + 4 * g) * 4) : 0x80000000u, v);
             } else {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
@@ -237,21 +252,22 @@ __global__ __launch_bounds__(256, 1) void wino3x3_kernel(ConvArgs a) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
                     }
-                    if constexpr (EPI == EPI_RELU_ADD2)
-                        v = (res[(q * 3 + m) * 2] + res[(q * 3 + m) * 2 + 1]) + v;   // e3 + d1 + d2 (unet.py:563-566)
-                    const int yy = oy + (q >> 1), xx = ox + (q & 1);
-                    const bool ok = yy < a.H && xx < a.W;
-                    bstore(orr,
-                           ok ? (unsigned)((((yy + a.oy) * a.Wout + xx + a.ox) * kF + 16 * m + 4 * g) * 4)
-                              : 0x80000000u,
-                           v);
+                    if constexpr (EPI == EPI_RELU_ADD2) v = (ra[q] + rb[q]) + v;   // e3 + d1 + d2 (unet.py:563-566)
+                    bstore(orr, so[q] + 64 * m, v);
                 }
             }
         }
-        // hand the prefetched patch over (p1 -> p0): the loop body is not unrolled, so the
-        // ping-pong parity is restored with 64 moves per unit (~1 % of the unit's cycles)
-#pragma unroll
-        for (int k = 0; k < 16; ++k) p0[k] = p1[k];
+        cur = nxt;
+    };
+
+#pragma unroll 1
+    for (;;) {
+        run_unit(I0{});
+        unit += gridDim.x;
+        if (unit >= a.ntiles) break;
+        run_unit(I1{});
+        unit += gridDim.x;
+        if (unit >= a.ntiles) break;
     }
 }
 
