@@ -39,23 +39,35 @@ __device__ __forceinline__ void bstore(__amdgpu_buffer_rsrc_t r, unsigned off, f
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, off, 0, 0);
 }
 
+// a - b as two v_pk_add_f32 with negated second operand: hipcc selects v_pk_add_f32 for vector
+// adds but four scalar v_sub_f32 for vector subtractions, and on gfx950 the f32 MFMA shares the
+// SIMD's f32 lanes with the VALU (VALU work is NOT hidden behind f32 MFMAs: measured, a finely
+// interleaved schedule ran slower than a clumped one), so every VALU instruction saved counts.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x4 sub4(f32x4 a, f32x4 b) {
+    f32x2 lo, hi;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(lo) : "v"(f32x2{a[0], a[1]}), "v"(f32x2{b[0], b[1]}));
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(hi) : "v"(f32x2{a[2], a[3]}), "v"(f32x2{b[2], b[3]}));
+    return f32x4{lo[0], lo[1], hi[0], hi[1]};
+}
+
 // B^T d B in place on a 4x4 patch of float4 (p[y*4+x]), in 8 slices so that the caller can
 // spread it between MFMA groups: slices 0..3 = column pass (x = slice), 4..7 = row pass.
 __device__ __forceinline__ void transform_slice(f32x4 (&p)[16], int sl) {
     if (sl < 4) {
         const int x = sl;
         const f32x4 d0 = p[x], d1 = p[4 + x], d2 = p[8 + x], d3 = p[12 + x];
-        p[x] = d0 - d2;
+        p[x] = sub4(d0, d2);
         p[4 + x] = d1 + d2;
-        p[8 + x] = d2 - d1;
-        p[12 + x] = d1 - d3;
+        p[8 + x] = sub4(d2, d1);
+        p[12 + x] = sub4(d1, d3);
     } else {
         const int y = sl - 4;
         const f32x4 t0 = p[4 * y], t1 = p[4 * y + 1], t2 = p[4 * y + 2], t3 = p[4 * y + 3];
-        p[4 * y] = t0 - t2;
+        p[4 * y] = sub4(t0, t2);
         p[4 * y + 1] = t1 + t2;
-        p[4 * y + 2] = t2 - t1;
-        p[4 * y + 3] = t1 - t3;
+        p[4 * y + 2] = sub4(t2, t1);
+        p[4 * y + 3] = sub4(t1, t3);
     }
 }
 
@@ -225,13 +237,13 @@ __global__ __launch_bounds__(256, 1) void wino3x3_kernel(ConvArgs a) {
 #pragma unroll
             for (int x = 0; x < 4; ++x) {
                 s0[x] = (acc[x][m] + acc[4 + x][m]) + acc[8 + x][m];
-                s1[x] = (acc[4 + x][m] - acc[8 + x][m]) - acc[12 + x][m];
+                s1[x] = sub4(sub4(acc[4 + x][m], acc[8 + x][m]), acc[12 + x][m]);
             }
             f32x4 y[4];   // q = 2*row + col
             y[0] = (s0[0] + s0[1]) + s0[2];
-            y[1] = (s0[1] - s0[2]) - s0[3];
+            y[1] = sub4(sub4(s0[1], s0[2]), s0[3]);
             y[2] = (s1[0] + s1[1]) + s1[2];
-            y[3] = (s1[1] - s1[2]) - s1[3];
+            y[3] = sub4(sub4(s1[1], s1[2]), s1[3]);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 y[q] = y[q] + bv[m];
