@@ -90,12 +90,6 @@ __global__ __launch_bounds__(256, 1) void wino3x3_kernel(ConvArgs a) {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lds_void*)(U + k * 256), 16, (unsigned)(k * 1024 + lane * 16),
                                                      0, 0, 0);
     }
-    f32x4 bv[3];
-#pragma unroll
-    for (int m = 0; m < 3; ++m) {
-        if constexpr (ACC_IN) bv[m] = f32x4{0.f, 0.f, 0.f, 0.f};
-        else bv[m] = *reinterpret_cast<const f32x4*>(a.bias + 16 * m + 4 * g);
-    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
@@ -157,23 +151,36 @@ __global__ __launch_bounds__(256, 1) void wino3x3_kernel(ConvArgs a) {
         constexpr int Y = 1 - X;
         load_patch(pb[Y], ld_u, ld_j);
         f32x4 wq[2][3];
+        // Position order: the accumulators that are SEEDED instead of zeroed come last, so that the
+        // loads that seed them (issued at the start of the unit) have eleven steps to land:
+        //   position (1,1) <- bias:        A^T M A with only M11 = b is b on all four outputs;
+        //   the four corners <- the partial sums of the first 48 input channels (two-pass 96->48
+        //   convs): M00 = P00, M03 = -P01, M30 = -P10, M33 = P11 give exactly Y += P.
+        // Neither costs an epilogue add.
+        constexpr int ORD[16] = {1, 2, 4, 6, 7, 8, 9, 10, 11, 13, 14, 5, 0, 3, 12, 15};
 #pragma unroll
-        for (int m = 0; m < 3; ++m) wq[0][m] = ldsA(J, 0, m);
+        for (int m = 0; m < 3; ++m) wq[0][m] = ldsA(J, ORD[0], m);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int pos = 0; pos < 16; ++pos) {
-            if (pos + 1 < 16) {
+        for (int st = 0; st < 16; ++st) {
+            const int pos = ORD[st];
+            const bool seeded = ACC_IN ? (pos == 0 || pos == 3 || pos == 12 || pos == 15) : pos == 5;
+            if (st + 1 < 16) {
 #pragma unroll
-                for (int m = 0; m < 3; ++m) wq[(pos + 1) & 1][m] = ldsA(J, pos + 1, m);
+                for (int m = 0; m < 3; ++m) wq[(st + 1) & 1][m] = ldsA(J, ORD[st + 1], m);
             }
-            if (pos >= 8) transform_slice(pb[Y], pos - 8);
+            if (st >= 8) transform_slice(pb[Y], st - 8);
+            if (first && ACC_IN && (pos == 3 || pos == 12)) {
+#pragma unroll
+                for (int m = 0; m < 3; ++m) acc[pos][m] = -acc[pos][m];
+            }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int m = 0; m < 3; ++m) {
-                    const f32x4 c = (first && i == 0) ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[pos][m];
-                    acc[pos][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[pos & 1][m][i], pb[X][pos][i], c, 0, 0, 0);
+                    const f32x4 c = (first && i == 0 && !seeded) ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[pos][m];
+                    acc[pos][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[st & 1][m][i], pb[X][pos][i], c, 0, 0, 0);
                 }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -197,6 +204,22 @@ __global__ __launch_bounds__(256, 1) void wino3x3_kernel(ConvArgs a) {
         using XQ = std::integral_constant<int, 1 - P>;
         locate(unit + gridDim.x, nxt);       // past the end: every pixel out of range -> zeros, stores dropped
         if (unit + (int)gridDim.x >= a.ntiles) nxt.ty = 1 << 20;
+        // seeds of this unit's accumulators (see the position order in `stage`)
+        if constexpr (ACC_IN) {
+            __amdgpu_buffer_rsrc_t pr = __builtin_amdgcn_make_buffer_rsrc(
+                (void*)(a.acc_in + (size_t)cur.b * a.H * a.W * kF), 0, in_bytes, 0x00020000);
+            constexpr int corner[4] = {0, 3, 12, 15};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int yy = 2 * cur.ty + (q >> 1), xx = 2 * cur.tx + (q & 1);
+                const unsigned o = (yy < a.H && xx < a.W) ? (unsigned)(((yy * a.W + xx) * kF + 4 * g) * 4) : 0x80000000u;
+#pragma unroll
+                for (int m = 0; m < 3; ++m) acc[corner[q]][m] = bload(pr, o + 64 * m);
+            }
+        } else {
+#pragma unroll
+            for (int m = 0; m < 3; ++m) acc[5][m] = *reinterpret_cast<const f32x4*>(a.bias + 16 * m + 4 * g);
+        }
         stage(I0{}, XP{}, true, cur, 1);
         stage(I1{}, XQ{}, false, cur, 2);
         stage(I2{}, XP{}, false, nxt, 0);
@@ -204,8 +227,6 @@ __global__ __launch_bounds__(256, 1) void wino3x3_kernel(ConvArgs a) {
         // ---- output transform A^T M A, epilogue, stores
         __amdgpu_buffer_rsrc_t orr = __builtin_amdgcn_make_buffer_rsrc(
             (void*)(a.out + (size_t)cur.b * a.Hout * a.Wout * kF), 0, out_bytes, 0x00020000);
-        __amdgpu_buffer_rsrc_t pr = __builtin_amdgcn_make_buffer_rsrc(
-            (void*)((ACC_IN ? a.acc_in : a.in) + (size_t)cur.b * a.H * a.W * kF), 0, in_bytes, 0x00020000);
         __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(
             (void*)((EPI == EPI_RELU_ADD2 ? a.res1 : a.in) + (size_t)cur.b * a.H * a.W * kF), 0, in_bytes, 0x00020000);
         __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc(
@@ -221,11 +242,7 @@ __global__ __launch_bounds__(256, 1) void wino3x3_kernel(ConvArgs a) {
         }
 #pragma unroll
         for (int m = 0; m < 3; ++m) {
-            f32x4 pin[4], ra[4], rb[4];
-            if constexpr (ACC_IN) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) pin[q] = bload(pr, po[q] + 64 * m);
-            }
+            f32x4 ra[4], rb[4];
             if constexpr (EPI == EPI_RELU_ADD2) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
@@ -244,11 +261,6 @@ __global__ __launch_bounds__(256, 1) void wino3x3_kernel(ConvArgs a) {
             y[1] = sub4(sub4(s0[1], s0[2]), s0[3]);
             y[2] = (s1[0] + s1[1]) + s1[2];
             y[3] = sub4(sub4(s1[1], s1[2]), s1[3]);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                y[q] = y[q] + bv[m];
-                if constexpr (ACC_IN) y[q] = y[q] + pin[q];
-            }
             if constexpr (EPI == EPI_POOL) {
                 // MaxPool2d(2) of the un-activated conv output = max over the tile's 2x2 pixels
                 f32x4 v;
