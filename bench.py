@@ -56,7 +56,7 @@ def main():
     ap.add_argument("--config", default="C2", choices=sorted(CONFIGS))
     ap.add_argument("--batch", type=int, default=4, help="sequences advanced in lockstep per GPU")
     ap.add_argument("--frames", type=int, default=0, help="override frames per sequence")
-    ap.add_argument("--cpu-frames", type=int, default=3, help="frames of the CPU-oracle sample (0 = skip)")
+    ap.add_argument("--cpu-frames", type=int, default=8, help="frames of the CPU-oracle sample (0 = skip)")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--all-kernel-events", action="store_true",
                     help="diagnostic: bracket EVERY launch of every kernel (costs ~6 %% of the frame rate); "

@@ -209,31 +209,53 @@ __global__ void warp3_kernel(const float* __restrict__ src4, const float* __rest
     o[2] = acc[2];
 }
 
-// 12 threads per pixel, one float4 (4 channels) each
-__global__ void warp48_kernel(const float* __restrict__ src, const float* __restrict__ flow_raw,
-                              float* __restrict__ dst, int B, int H, int W) {
-    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const size_t pix = gid / 12;
-    const int c4 = gid - pix * 12;
-    if (pix >= (size_t)B * H * W) return;
-    const int x = pix % W;
-    const int y = (pix / W) % H;
+// 192 threads = 16 pixels x 12 float4 chunks.  The 16 taps of a pixel (flow upsample, coordinate
+// round trip, cubic weights: ~150 VALU instructions) are computed ONCE per pixel by the first 16
+// threads and shared through LDS; computed by each of the 12 lanes of a pixel they cost as much
+// SIMD time as the gather itself.
+__global__ __launch_bounds__(192) void warp48_kernel(const float* __restrict__ src,
+                                                     const float* __restrict__ flow_raw,
+                                                     float* __restrict__ dst, int B, int H, int W) {
+    __shared__ int s_i[16][8];      // xi[4], yi[4]
+    __shared__ float s_w[16][8];    // wx[4], wy[4]
+    const size_t npix = (size_t)B * H * W;
+    const size_t pix0 = (size_t)blockIdx.x * 16;
+    if (threadIdx.x < 16) {
+        const size_t pix = pix0 + threadIdx.x;
+        if (pix < npix) {
+            const int x = pix % W;
+            const int y = (pix / W) % H;
+            const int b = pix / ((size_t)W * H);
+            const int h = H / 2, w = W / 2;
+            float fx, fy;
+            flow_at(flow_raw + (size_t)b * 2 * h * w, h, w, H, W, y, x, fx, fy);
+            Taps t;
+            make_taps(fx, fy, x, y, H, W, t);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                s_i[threadIdx.x][k] = t.xi[k];
+                s_i[threadIdx.x][4 + k] = t.yi[k] * W;
+                s_w[threadIdx.x][k] = t.wx[k];
+                s_w[threadIdx.x][4 + k] = t.wy[k];
+            }
+        }
+    }
+    __syncthreads();
+    const int p = threadIdx.x / 12;
+    const int c4 = threadIdx.x - p * 12;
+    const size_t pix = pix0 + p;
+    if (pix >= npix) return;
     const int b = pix / ((size_t)W * H);
-    const int h = H / 2, w = W / 2;
-    float fx, fy;
-    flow_at(flow_raw + (size_t)b * 2 * h * w, h, w, H, W, y, x, fx, fy);
-    Taps t;
-    make_taps(fx, fy, x, y, H, W, t);
     const f32x4* s = reinterpret_cast<const f32x4*>(src) + (size_t)b * H * W * 12 + c4;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         f32x4 row = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int i = 0; i < 4; ++i) row = row + s[((size_t)t.yi[j] * W + t.xi[i]) * 12] * t.wx[i];
-        acc = acc + row * t.wy[j];
+        for (int i = 0; i < 4; ++i) row = row + s[(size_t)(s_i[p][4 + j] + s_i[p][i]) * 12] * s_w[p][i];
+        acc = acc + row * s_w[p][4 + j];
     }
-    reinterpret_cast<f32x4*>(dst)[gid] = acc;
+    reinterpret_cast<f32x4*>(dst)[pix * 12 + c4] = acc;
 }
 
 __global__ void warp_nchw_kernel(const float* __restrict__ xin, const float* __restrict__ flow,
@@ -464,8 +486,8 @@ hipError_t launch_warp3(const float* src4, const float* flow_raw, float* dst, in
 
 hipError_t launch_warp48(const float* src, const float* flow_raw, float* dst, int B, int H, int W,
                          hipStream_t s) {
-    const size_t n = (size_t)B * H * W * 12;
-    hipLaunchKernelGGL(warp48_kernel, dim3(nblocks(n, 192)), dim3(192), 0, s, src, flow_raw, dst, B, H, W);
+    const size_t npix = (size_t)B * H * W;
+    hipLaunchKernelGGL(warp48_kernel, dim3(nblocks(npix, 16)), dim3(192), 0, s, src, flow_raw, dst, B, H, W);
     return hipGetLastError();
 }
 

@@ -329,10 +329,11 @@ const char* conv_name(int cin, int epi, bool acc) {
 }
 
 const char* wino_name(int epi, bool acc) {
-    static const char* names[4][2] = {{"wino3x3_kernel<0, false>", "wino3x3_kernel<0, true>"},
+    static const char* names[5][2] = {{"wino3x3_kernel<0, false>", "wino3x3_kernel<0, true>"},
                                       {"wino3x3_kernel<1, false>", "wino3x3_kernel<1, true>"},
                                       {"wino3x3_kernel<2, false>", "wino3x3_kernel<2, true>"},
-                                      {"wino3x3_kernel<3, false>", "wino3x3_kernel<3, true>"}};
+                                      {"wino3x3_kernel<3, false>", "wino3x3_kernel<3, true>"},
+                                      {"wino3x3_kernel<4, false>", "wino3x3_kernel<4, true>"}};
     return names[epi][acc];
 }
 
@@ -347,7 +348,13 @@ struct ConvCall {
     float* out = nullptr;
     int H = 0, W = 0;        // conv domain
     int Hout = 0, Wout = 0, oy = 0, ox = 0;
+    float* out3_nchw = nullptr;    // EPI_RELU_OUT3 targets
+    float* out3_nhwc4 = nullptr;
 };
+
+bool wino_applies(const rvdd_t* h, int H, int W) {
+    return h->use_wino && (h->force_wino || h->cfg.batch * ((W + 31) / 32) * ((H + 7) / 8) >= 200);
+}
 
 int run_conv(rvdd_t* h, const Conv3& L, const ConvCall& c, hipStream_t s) {
     ConvArgs a{};
@@ -381,8 +388,11 @@ int run_conv(rvdd_t* h, const Conv3& L, const ConvCall& c, hipStream_t s) {
     if (c.epi == EPI_RELU_ADD2) bytes += px * 384.0;
     // Winograd needs enough 8x32-pixel units to fill the chip (its 144 KiB filter bank is loaded once
     // per workgroup); the 1/8-resolution level of a single 720p sequence (60 units) runs faster direct
-    const int wino_units = a.B * ((c.W + 31) / 32) * ((c.H + 7) / 8);
-    if (h->use_wino && cin == 48 && L.wu[c.src] && (wino_units >= 200 || h->force_wino)) {
+    a.w3 = h->w_out;
+    a.b3 = h->b_out;
+    a.out3_nchw = c.out3_nchw;
+    a.out3_nhwc4 = c.out3_nhwc4;
+    if (cin == 48 && L.wu[c.src] && wino_applies(h, c.H, c.W)) {
         a.w = L.wu[c.src];
         Scope sc(h, s, wino_name(c.epi, c.acc_in != nullptr), flops, bytes);
         HIPCHK(h, launch_wino3x3(a, c.epi, s));
@@ -468,6 +478,13 @@ int run_convunet(rvdd_t* h, const float* netin, const float* featw, float* feat_
     }
     // ---- post: hooked 48-ch map = next frame's features (:808-812), then 1x1 -> 3
     float* fdst = feat_dst ? feat_dst : lv[0].t[2];
+    if (wino_applies(h, lv[0].H, lv[0].W)) {
+        // PostConvs[1] (1x1, 48 -> 3) rides in the epilogue of PostConvs[0]'s Winograd kernel
+        ConvCall c;
+        c.in = d; c.out = fdst; c.H = lv[0].H; c.W = lv[0].W; c.epi = EPI_RELU_OUT3;
+        c.out3_nchw = out_nchw; c.out3_nhwc4 = out_nhwc4;
+        return run_conv(h, L("PostConvs.0.0"), c, s);
+    }
     RC(conv("PostConvs.0.0", d, fdst, 0, EPI_RELU));
     {
         const double px = (double)B * h->cfg.height * h->cfg.width;

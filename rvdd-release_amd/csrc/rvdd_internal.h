@@ -12,7 +12,8 @@ constexpr int kF = 48;        // feature channels everywhere (filters=48)
 constexpr int kNetInC = 16;   // padded channel count of the network input map
 
 // ---------------------------------------------------------------- conv3x3 --
-enum ConvEpi { EPI_NONE = 0, EPI_RELU = 1, EPI_POOL = 2, EPI_RELU_ADD2 = 3 };
+// EPI_RELU_OUT3 (Winograd kernel only): ReLU, store the 48-channel map AND apply the final 1x1 conv 48->3
+enum ConvEpi { EPI_NONE = 0, EPI_RELU = 1, EPI_POOL = 2, EPI_RELU_ADD2 = 3, EPI_RELU_OUT3 = 4 };
 
 struct ConvArgs {
     const float* in;      // NHWC [B][H][W][CIN]
@@ -26,6 +27,11 @@ struct ConvArgs {
     int Hout, Wout;       // size of the map `out` points to
     int oy, ox;           // placement of the conv output inside it (zero_pad_features)
     int tiles_x, tiles_y, ntiles;
+    // EPI_RELU_OUT3: PostConvs[1] (networks/unet.py:713-720) fused into PostConvs[0]'s epilogue
+    const float* w3;      // [3][48]
+    const float* b3;      // [3]
+    float* out3_nchw;     // [B][3][H][W]
+    float* out3_nhwc4;    // [B][H][W][4] copy for the next frame's warp, or nullptr
 };
 
 // cin = 16 or 48.  Returns hipGetLastError().

@@ -240,6 +240,11 @@ __global__ __launch_bounds__(256, 1) void wino3x3_kernel(ConvArgs a) {
             po[q] = ok ? (unsigned)(((yy * a.W + xx) * kF + 4 * g) * 4) : 0x80000000u;
             so[q] = ok ? (unsigned)((((yy + a.oy) * a.Wout + xx + a.ox) * kF + 4 * g) * 4) : 0x80000000u;
         }
+        float o3[4][3];      // EPI_RELU_OUT3: this lane's share of the 1x1 conv, per output pixel q and channel
+        if constexpr (EPI == EPI_RELU_OUT3) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) o3[q][0] = o3[q][1] = o3[q][2] = 0.f;
+        }
 #pragma unroll
         for (int m = 0; m < 3; ++m) {
             f32x4 ra[4], rb[4];
@@ -272,12 +277,42 @@ __global__ __launch_bounds__(256, 1) void wino3x3_kernel(ConvArgs a) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     f32x4 v = y[q];
-                    if constexpr (EPI == EPI_RELU || EPI == EPI_RELU_ADD2) {
+                    if constexpr (EPI == EPI_RELU || EPI == EPI_RELU_ADD2 || EPI == EPI_RELU_OUT3) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
                     }
                     if constexpr (EPI == EPI_RELU_ADD2) v = (ra[q] + rb[q]) + v;   // e3 + d1 + d2 (unet.py:563-566)
                     bstore(orr, so[q] + 64 * m, v);
+                    if constexpr (EPI == EPI_RELU_OUT3) {
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) {
+                            const f32x4 w = *reinterpret_cast<const f32x4*>(a.w3 + c * kF + 16 * m + 4 * g);
+                            o3[q][c] += (v[0] * w[0] + v[1] * w[1]) + (v[2] * w[2] + v[3] * w[3]);
+                        }
+                    }
+                }
+            }
+        }
+        if constexpr (EPI == EPI_RELU_OUT3) {
+            // sum the four channel groups (lanes l, l^16, l^32, l^48), add the bias, lane group 0 stores
+            const size_t hw = (size_t)a.H * a.W;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float t[3];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    float v = o3[q][c];
+                    v += __shfl_xor(v, 16);
+                    v += __shfl_xor(v, 32);
+                    t[c] = v + a.b3[c];
+                }
+                const int yy = oy + (q >> 1), xx = ox + (q & 1);
+                if (g == 0 && yy < a.H && xx < a.W) {
+                    const size_t pidx = (size_t)yy * a.W + xx;
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) a.out3_nchw[((size_t)cur.b * 3 + c) * hw + pidx] = t[c];
+                    if (a.out3_nhwc4)
+                        reinterpret_cast<f32x4*>(a.out3_nhwc4)[(size_t)cur.b * hw + pidx] = f32x4{t[0], t[1], t[2], 0.f};
                 }
             }
         }
@@ -335,6 +370,8 @@ hipError_t launch_wino3x3(const ConvArgs& a, int epi, hipStream_t s) {
             return acc ? hipErrorInvalidValue : launch_w<EPI_POOL, false>(a, s);
         case EPI_RELU_ADD2:
             return acc ? hipErrorInvalidValue : launch_w<EPI_RELU_ADD2, false>(a, s);
+        case EPI_RELU_OUT3:
+            return acc ? hipErrorInvalidValue : launch_w<EPI_RELU_OUT3, false>(a, s);
     }
     return hipErrorInvalidValue;
 }
