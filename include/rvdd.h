@@ -128,6 +128,14 @@ int rvdd_warp_bicubic(rvdd_t* h, const float* x, const float* flow, int32_t n, i
 int rvdd_upsample_factor_2(rvdd_t* h, const float* t, int32_t n, int32_t c, int32_t hh, int32_t ww,
                            float multiply_by, float* out, void* stream);
 
+/* library.CPPbridge.TVL1_flow -> libBridge `tvl1flow(I0, I1, u, nx, ny)` (libBridge.cpp:44-163): Dual TV-L1
+ * optical flow with the reference's hard-wired parameters (3rdparty/tvl1flow/tvl1flow_lib.c:91-278, 343-472).
+ *   I0, I1 [ny,nx] gray images; u [2,ny,nx] = x displacement then y displacement (libBridge.cpp:150) such
+ *   that I1(x + u) ~ I0(x).  `iterations` (HOST, nullable) receives the total primal-dual iterations run.
+ * Synchronises `stream` every few iterations (the convergence test lives on the device, the host peeks). */
+int rvdd_tvl1flow(rvdd_t* h, const float* I0, const float* I1, float* u, int32_t nx, int32_t ny,
+                  int32_t* iterations, void* stream);
+
 /* ---- measurement ----------------------------------------------------------- */
 
 /* When enabled, every launch of the U-Net kernels is bracketed by HIP events

@@ -80,6 +80,7 @@ struct rvdd_handle {
     double* loss_result = nullptr;
     float* scratch = nullptr;
     size_t scratch_bytes = 0;
+    Tvl1Workspace* tvl1 = nullptr;   // cached for the last (nx, ny)
 
     // measurement
     bool prof_on = false;
@@ -594,6 +595,7 @@ void rvdd_destroy(rvdd_t* h) {
     (void)hipDeviceSynchronize();
     for (void* p : h->allocs) (void)hipFree(p);
     if (h->scratch) (void)hipFree(h->scratch);
+    tvl1_free(h->tvl1);
     for (auto& p : h->pending) {
         (void)hipEventDestroy(p.e0);
         (void)hipEventDestroy(p.e1);
@@ -785,6 +787,21 @@ int rvdd_upsample_factor_2(rvdd_t* h, const float* t, int32_t n, int32_t c, int3
                            float multiply_by, float* out, void* stream) {
     if (!h || !t || !out || n < 0 || c < 1 || hh < 1 || ww < 1) return fail(h, RVDD_ERR_ARG, "rvdd_upsample_factor_2: bad argument");
     HIPCHK(h, launch_upsample_flow(t, out, n * c, hh, ww, multiply_by, static_cast<hipStream_t>(stream)));
+    return RVDD_OK;
+}
+
+int rvdd_tvl1flow(rvdd_t* h, const float* I0, const float* I1, float* u, int32_t nx, int32_t ny, int32_t* iterations,
+                  void* stream) {
+    if (!h || !I0 || !I1 || !u || nx < 16 || ny < 16) return fail(h, RVDD_ERR_ARG, "rvdd_tvl1flow: bad argument (images must be >= 16x16)");
+    if (!h->tvl1 || tvl1_ws_nx(h->tvl1) != nx || tvl1_ws_ny(h->tvl1) != ny) {
+        HIPCHK(h, hipDeviceSynchronize());
+        tvl1_free(h->tvl1);
+        h->tvl1 = nullptr;
+        HIPCHK(h, tvl1_alloc(&h->tvl1, nx, ny));
+    }
+    int it = 0;
+    HIPCHK(h, tvl1_run(h->tvl1, I0, I1, u, static_cast<hipStream_t>(stream), iterations ? &it : nullptr));
+    if (iterations) *iterations = it;
     return RVDD_OK;
 }
 

@@ -104,3 +104,13 @@ hipError_t launch_proj1x1(const float* in1, int c1, const float* in2, int c2, co
 // zero_pad_features: src [B][h][w] -> dst [B][H][W] at (oy,ox), zeros elsewhere (NHWC48)
 hipError_t launch_pad_copy(const float* src, float* dst, int B, int h, int w, int H, int W, int oy, int ox,
                            hipStream_t s);
+
+// ------------------------------------------------------------------ TV-L1 --
+struct Tvl1Workspace;
+hipError_t tvl1_alloc(Tvl1Workspace** out, int nx, int ny);
+void tvl1_free(Tvl1Workspace* w);
+int tvl1_num_scales(int nx, int ny);
+// I0, I1 [ny][nx] -> u [2][ny][nx]; synchronises the stream every few iterations (convergence peek)
+hipError_t tvl1_run(Tvl1Workspace* w, const float* I0, const float* I1, float* u, hipStream_t st, int* total_iters);
+int tvl1_ws_nx(const Tvl1Workspace* w);
+int tvl1_ws_ny(const Tvl1Workspace* w);

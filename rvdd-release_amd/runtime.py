@@ -170,6 +170,17 @@ class RvddRuntime:
                                                     _ptr(out), self._stream()), "rvdd_upsample_factor_2")
         return out
 
+    def tvl1flow(self, I0: torch.Tensor, I1: torch.Tensor, want_iterations: bool = False):
+        """[ny,nx] x2 -> flow [2,ny,nx] (libBridge tvl1flow, libBridge.cpp:44)."""
+        ny, nx = I0.shape
+        I0 = _chk_dev(I0, (ny, nx), "I0")
+        I1 = _chk_dev(I1, (ny, nx), "I1")
+        u = torch.empty(2, ny, nx, dtype=torch.float32, device=I0.device)
+        it = C.c_int32(0)
+        self._check(self.lib.rvdd_tvl1flow(self.h, _ptr(I0), _ptr(I1), _ptr(u), nx, ny,
+                                           C.byref(it) if want_iterations else None, self._stream()), "rvdd_tvl1flow")
+        return (u, int(it.value)) if want_iterations else u
+
     # -- measurement ------------------------------------------------------------
     def profile_enable(self, on: bool):
         self._check(self.lib.rvdd_profile_enable(self.h, 1 if on else 0), "rvdd_profile_enable")

@@ -1,0 +1,92 @@
+"""TV-L1 optical flow: the numpy oracle against flows produced by the
+reference's own native code (golden fixtures; and live against oracle/_ref/libBridge.so where that
+build exists), and the HIP path against both.
+
+The reference sums its convergence error with an OpenMP reduction and compares it with a hard
+threshold, so its own result moves in the 5th digit with the thread count; tolerances: max-abs
+2e-3 px / mean-abs 1e-4 px on flows of a few pixels (observed: 3e-5 / 2e-6)."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import tvl1_oracle as T
+from conftest import GOLDEN, REPO
+
+CASES = ["a_48x64", "b_40x72", "c_33x47", "d_90x160"]
+REF_LIB = os.path.join(REPO, "oracle", "_ref", "libBridge.so")
+
+
+def _load(name):
+    return np.load(os.path.join(GOLDEN, f"tvl1_{name}.npz"))
+
+
+def _close(a, b):
+    d = np.abs(a - b)
+    assert d.max() < 2e-3 and d.mean() < 1e-4, (float(d.max()), float(d.mean()))
+
+
+@pytest.mark.parametrize("name", CASES[:3])
+def test_oracle_matches_reference_flow(name):
+    g = _load(name)
+    _close(T.tvl1flow(g["I0"], g["I1"]), g["flow"])
+
+
+@pytest.mark.skipif(not os.path.exists(REF_LIB), reason="oracle/_ref not built (build container only)")
+def test_oracle_matches_live_reference_library():
+    lib = ctypes.CDLL(REF_LIB)
+    lib.tvl1flow.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int] * 2
+    lib.tvl1flow.restype = None
+    rng = np.random.default_rng(7)
+    h, w = 37, 53
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
+    I0 = (np.sin(0.3 * xx) * np.cos(0.2 * yy) + 0.05 * rng.standard_normal((h, w))).astype(np.float32)
+    I1 = (np.sin(0.3 * (xx - 0.8)) * np.cos(0.2 * (yy + 1.3)) + 0.05 * rng.standard_normal((h, w))).astype(np.float32)
+    u = np.zeros(2 * h * w, np.float32)
+    lib.tvl1flow(I0.ctypes.data, I1.ctypes.data, u.ctypes.data, w, h)
+    _close(T.tvl1flow(I0, I1), u.reshape(2, h, w))
+
+
+def test_oracle_pieces():
+    # zoom sizes and scale count as the C code computes them (zoom.c:22-34, libBridge.cpp:131-136)
+    assert T.zoom_size(640, 360, 0.5) == (320, 180) and T.zoom_size(45, 23, 0.5) == (23, 12)
+    assert T.num_scales(640, 360) == 6 and T.num_scales(64, 48) == 3 and T.num_scales(16, 16) == 1
+    # the quirk: the previous row follows the sign of the COLUMN coordinate
+    img = np.arange(30, dtype=np.float32).reshape(5, 6) ** 2
+    v = T.bicubic_at(img, np.array([-0.4], np.float32), np.array([2.5], np.float32), False)
+    assert np.isfinite(v).all()
+    # divergence is the negative adjoint of the forward gradient
+    rng = np.random.default_rng(0)
+    f, p1, p2 = (rng.standard_normal((9, 11)).astype(np.float32) for _ in range(3))
+    fx, fy = T.forward_gradient(f)
+    assert abs(float((fx * p1 + fy * p2).sum() + (f * T.divergence(p1, p2)).sum())) < 1e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", CASES)
+def test_hip_flow_matches_reference_flow(name):
+    from rvdd_release_amd.util._ops import ops_runtime
+    g = _load(name)
+    rt = ops_runtime(0)
+    u, iters = rt.tvl1flow(torch.from_numpy(g["I0"]).cuda(), torch.from_numpy(g["I1"]).cuda(), want_iterations=True)
+    assert iters > 10
+    _close(u.cpu().numpy(), g["flow"])
+
+
+@pytest.mark.gpu
+def test_hip_flow_matches_oracle_and_bridge_surface():
+    from rvdd_release_amd.library import CPPbridge
+    rng = np.random.default_rng(11)
+    h, w = 52, 76
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
+    raw0 = np.stack([np.sin(0.21 * xx + k) + np.cos(0.17 * yy) for k in range(4)], -1).astype(np.float32)
+    raw1 = np.stack([np.sin(0.21 * (xx + 1.2) + k) + np.cos(0.17 * (yy - 0.6)) for k in range(4)], -1).astype(np.float32)
+    raw0 += 0.03 * rng.standard_normal(raw0.shape).astype(np.float32)
+    raw1 += 0.03 * rng.standard_normal(raw1.shape).astype(np.float32)
+    flow = CPPbridge('./build/libBridge.so').TVL1_flow(raw0, raw1)        # reference call shape (library.py:150)
+    assert flow.shape == (h, w, 2) and flow.dtype == np.float32
+    want = T.TVL1_flow(raw0, raw1)
+    _close(flow, want)
+    assert abs(np.median(flow[..., 0]) + 1.2) < 0.1 and abs(np.median(flow[..., 1]) - 0.6) < 0.1
