@@ -182,8 +182,8 @@ constexpr int M_NPB = 1;                       // 16-pixel groups per wave itera
 
 // nn.GELU() default = exact erf form (networks/new_unet.py:94): 0.5 v (1 + erf(v/sqrt2)).
 // On gfx950 the f32 MFMA and the VALU share the SIMD's fp32 lanes, so the 192 GELUs per pixel are not
-// hidden behind the MFMAs: this single-branch form costs 16 instructions instead of 27 for the
-// two-branch <1-ulp erf above.  erf(v/sqrt2) = sign(v) (1 - 2^(t P(t))), t = min(|v|, 6.36), P a
+// hidden behind the MFMAs: this single-branch form costs 16 instructions instead of 27 for a
+// two-branch <1-ulp erf (and ocml's erff, inlined 48x per lane, spilled 260 registers).  erf(v/sqrt2) = sign(v) (1 - 2^(t P(t))), t = min(|v|, 6.36), P a
 // degree-7 polynomial fitted (weighted least squares, host, float32 Horner) to log2 erfc(t/sqrt2)/t:
 // max |GELU error| 4.3e-7 on [-9, 9] against the double-precision erf form (fp32 rounding of the
 // exact form is ~2e-7 there).

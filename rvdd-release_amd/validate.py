@@ -1,0 +1,75 @@
+"""The validation loop of the reference (validate.py:16-114) on the HIP runtime, minus file I/O:
+`compute_validation(model, val_dataset, opt)` drives `set_input` / `test` / `compute_losses` per
+output frame, latches `FirstOfVideo` on a change of video folder, and -- with
+`opt.val_flow_from_denoised` -- recomputes the optical flow online from the previous DENOISED frame
+(`compute_flows_from_denoised`, validate.py:16-38): remosaick -> TV-L1 -> backward flow, all on the
+device (`rvdd_tvl1flow`).
+
+`val_dataset` is any iterable of the dicts the reference's `infer4recDataset` yields
+(data/infer4rec_dataset.py:226-230): 'n' [1,(2+f)*4,h,w], 'gt' [1,6,H,W], 'flow' [1,1+f,2,h,w],
+'n_path', 'gt_path'.
+"""
+from __future__ import annotations
+
+from os.path import dirname
+from typing import Callable, Dict, Iterable, Optional
+
+import torch
+
+from .util._ops import ops_runtime
+from .util.Hamilton_Adam_demo import HamiltonAdam
+
+
+def compute_flows_from_denoised(data: dict, model, opt) -> None:
+    """validate.py:16-38.  The flow goes from the last noisy frame of `data['n']` to the
+    remosaicked previous output; the reference repeats it `opt.patch_depth - 1` times (it passes the
+    training patch depth there), which is kept so that `data['flow']` has the reference's shape."""
+    if getattr(opt, "future_patch_depth", 0):
+        raise NotImplementedError("rvdd: --val_flow_from_denoised with a future frame is not built "
+                                  "(the reference pairs the NEXT frame with the previous output there)")
+    dev = model.device
+    ha = HamiltonAdam('gbrg')
+    img2 = data['n'][0, -4:, :, :].to(dev, torch.float32)                  # last noisy frame, packed raw
+    img1 = ha.remosaick(model.denoised.to(dev))[0]                          # previous output, re-mosaicked
+    # singleiT = (x+1)/2 as an [h,w,c] image (library.py:67-68); CPPbridge takes the channel mean
+    g2 = ((img2 + 1.0) / 2.0).mean(dim=0).contiguous()
+    g1 = ((img1 + 1.0) / 2.0).mean(dim=0).contiguous()
+    flow = ops_runtime(dev.index or 0).tvl1flow(g2, g1)                     # TVL1_flow(img2, img1): img1(x+u) ~ img2(x)
+    reps = max(1, opt.patch_depth - 1)
+    data['flow'] = flow[None].repeat(reps, 1, 1, 1).unsqueeze(0)
+
+
+def compute_validation(model, val_dataset: Iterable[Dict], opt, on_frame: Optional[Callable] = None) -> dict:
+    """validate.py:54-114 without the image dump: returns {'L1_valLoss', 'PSNR_valLoss',
+    'Denoiser_valLoss', 'lr'}.  `on_frame(i, data, visuals, losses)` replaces save_images/print_dict."""
+    val_flow_from_denoised = False if model.isTrain else getattr(opt, "val_flow_from_denoised", False)
+    bak_isTrain = model.isTrain
+    model.isTrain = False
+    model.eval()
+    val_losses = model.get_current_losses().copy()
+    for k in val_losses:
+        val_losses[k] = 0.0
+    count = 0
+    with torch.no_grad():
+        lastvideopath = ''
+        for i, data in enumerate(val_dataset):
+            thisvideopath = dirname(data['gt_path'][0])
+            data['FirstOfVideo'] = not thisvideopath == lastvideopath
+            if (not opt.no_warp) and val_flow_from_denoised and not data['FirstOfVideo']:
+                compute_flows_from_denoised(data, model, opt)
+            model.set_input(data)
+            model.test()
+            model.compute_losses()
+            losses = model.get_current_losses()
+            if on_frame is not None:
+                on_frame(i, data, model.get_current_visuals(), losses)
+            lastvideopath = thisvideopath
+            for k, v in losses.items():
+                val_losses[k] += v
+            count += 1
+    for k in val_losses:
+        val_losses[k] /= max(count, 1)
+    out = dict([(k + "_valLoss", v) for k, v in val_losses.items()])
+    out['lr'] = model.optimizers[0].param_groups[0]['lr']
+    model.isTrain = bak_isTrain
+    return out
