@@ -22,8 +22,10 @@ from .util.Hamilton_Adam_demo import HamiltonAdam
 
 def compute_flows_from_denoised(data: dict, model, opt) -> None:
     """validate.py:16-38.  The flow goes from the last noisy frame of `data['n']` to the
-    remosaicked previous output; the reference repeats it `opt.patch_depth - 1` times (it passes the
-    training patch depth there), which is kept so that `data['flow']` has the reference's shape."""
+    remosaicked previous output.  The released reference cannot actually run this branch (it hands
+    `remosaick` a squeezed 3-D tensor, validate.py:29-31 vs util/Hamilton_Adam_demo.py:237-238, and
+    appends the same flow `opt.patch_depth - 1` times); this is its evident intent: ONE flow, shaped
+    like the dataset's `data['flow']` ([1,1,2,h,w])."""
     if getattr(opt, "future_patch_depth", 0):
         raise NotImplementedError("rvdd: --val_flow_from_denoised with a future frame is not built "
                                   "(the reference pairs the NEXT frame with the previous output there)")
@@ -35,8 +37,7 @@ def compute_flows_from_denoised(data: dict, model, opt) -> None:
     g2 = ((img2 + 1.0) / 2.0).mean(dim=0).contiguous()
     g1 = ((img1 + 1.0) / 2.0).mean(dim=0).contiguous()
     flow = ops_runtime(dev.index or 0).tvl1flow(g2, g1)                     # TVL1_flow(img2, img1): img1(x+u) ~ img2(x)
-    reps = max(1, opt.patch_depth - 1)
-    data['flow'] = flow[None].repeat(reps, 1, 1, 1).unsqueeze(0)
+    data['flow'] = flow[None, None]
 
 
 def compute_validation(model, val_dataset: Iterable[Dict], opt, on_frame: Optional[Callable] = None) -> dict:
