@@ -136,6 +136,28 @@ int rvdd_upsample_factor_2(rvdd_t* h, const float* t, int32_t n, int32_t c, int3
 int rvdd_tvl1flow(rvdd_t* h, const float* I0, const float* I1, float* u, int32_t nx, int32_t ny,
                   int32_t* iterations, void* stream);
 
+/* dataset/fwd_ppipe.py `ppipe(im, rgb_gain, red_gain, blue_gain, iso)` (:48-77) fused with the range
+ * normalisation in front of it (:131-137) and the uint8 conversion behind it (:141): linear camera RGB ->
+ * display sRGB (inverse percentile matching per ISO, black level, white-balance gains, inverse CCM,
+ * gamma 1/2.2, smoothstep tone curve, x255).
+ *   img        n images of 3 channels, element (i,c,y,x) at img[i*stride_n + c*stride_c + y*stride_y + x*stride_x]
+ *              (NCHW network output or the HWC image validate.py writes -- both are strides);
+ *   bit_depth  fwd_ppipe.py --bit_depth: 0 ([0,1]), 8 ([0,255]), 10, anything else = already [0,4095];
+ *              RVDD_PPIPE_FROM_NET (-1) = network output in [-1,1]: util/util.py:40 (tensor2im) then the 8-bit branch;
+ *   gains      the three values fwd_ppipe.py:116-118 passes (rgb_gain = 1/n from the white-balance table);
+ *   out_u8     [n,H,W,3] uint8 (what the reference writes to *_processed_pipeline.png);
+ *   out_f32    [n,H,W,3] float32 = ppipe()'s return value before rounding; may be NULL. */
+#define RVDD_PPIPE_FROM_NET (-1)
+int rvdd_ppipe(rvdd_t* h, const float* img, int32_t n, int32_t height, int32_t width, int64_t stride_n,
+               int64_t stride_c, int64_t stride_y, int64_t stride_x, int32_t bit_depth, double rgb_gain,
+               double red_gain, double blue_gain, int32_t iso, uint8_t* out_u8, float* out_f32, void* stream);
+
+/* dataset/fwd_ppipe.py `psnr(img1, img2)` (:79-84) and `ssim` (:86, skimage.metrics.structural_similarity with
+ * multichannel=True, data_range=255: 7x7 uniform window, sample covariance, 3-pixel border cropped) on uint8
+ * [n,H,W,3] images.  psnr / ssim: HOST arrays of n doubles (either may be NULL).  H, W >= 7.  Synchronous. */
+int rvdd_srgb_metrics(rvdd_t* h, const uint8_t* a, const uint8_t* b, int32_t n, int32_t height, int32_t width,
+                      double* psnr, double* ssim, void* stream);
+
 /* ---- measurement ----------------------------------------------------------- */
 
 /* When enabled, every launch of the U-Net kernels is bracketed by HIP events

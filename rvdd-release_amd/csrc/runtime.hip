@@ -805,6 +805,37 @@ int rvdd_tvl1flow(rvdd_t* h, const float* I0, const float* I1, float* u, int32_t
     return RVDD_OK;
 }
 
+int rvdd_ppipe(rvdd_t* h, const float* img, int32_t n, int32_t H, int32_t W, int64_t sn, int64_t sc, int64_t sy, int64_t sx,
+               int32_t bit_depth, double rgb_gain, double red_gain, double blue_gain, int32_t iso, uint8_t* out_u8,
+               float* out_f32, void* stream) {
+    if (!h || !img || !out_u8 || n < 0 || H < 1 || W < 1) return fail(h, RVDD_ERR_ARG, "rvdd_ppipe: bad argument");
+    if (!(rgb_gain != 0.0) || !(red_gain != 0.0) || !(blue_gain != 0.0)) return fail(h, RVDD_ERR_ARG, "rvdd_ppipe: zero gain");
+    // fwd_ppipe.py:29: a float32 tensor of Python-double quotients
+    const float gains[3] = {(float)(1.0 / (red_gain * rgb_gain)), (float)(1.0 / rgb_gain), (float)(1.0 / (blue_gain * rgb_gain))};
+    HIPCHK(h, launch_ppipe(img, n, H, W, sn, sc, sy, sx, bit_depth, gains, iso, out_u8, out_f32, static_cast<hipStream_t>(stream)));
+    return RVDD_OK;
+}
+
+int rvdd_srgb_metrics(rvdd_t* h, const uint8_t* a, const uint8_t* b, int32_t n, int32_t H, int32_t W, double* psnr,
+                      double* ssim, void* stream) {
+    if (!h || !a || !b || n < 1) return fail(h, RVDD_ERR_ARG, "rvdd_srgb_metrics: bad argument");
+    if (H < 7 || W < 7) return fail(h, RVDD_ERR_ARG, "rvdd_srgb_metrics: win_size exceeds image extent (images must be >= 7x7)");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    RC(ensure_scratch(h, srgb_metrics_workspace(n, H, W)));
+    HIPCHK(h, launch_srgb_metrics(a, b, n, H, W, h->scratch, s));
+    std::vector<unsigned long long> ssd(n);
+    std::vector<double> sums(n);
+    HIPCHK(h, hipMemcpyAsync(ssd.data(), h->scratch, (size_t)n * 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipMemcpyAsync(sums.data(), reinterpret_cast<char*>(h->scratch) + (size_t)n * 8, (size_t)n * 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipStreamSynchronize(s));
+    for (int i = 0; i < n; ++i) {
+        // mean((a/255 - b/255)^2) = SSD / 255^2 / count; 10 log10(1 / 0) = inf as in numpy
+        if (psnr) psnr[i] = 10.0 * std::log10(1.0 / ((double)ssd[i] / (255.0 * 255.0) / ((double)H * W * 3)));
+        if (ssim) ssim[i] = sums[i] / (3.0 * (double)(H - 6) * (double)(W - 6));
+    }
+    return RVDD_OK;
+}
+
 int rvdd_profile_enable(rvdd_t* h, int32_t on) {
     if (!h) return RVDD_ERR_ARG;
     RC(prof_flush(h));

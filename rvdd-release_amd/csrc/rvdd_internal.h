@@ -105,6 +105,12 @@ hipError_t launch_proj1x1(const float* in1, int c1, const float* in2, int c2, co
 hipError_t launch_pad_copy(const float* src, float* dst, int B, int h, int w, int H, int W, int oy, int ox,
                            hipStream_t s);
 
+// srgb.hip -- sRGB post-processing + display-domain metrics (dataset/fwd_ppipe.py)
+hipError_t launch_ppipe(const float* img, int n, int H, int W, int64_t sn, int64_t sc, int64_t sy, int64_t sx, int bit_depth,
+                        const float gains[3], int iso, uint8_t* out_u8, float* out_f32, hipStream_t s);
+size_t srgb_metrics_workspace(int n, int H, int W);
+hipError_t launch_srgb_metrics(const uint8_t* a, const uint8_t* b, int n, int H, int W, void* ws, hipStream_t s);
+
 // ------------------------------------------------------------------ TV-L1 --
 struct Tvl1Workspace;
 hipError_t tvl1_alloc(Tvl1Workspace** out, int nx, int ny);

@@ -32,3 +32,79 @@ class CPPbridge(object):
         g2 = b.to(dev, torch.float32).mean(dim=2).contiguous()
         flow = self.rt.tvl1flow(g1, g2)
         return flow.permute(1, 2, 0).contiguous().cpu().numpy()
+
+
+# ---- file helpers of library.py (host side; no arithmetic beyond the [0,1] scaling) -----------------
+import fnmatch  # noqa: E402
+import os  # noqa: E402
+
+from . import tiffio  # noqa: E402
+
+
+def iio_read(path):
+    """library.py:75-77.  TIFF through rvdd's own reader, 8-bit formats (png, jpg) through Pillow;
+    always [H,W,C] like iio."""
+    if path.lower().endswith(('.tif', '.tiff')):
+        return tiffio.read(path)
+    from PIL import Image
+    return np.atleast_3d(np.array(Image.open(path)))
+
+
+def iio_write(arr, path):
+    """library.py:71-73 (note the argument order)."""
+    if path.lower().endswith(('.tif', '.tiff')):
+        return tiffio.write(path, arr)
+    from PIL import Image
+    a = np.asarray(arr)
+    Image.fromarray(a[:, :, 0] if a.ndim == 3 and a.shape[2] == 1 else a).save(path)
+
+
+def get_files_pattern(d, pattern):
+    """library.py:95-102."""
+    return sorted(fnmatch.filter(os.listdir(d), pattern))
+
+
+def list_video_files_at_dir(d):
+    """library.py:104-117: the first extension that matches anything wins."""
+    for pattern in ('*tiff', '*tif', '*png', '*jpg', '*jpeg', '*raw'):
+        paths = get_files_pattern(d, pattern)
+        if len(paths) > 0:
+            return [os.path.join(d, p) for p in paths]
+    raise AssertionError("%s is empty!" % d)
+
+
+def load_image(path, ftype=8):
+    """library.py:119-131: image scaled to [0,1] by its bit depth, float32."""
+    return np.asarray(iio_read(path), dtype=np.float32) / (2 ** float(ftype) - 1)
+
+
+def pathdiff(a, b):
+    """library.py:134-140."""
+    assert a[:len(b)] == b, "b should be a subfolder/subfile of a"
+    res = os.path.dirname(a[len(b):])
+    return res[1:] if res[0] == '/' else res
+
+
+def warpedimagefile(wfolder, fromCode, toCode):
+    """library.py:142-143."""
+    return os.path.join(wfolder, fromCode + '_' + toCode + '.tif')
+
+
+def print_dict(val_losses, suffix="_valLoss", savefile=None):
+    """library.py:21-30."""
+    message = "[" + ", ".join('%s: %.3f' % (k + suffix, v) for k, v in val_losses.items()) + "]"
+    print(message)
+    if savefile is not None:
+        with open(savefile, "a") as log_file:
+            log_file.write('%s\n' % message)
+
+
+def define_transforms(opt=None):
+    """library.py:52-69: T = ToTensor (HWC ndarray -> CHW tensor, no scaling for float input) then
+    2x - 1; iT = (x + 1)/2 back to an [H,W,C] ndarray."""
+    def T(x):
+        return 2. * torch.from_numpy(np.ascontiguousarray(np.asarray(x).transpose(2, 0, 1))) - 1.
+
+    def iT(x):
+        return ((x + 1.) / 2.).permute(1, 2, 0).numpy()
+    return T, iT

@@ -181,6 +181,43 @@ class RvddRuntime:
                                            C.byref(it) if want_iterations else None, self._stream()), "rvdd_tvl1flow")
         return (u, int(it.value)) if want_iterations else u
 
+    def ppipe(self, img: torch.Tensor, rgb_gain: float, red_gain: float, blue_gain: float, iso: int,
+              bit_depth: int, layout: str = "nchw", want_float: bool = False):
+        """dataset/fwd_ppipe.py:48-77,131-141.  img [n,3,H,W] ("nchw") or [n,H,W,3] ("hwc"), any strides.
+        -> uint8 [n,H,W,3] (and the float32 sRGB x 255 image before rounding)."""
+        if not img.is_cuda or img.dtype != torch.float32 or img.dim() != 4:
+            raise RuntimeError("ppipe: img must be a 4-D float32 GPU tensor (rvdd has no CPU path)")
+        if layout == "nchw":
+            n, c, H, W = img.shape
+            sn, sc, sy, sx = img.stride()
+        elif layout == "hwc":
+            n, H, W, c = img.shape
+            sn, sy, sx, sc = img.stride()
+        else:
+            raise ValueError("layout must be 'nchw' or 'hwc'")
+        if c != 3:
+            raise AssertionError("The data should have 3 channels.")              # fwd_ppipe.py:129
+        u8 = torch.empty(n, H, W, 3, dtype=torch.uint8, device=img.device)
+        f32 = torch.empty(n, H, W, 3, dtype=torch.float32, device=img.device) if want_float else None
+        self._check(self.lib.rvdd_ppipe(self.h, _ptr(img), n, H, W, sn, sc, sy, sx, int(bit_depth), float(rgb_gain),
+                                        float(red_gain), float(blue_gain), int(iso), _ptr(u8), _ptr(f32),
+                                        self._stream()), "rvdd_ppipe")
+        return (u8, f32) if want_float else u8
+
+    def srgb_metrics(self, a: torch.Tensor, b: torch.Tensor):
+        """dataset/fwd_ppipe.py:79-86 on uint8 [n,H,W,3] images -> (psnr[n], ssim[n]) Python floats."""
+        if a.shape != b.shape:
+            raise RuntimeError(f"srgb_metrics: shapes differ: {tuple(a.shape)} vs {tuple(b.shape)}")
+        if not (a.is_cuda and b.is_cuda) or a.dtype != torch.uint8 or b.dtype != torch.uint8 or a.dim() != 4 \
+                or a.shape[3] != 3:
+            raise RuntimeError("srgb_metrics: a, b must be uint8 GPU tensors [n,H,W,3]")
+        a, b = a.contiguous(), b.contiguous()
+        n, H, W, _ = a.shape
+        ps, ss = (C.c_double * n)(), (C.c_double * n)()
+        self._check(self.lib.rvdd_srgb_metrics(self.h, _ptr(a), _ptr(b), n, H, W, ps, ss, self._stream()),
+                    "rvdd_srgb_metrics")
+        return list(ps), list(ss)
+
     # -- measurement ------------------------------------------------------------
     def profile_enable(self, on: bool):
         self._check(self.lib.rvdd_profile_enable(self.h, 1 if on else 0), "rvdd_profile_enable")

@@ -11,7 +11,7 @@ device (`rvdd_tvl1flow`).
 """
 from __future__ import annotations
 
-from os.path import dirname
+from os.path import basename, dirname, join
 from typing import Callable, Dict, Iterable, Optional
 
 import torch
@@ -40,9 +40,29 @@ def compute_flows_from_denoised(data: dict, model, opt) -> None:
     data['flow'] = flow[None, None]
 
 
-def compute_validation(model, val_dataset: Iterable[Dict], opt, on_frame: Optional[Callable] = None) -> dict:
-    """validate.py:54-114 without the image dump: returns {'L1_valLoss', 'PSNR_valLoss',
-    'Denoiser_valLoss', 'lr'}.  `on_frame(i, data, visuals, losses)` replaces save_images/print_dict."""
+def init_validation_dataloader(opt):
+    """validate.py:40-52."""
+    import copy
+    from .data import create_dataset
+    opt_val = copy.deepcopy(opt)
+    opt_val.dataroot = opt.val_dataroot
+    opt_val.dataset_mode = opt.val_dataset_mode
+    opt_val.max_dataset_size = float("inf")
+    opt_val.videos = opt.val_videos
+    opt_val.num_threads = 0
+    opt_val.batch_size = 1
+    opt_val.serial_batches = True
+    if hasattr(opt, 'model_patch_depth'):
+        opt_val.patch_depth = opt.model_patch_depth
+    return create_dataset(opt_val)
+
+
+def compute_validation(model, val_dataset: Iterable[Dict], opt, on_frame: Optional[Callable] = None,
+                       val_image_dir: Optional[str] = None) -> dict:
+    """validate.py:54-114: returns {'L1_valLoss', 'PSNR_valLoss', 'Denoiser_valLoss', 'lr'}.
+    With `val_image_dir` (and a dataset made by `create_dataset`) every frame is written to
+    <val_image_dir>/<video>/<frame>_denoised.tif and its losses appended to output.log, as the
+    reference does; `on_frame(i, data, visuals, losses)` is an in-memory hook beside that."""
     val_flow_from_denoised = False if model.isTrain else getattr(opt, "val_flow_from_denoised", False)
     bak_isTrain = model.isTrain
     model.isTrain = False
@@ -64,6 +84,15 @@ def compute_validation(model, val_dataset: Iterable[Dict], opt, on_frame: Option
             losses = model.get_current_losses()
             if on_frame is not None:
                 on_frame(i, data, model.get_current_visuals(), losses)
+            if val_image_dir is not None:
+                from .library import pathdiff, print_dict
+                from .util.visualizer import save_images
+                img_path = model.get_image_paths()
+                if i % 40 == 0:
+                    print('processing (%04d)-th image... %s' % (i, img_path))
+                sfolder = pathdiff(img_path[0], val_dataset.dataset.n_paths)
+                save_images(val_image_dir, model.get_current_visuals(), [basename(img_path[0])], subfolder=sfolder)
+                print_dict(losses, suffix="", savefile=join(val_image_dir, "output.log"))
             lastvideopath = thisvideopath
             for k, v in losses.items():
                 val_losses[k] += v
@@ -74,3 +103,29 @@ def compute_validation(model, val_dataset: Iterable[Dict], opt, on_frame: Option
     out['lr'] = model.optimizers[0].param_groups[0]['lr']
     model.isTrain = bak_isTrain
     return out
+
+
+def main(argv=None) -> dict:
+    """validate.py:117-153: options -> dataset -> model -> validation -> averaged losses."""
+    import time
+    from .models import create_model
+    from .options import parse
+    opt = parse(argv)
+    val_dataset = init_validation_dataloader(opt)
+    print('Number of validation images = %d' % len(val_dataset))
+    val_image_dir = join(opt.checkpoints_dir, opt.name, "val_visuals")
+    model = create_model(opt)
+    model.setup(opt)
+    opt.isTrain = False
+    model.isTrain = False
+    t0 = time.time()
+    val_losses = compute_validation(model, val_dataset, opt, val_image_dir=val_image_dir)
+    dt = time.time() - t0
+    print('c --------------------------------------- ')
+    print('(validation, %d images, %.3f s, %.2f frames/s) ' % (len(val_dataset), dt, len(val_dataset) / max(dt, 1e-9))
+          + ', '.join('%s: %.3f' % kv for kv in val_losses.items()))
+    return val_losses
+
+
+if __name__ == '__main__':
+    main()

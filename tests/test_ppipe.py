@@ -1,0 +1,167 @@
+"""sRGB post-processing + display-domain PSNR/SSIM: the CPU oracle against
+vectors produced by the reference's own dataset/fwd_ppipe.py (tools/make_golden_ppipe.py), and the
+HIP path (rvdd_ppipe / rvdd_srgb_metrics) against both.
+
+Tolerances.  The float sRGB image (x255) is a chain of ~20 fp32 operations with a pow(); the HIP
+kernel follows the reference's operation order with contraction off and differs only in powf and the
+3x3 matrix accumulation order: |diff| <= 2e-3 relative to max(|value|, 255) (observed ~1e-5).  The
+uint8 image can therefore differ by one level where the float value sits on a rounding boundary: at
+most 0.1 % of samples off by exactly 1, none by more.  PSNR on uint8 is exact integer arithmetic up
+to the final float64 division/log: 1e-9 dB.  SSIM: 1e-9."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import ppipe_oracle as P
+from conftest import GOLDEN, REPO
+
+CASES = sorted(os.path.basename(p)[6:-4] for p in glob.glob(os.path.join(GOLDEN, "ppipe_*.npz"))
+               if "bitdepth" not in p)
+BITDEPTH = [0, 10, 12]
+
+
+def _gains(seq, iso):
+    from rvdd_release_amd.ppipe import find_gains
+    n, red, blue = find_gains(seq, iso)
+    return 1 / n, red, blue
+
+
+def test_cases_present():
+    assert len(CASES) == 6
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_oracle_matches_reference(name):
+    g = np.load(os.path.join(GOLDEN, f"ppipe_{name}.npz"))
+    img = P.tensor2im(torch.from_numpy(g["x"]))
+    assert np.array_equal(img, g["tif"])
+    srgb = P.ppipe(P.normalise_bit_depth(img, 8), *_gains(int(g["seq"]), int(g["iso"])), int(g["iso"]))
+    assert np.array_equal(srgb, g["srgb"])                      # same torch build, same ops: bit-exact
+    assert np.array_equal(P.to_uint8(srgb), g["u8"])
+    assert abs(P.psnr_u8(g["u8"], g["gt_u8"]) - float(g["psnr"])) < 1e-12
+
+
+@pytest.mark.parametrize("bd", BITDEPTH)
+def test_oracle_bit_depths(bd):
+    g = np.load(os.path.join(GOLDEN, f"ppipe_bitdepth{bd}.npz"))
+    srgb = P.ppipe(P.normalise_bit_depth(g["img"], bd), *_gains(int(g["seq"]), int(g["iso"])), int(g["iso"]))
+    assert np.array_equal(srgb, g["srgb"])
+
+
+def test_ssim_analytic():
+    rng = np.random.default_rng(0)
+    a = rng.integers(0, 256, (24, 31, 3)).astype(np.uint8)
+    assert abs(P.ssim(a, a) - 1.0) < 1e-12
+    # two constant images: variances vanish, SSIM = (2ab + C1) / (a^2 + b^2 + C1)
+    x = np.full((16, 16, 3), 100, np.uint8)
+    y = np.full((16, 16, 3), 140, np.uint8)
+    C1 = (0.01 * 255) ** 2
+    assert abs(P.ssim(x, y) - (2 * 100 * 140 + C1) / (100 ** 2 + 140 ** 2 + C1)) < 1e-12
+    # brute-force window statistics on one interior pixel of a small random pair
+    b = rng.integers(0, 256, (9, 9, 1)).astype(np.uint8)
+    c = rng.integers(0, 256, (9, 9, 1)).astype(np.uint8)
+    tot = []
+    for cy in range(3, 6):
+        for cx in range(3, 6):
+            X = b[cy - 3:cy + 4, cx - 3:cx + 4, 0].astype(np.float64).ravel()
+            Y = c[cy - 3:cy + 4, cx - 3:cx + 4, 0].astype(np.float64).ravel()
+            ux, uy = X.mean(), Y.mean()
+            vx, vy, vxy = X.var(ddof=1), Y.var(ddof=1), ((X - ux) * (Y - uy)).sum() / 48
+            C2 = (0.03 * 255) ** 2
+            tot.append((2 * ux * uy + C1) * (2 * vxy + C2) / ((ux * ux + uy * uy + C1) * (vx + vy + C2)))
+    assert abs(P.ssim(b, c) - np.mean(tot)) < 1e-10
+
+
+def test_find_gains_table():
+    from rvdd_release_amd.ppipe import find_gains, WHITE_BALANCE
+    assert len(WHITE_BALANCE) == 30
+    assert find_gains(0, 3200) == [0.8236, 2.2221, 3.3301]      # dataset/fwd_ppipe.py:12, :43-46
+    assert find_gains(0, 12800) == [0.7092, 1.9675, 3.6828]
+    assert find_gains(29, 100) == find_gains(29, 12800)        # anything but 3200 takes the first entry
+
+
+# ------------------------------------------------------------------------------------------------ GPU
+
+def _close_srgb(got, want):
+    tol = 2e-3 * np.maximum(np.abs(want), 255.0) / 255.0
+    d = np.abs(got - want)
+    assert (d <= tol).all(), float((d / tol).max())
+
+
+def _close_u8(got, want):
+    d = np.abs(got.astype(np.int32) - want.astype(np.int32))
+    assert d.max() <= 1 and (d != 0).mean() <= 1e-3, (int(d.max()), float((d != 0).mean()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", CASES)
+def test_hip_ppipe_matches_reference(name):
+    from rvdd_release_amd.ppipe import ppipe
+    g = np.load(os.path.join(GOLDEN, f"ppipe_{name}.npz"))
+    x = torch.from_numpy(g["x"]).cuda()
+    u8, f32 = ppipe(x, *_gains(int(g["seq"]), int(g["iso"])), int(g["iso"]), bit_depth=-1, want_float=True)
+    assert u8.shape == (1,) + g["u8"].shape and u8.dtype == torch.uint8
+    _close_srgb(f32[0].cpu().numpy(), g["srgb"])
+    _close_u8(u8[0].cpu().numpy(), g["u8"])
+    # the saved-image entry (HWC float in [0,255], what fwd_ppipe.py reads back from *_denoised.tif)
+    u8b, f32b = ppipe(torch.from_numpy(g["tif"]).cuda()[None], *_gains(int(g["seq"]), int(g["iso"])), int(g["iso"]),
+                      bit_depth=8, layout="hwc", want_float=True)
+    _close_srgb(f32b[0].cpu().numpy(), g["srgb"])
+    _close_u8(u8b[0].cpu().numpy(), g["u8"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bd", BITDEPTH)
+def test_hip_ppipe_bit_depths(bd):
+    from rvdd_release_amd.ppipe import ppipe
+    g = np.load(os.path.join(GOLDEN, f"ppipe_bitdepth{bd}.npz"))
+    u8, f32 = ppipe(torch.from_numpy(g["img"]).cuda()[None], *_gains(int(g["seq"]), int(g["iso"])), int(g["iso"]),
+                    bit_depth=bd, layout="hwc", want_float=True)
+    _close_srgb(f32[0].cpu().numpy(), g["srgb"])
+    _close_u8(u8[0].cpu().numpy(), g["u8"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(1, 40, 56), (3, 33, 47), (2, 7, 7), (1, 720, 1280)])
+def test_hip_metrics_match_oracle(shape):
+    from rvdd_release_amd.ppipe import srgb_metrics
+    n, H, W = shape
+    rng = np.random.default_rng(n * 1000 + H)
+    a = rng.integers(0, 256, (n, H, W, 3)).astype(np.uint8)
+    noise = rng.integers(-20, 21, a.shape)
+    b = np.clip(a.astype(np.int32) + noise, 0, 255).astype(np.uint8)
+    b[0, : H // 2] = a[0, : H // 2]                               # flat agreement region
+    psnr, ssim = srgb_metrics(torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda())
+    for i in range(n):
+        assert abs(psnr[i] - P.psnr_u8(a[i], b[i])) < 1e-9
+        assert abs(ssim[i] - P.ssim(a[i], b[i])) < 1e-9
+    p2, s2 = srgb_metrics(torch.from_numpy(a).cuda(), torch.from_numpy(a).cuda())
+    assert all(np.isinf(p2)) and all(abs(s - 1.0) < 1e-12 for s in s2)
+
+
+@pytest.mark.gpu
+def test_hip_metrics_reject_small_or_mismatched():
+    from rvdd_release_amd.ppipe import srgb_metrics
+    a = torch.zeros(1, 6, 9, 3, dtype=torch.uint8, device="cuda")
+    with pytest.raises(RuntimeError):
+        srgb_metrics(a, a)                                       # smaller than the 7x7 window (skimage raises too)
+    with pytest.raises(RuntimeError):
+        srgb_metrics(torch.zeros(1, 8, 9, 3, dtype=torch.uint8, device="cuda"),
+                     torch.zeros(1, 9, 9, 3, dtype=torch.uint8, device="cuda"))
+
+
+@pytest.mark.gpu
+def test_hip_ppipe_full_size_properties():
+    """720p: per-pixel independence (a crop equals the crop of the full result) and batch consistency."""
+    from rvdd_release_amd.ppipe import ppipe
+    gen = torch.Generator().manual_seed(3)
+    x = (torch.rand(2, 3, 720, 1280, generator=gen) * 2.2 - 1.1).cuda()
+    gains = _gains(4, 3200)
+    full = ppipe(x, *gains, 3200, bit_depth=-1)
+    crop = ppipe(x[:, :, 100:164, 200:328].contiguous(), *gains, 3200, bit_depth=-1)
+    assert torch.equal(full[:, 100:164, 200:328], crop)
+    one = ppipe(x[1:2].contiguous(), *gains, 3200, bit_depth=-1)
+    assert torch.equal(full[1:2], one)
