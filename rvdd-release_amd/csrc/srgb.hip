@@ -23,17 +23,29 @@ struct PpipeArgs {
     int n, H, W;
     int bit_depth;      // -1: network output in [-1,1]; 0, 8, 10: fwd_ppipe.py:131-137; anything else: already [0,4095]
     int iso;
-    float g0, g1, g2;   // fwd_ppipe.py:29
+    float g[3];         // fwd_ppipe.py:29
+    float rg[3];        // RN(1/g)
 };
+
+// x / c for a divisor known at launch time, correctly rounded (bit-identical to the IEEE division the reference
+// performs) in 3 instructions instead of the ~10 of v_div_*: Markstein's sequence with rc = RN(1/c) --
+// q = RN(x*rc); r = x - c*q (exact in an FMA); RN(q + r*rc) = RN(x/c).  Checked against np.float32 division on
+// 16M samples per divisor used here (tools note in DESIGN.md); inputs are finite and far from the subnormal range.
+__device__ __forceinline__ float div_c(float x, float c, float rc) {
+    const float q = x * rc;
+    const float r = __builtin_fmaf(-c, q, x);
+    return __builtin_fmaf(r, rc, q);
+}
+#define DIVC(x, c) div_c((x), (c), (float)(1.0 / (double)(c)))
 
 __device__ __forceinline__ float to_4095(float v, int bit_depth) {
     if (bit_depth == -1) {                 // util/util.py:40 then fwd_ppipe.py:134
         v = (v + 1.0f) / 2.0f * 255.0f;
-        v = v / 255.0f * 4095.0f;
+        v = DIVC(v, 255.0f) * 4095.0f;
     } else if (bit_depth == 0) {
         v = v * 4095.0f;
     } else if (bit_depth == 8) {
-        v = v / 255.0f * 4095.0f;
+        v = DIVC(v, 255.0f) * 4095.0f;
     } else if (bit_depth == 10) {
         v = v / 1024.0f * 4095.0f;
     }
@@ -42,9 +54,9 @@ __device__ __forceinline__ float to_4095(float v, int bit_depth) {
 
 __device__ __forceinline__ float linearise(float v, int iso) {
     // fwd_ppipe.py:50-57: undo the REDS<->CRVD percentile matching, subtract the black level
-    if (iso == 3200) v = (v - 266.0f) * 2060.0f / 3344.0f + 245.0f;
-    if (iso == 12800) v = (v - 268.0f) * 2060.0f / 3807.0f + 245.0f;
-    return (v - 240.0f) / 3855.0f;
+    if (iso == 3200) v = DIVC((v - 266.0f) * 2060.0f, 3344.0f) + 245.0f;
+    if (iso == 12800) v = DIVC((v - 268.0f) * 2060.0f, 3807.0f) + 245.0f;
+    return DIVC(v - 240.0f, 3855.0f);
 }
 
 __device__ __forceinline__ float tone(float v) {
@@ -54,6 +66,21 @@ __device__ __forceinline__ float tone(float v) {
     return 3.0f * v2 - 2.0f * (v2 * v);
 }
 
+// one pixel: three linear camera values -> three display values x 255 (before rounding)
+__device__ __forceinline__ void pixel(const PpipeArgs& a, float r, float g, float bl, float o[3]) {
+    r = div_c(linearise(to_4095(r, a.bit_depth), a.iso), a.g[0], a.rg[0]);
+    g = div_c(linearise(to_4095(g, a.bit_depth), a.iso), a.g[1], a.rg[1]);
+    bl = div_c(linearise(to_4095(bl, a.bit_depth), a.iso), a.g[2], a.rg[2]);
+    // apply_mat_inv_ccm (fwd_ppipe.py:20-26): out[c] = sum_j in[j] * inv_ccm[c][j]
+    o[0] = tone(r * 1.07955733f + g * -0.40125771f + bl * 0.32170038f) * 255.0f;
+    o[1] = tone(r * -0.15390743f + g * 1.35677921f + bl * -0.20287178f) * 255.0f;
+    o[2] = tone(r * -0.00235972f + g * -0.55155296f + bl * 1.55391268f) * 255.0f;
+}
+
+// fwd_ppipe.py:141: round (half to even) -> clip -> uint8
+__device__ __forceinline__ unsigned to_u8(float s) { return (unsigned)fminf(fmaxf(rintf(s), 0.0f), 255.0f); }
+
+// any strides, one pixel per thread
 __global__ __launch_bounds__(256) void ppipe_kernel(PpipeArgs a) {
     const int64_t total = (int64_t)a.n * a.H * a.W;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -61,20 +88,44 @@ __global__ __launch_bounds__(256) void ppipe_kernel(PpipeArgs a) {
         const int y = (int)((i / a.W) % a.H);
         const int b = (int)(i / ((int64_t)a.W * a.H));
         const float* p = a.img + b * a.sn + y * a.sy + x * a.sx;
-        float r = linearise(to_4095(p[0], a.bit_depth), a.iso) / a.g0;
-        float g = linearise(to_4095(p[a.sc], a.bit_depth), a.iso) / a.g1;
-        float bl = linearise(to_4095(p[2 * a.sc], a.bit_depth), a.iso) / a.g2;
-        // apply_mat_inv_ccm (fwd_ppipe.py:20-26): out[c] = sum_j in[j] * inv_ccm[c][j]
         float o[3];
-        o[0] = r * 1.07955733f + g * -0.40125771f + bl * 0.32170038f;
-        o[1] = r * -0.15390743f + g * 1.35677921f + bl * -0.20287178f;
-        o[2] = r * -0.00235972f + g * -0.55155296f + bl * 1.55391268f;
+        pixel(a, p[0], p[a.sc], p[2 * a.sc], o);
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            const float s = tone(o[c]) * 255.0f;
-            if (a.out_f32) a.out_f32[i * 3 + c] = s;
-            // fwd_ppipe.py:141: round (half to even) -> clip -> uint8
-            a.out_u8[i * 3 + c] = (uint8_t)fminf(fmaxf(rintf(s), 0.0f), 255.0f);
+            if (a.out_f32) a.out_f32[i * 3 + c] = o[c];
+            a.out_u8[i * 3 + c] = (uint8_t)to_u8(o[c]);
+        }
+    }
+}
+
+// planar input with unit x stride (the network's NCHW output), W % 4 == 0, 16-byte aligned rows:
+// four pixels per thread -- three 16-byte loads, one 12-byte store (+ three 16-byte stores for the float copy)
+__global__ __launch_bounds__(256) void ppipe_planar4_kernel(PpipeArgs a) {
+    const int W4 = a.W >> 2;
+    const int64_t total = (int64_t)a.n * a.H * W4;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int x4 = (int)(i % W4);
+        const int y = (int)((i / W4) % a.H);
+        const int b = (int)(i / ((int64_t)W4 * a.H));
+        const float* p = a.img + b * a.sn + y * a.sy + x4 * 4;
+        const float4 R = *reinterpret_cast<const float4*>(p);
+        const float4 G = *reinterpret_cast<const float4*>(p + a.sc);
+        const float4 B = *reinterpret_cast<const float4*>(p + 2 * a.sc);
+        const float rr[4] = {R.x, R.y, R.z, R.w}, gg[4] = {G.x, G.y, G.z, G.w}, bb[4] = {B.x, B.y, B.z, B.w};
+        float o[12];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) pixel(a, rr[k], gg[k], bb[k], o + 3 * k);
+        unsigned w[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            w[k] = to_u8(o[4 * k]) | (to_u8(o[4 * k + 1]) << 8) | (to_u8(o[4 * k + 2]) << 16) | (to_u8(o[4 * k + 3]) << 24);
+        unsigned* q = reinterpret_cast<unsigned*>(a.out_u8 + i * 12);
+        q[0] = w[0]; q[1] = w[1]; q[2] = w[2];
+        if (a.out_f32) {
+            float4* f = reinterpret_cast<float4*>(a.out_f32 + i * 12);
+            f[0] = make_float4(o[0], o[1], o[2], o[3]);
+            f[1] = make_float4(o[4], o[5], o[6], o[7]);
+            f[2] = make_float4(o[8], o[9], o[10], o[11]);
         }
     }
 }
@@ -160,12 +211,19 @@ __global__ __launch_bounds__(256) void ssim_final_kernel(const double* partial, 
 
 hipError_t launch_ppipe(const float* img, int n, int H, int W, int64_t sn, int64_t sc, int64_t sy, int64_t sx, int bit_depth,
                         const float gains[3], int iso, uint8_t* out_u8, float* out_f32, hipStream_t s) {
-    PpipeArgs a{img, out_u8, out_f32, sn, sc, sy, sx, n, H, W, bit_depth, iso, gains[0], gains[1], gains[2]};
-    const int64_t total = (int64_t)n * H * W;
+    PpipeArgs a{img, out_u8, out_f32, sn, sc, sy, sx, n, H, W, bit_depth, iso, {gains[0], gains[1], gains[2]},
+                {(float)(1.0 / (double)gains[0]), (float)(1.0 / (double)gains[1]), (float)(1.0 / (double)gains[2])}};
+    int64_t total = (int64_t)n * H * W;
     if (total == 0) return hipSuccess;
+    const bool planar4 = sx == 1 && (W & 3) == 0 && ((sn | sc | sy) & 3) == 0 && (reinterpret_cast<uintptr_t>(img) & 15) == 0 &&
+                         (reinterpret_cast<uintptr_t>(out_u8) & 3) == 0 && (reinterpret_cast<uintptr_t>(out_f32) & 15) == 0;
+    if (planar4) total >>= 2;
     int64_t blocks = (total + 255) / 256;
     if (blocks > 256 * 32) blocks = 256 * 32;
-    hipLaunchKernelGGL(ppipe_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a);
+    if (planar4)
+        hipLaunchKernelGGL(ppipe_planar4_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a);
+    else
+        hipLaunchKernelGGL(ppipe_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 

@@ -175,7 +175,7 @@ def test_tiff_errors(tmp_path):
         tiffio.read(p)
     with pytest.raises(tiffio.TiffError):
         tiffio.write(p, np.zeros((4, 4), np.complex64))
-    assert len(raw) == 8 + a.nbytes + 2 + 12 * 12 + 4 + 2 * 2 * 2     # header + data + 12-entry IFD + two out-of-line SHORT pairs
+    assert len(raw) == 8 + a.nbytes + 2 + 12 * 12 + 4              # header + data + 12-entry IFD (2-channel tags fit inline)
 
 
 # ------------------------------------------------------------------------------- library helpers
