@@ -132,7 +132,9 @@ int rvdd_upsample_factor_2(rvdd_t* h, const float* t, int32_t n, int32_t c, int3
  * optical flow with the reference's hard-wired parameters (3rdparty/tvl1flow/tvl1flow_lib.c:91-278, 343-472).
  *   I0, I1 [ny,nx] gray images; u [2,ny,nx] = x displacement then y displacement (libBridge.cpp:150) such
  *   that I1(x + u) ~ I0(x).  `iterations` (HOST, nullable) receives the total primal-dual iterations run.
- * Synchronises `stream` every few iterations (the convergence test lives on the device, the host peeks). */
+ * One cooperative (grid-synchronising) kernel per pyramid scale; needs a device that can hold one block per
+ * CU.  Synchronous: returns after the flow is complete (the control words are read back to catch a grid
+ * barrier that timed out -- RVDD_ERR_HIP then, never a half-finished flow). */
 int rvdd_tvl1flow(rvdd_t* h, const float* I0, const float* I1, float* u, int32_t nx, int32_t ny,
                   int32_t* iterations, void* stream);
 

@@ -5,12 +5,17 @@
 // (listed in DESIGN.md), fp32 with the reference's double-precision islands (Gaussian,
 // bicubic cell, normalisation, hypot).  Compiled with -ffp-contract=off.
 //
-// All maps are planar fp32 [ny][nx].  The per-iteration work is three tiny HBM/latency-bound
-// kernels; convergence is decided on the device (a `done` word that later iterations test), the
-// host only peeks at it every few iterations to stop launching.
+// All maps are planar fp32 [ny][nx].  One scale of the pyramid = ONE persistent cooperative kernel
+// (scale_kernel): gradient of I1, then 5 x [warp of I1 / I1x / I1y, then <= 300 x (u update | grid
+// barrier | convergence test + p update | grid barrier)].  An iteration touches ~120 B per pixel that
+// stay in L2, so the path is bound by the two grid barriers per iteration, not by HBM; as separate
+// launches (three per iteration, the first version of this file) it was bound by launch gaps, 3x slower.
+// Every block evaluates the convergence test itself from the same per-tile partial sums in the same
+// fixed order, so all blocks leave the loop in the same iteration without a broadcast.
 #include "rvdd_internal.h"
 
 #include <cmath>
+#include <cstdlib>
 #include <vector>
 
 namespace {
@@ -92,10 +97,8 @@ __global__ void gauss_kernel(const float* __restrict__ in, float* __restrict__ o
     out[i * nx + j] = (float)sum;
 }
 
-__global__ void centered_gradient_kernel(const float* __restrict__ I, float* __restrict__ dx,
-                                         float* __restrict__ dy, int nx, int ny) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
-    if (j >= nx) return;
+__device__ __forceinline__ void centered_gradient_px(const float* __restrict__ I, float* __restrict__ dx,
+                                                     float* __restrict__ dy, int nx, int ny, int i, int j) {
     const int p = i * nx + j;
     const float l = I[j > 0 ? p - 1 : p], r = I[j < nx - 1 ? p + 1 : p];
     const float u = I[i > 0 ? p - nx : p], d = I[i < ny - 1 ? p + nx : p];
@@ -138,121 +141,330 @@ __global__ void normalize_kernel(const float* __restrict__ a, const float* __res
 }
 
 // --------------------------------------------------------------------- tvl1flow_lib.c --
+// Values that cross workgroups INSIDE the persistent kernel (u and p of neighbouring tiles, the per-tile error
+// sums) move with device-scope relaxed atomics: `sc1` stores write through to the memory side, `sc1` loads do
+// not trust the XCD-local L2.  That keeps the eight L2s coherent for exactly these words, so the per-iteration
+// grid barrier needs no L2 write-back / invalidate (which cost ~25 us each when every barrier did them).
+__device__ __forceinline__ float ldc(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void stc(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 struct Scale {
     int nx, ny;
     float *I0, *I1, *u1, *u2;
 };
 struct IterBufs {
-    float *I1x, *I1y, *I1w, *I1wx, *I1wy, *rho_c, *grad, *p11, *p12, *p21, *p22;
+    float *I1x, *I1y, *I1w, *p11, *p12, *p21, *p22;      // I1w: scratch of the Gaussian passes
 };
 
+// ------------------------------------------------------------- one scale, one kernel --
+constexpr unsigned kSpinLimit = 1u << 21;      // ~ seconds; a barrier that is never completed ends the kernel, not the GPU
+
+// Grid-wide barrier on a monotonically increasing arrival counter.  Returns false when it timed out or
+// another block reported that (abort word): the caller returns, so the grid always drains.
+//   HEAVY: release/acquire at agent scope on every thread (L2 write-back + invalidate across the XCDs) -- for
+//          phases whose plain stores are read by other blocks (the gradient maps); once per scale.
+//   light: only waits for this wave's (write-through) stores; the data exchanged across it is ldc/stc.
+template <bool HEAVY>
+__device__ __forceinline__ bool grid_sync(unsigned* count, unsigned& target, int* abort_word) {
+    __shared__ int ok;
+    if (HEAVY) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    } else {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_s_waitcnt(0);                          // vmcnt(0): the sc1 stores of this wave have been acknowledged
+    }
+    __syncthreads();
+    target += gridDim.x;
+    if (threadIdx.x == 0) {
+        __hip_atomic_fetch_add(count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int good = 1;
+        unsigned spins = 0;
+        while (__hip_atomic_load(count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > kSpinLimit || __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                __hip_atomic_store(abort_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                good = 0;
+                break;
+            }
+        }
+        ok = good;
+    }
+    __syncthreads();
+    if (HEAVY)
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    else
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    return ok != 0;
+}
+
+// ---- the per-pixel arithmetic, shared by the two kernels below ----
 // warp of I1, I1x, I1y by (u1,u2) with zero outside + grad, rho_c (tvl1flow_lib.c:144-163)
-__global__ void warp_rho_kernel(Scale s, IterBufs b, int* __restrict__ ctl) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
-    if (j == 0 && i == 0) { ctl[0] = 0; ctl[1] = 0; }     // done flag, iteration counter of this warping
-    if (j >= s.nx) return;
-    const int p = i * s.nx + j;
-    const float u1 = s.u1[p], u2 = s.u2[p];
+__device__ __forceinline__ void warp_px(const Scale& s, const IterBufs& b, int i, int j, int p, float u1, float u2, float& wx,
+                                        float& wy, float& grad, float& rho_c) {
     Bicubic bc;
     bc.setup((float)((float)j + u1), (float)((float)i + u2), s.nx, s.ny);
-    float w = 0.f, wx = 0.f, wy = 0.f;
+    float w = 0.f;
+    wx = wy = 0.f;
     if (!bc.out) {
         w = bc.eval(s.I1, s.nx);
         wx = bc.eval(b.I1x, s.nx);
         wy = bc.eval(b.I1y, s.nx);
     }
-    b.I1w[p] = w;
-    b.I1wx[p] = wx;
-    b.I1wy[p] = wy;
     const float Ix2 = wx * wx, Iy2 = wy * wy;
-    b.grad[p] = Ix2 + Iy2;
-    b.rho_c[p] = w - wx * u1 - wy * u2 - s.I0[p];
+    grad = Ix2 + Iy2;
+    rho_c = w - wx * u1 - wy * u2 - s.I0[p];
 }
-
-// thresholding step, divergence of p, update of u, error (tvl1flow_lib.c:171-215)
-__global__ void iter_u_kernel(Scale s, IterBufs b, const int* __restrict__ ctl, float* __restrict__ partial) {
-    if (ctl[0]) return;
-    const int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
-    float e = 0.f;
-    if (j < s.nx) {
-        const int nx = s.nx, ny = s.ny, p = i * nx + j;
-        const float l_t = kLambda * kTheta;
-        const float u1k = s.u1[p], u2k = s.u2[p];
-        const float wx = b.I1wx[p], wy = b.I1wy[p], g = b.grad[p];
-        const float rho = b.rho_c[p] + (wx * u1k + wy * u2k);
-        float d1, d2;
-        if (rho < -l_t * g) {
-            d1 = l_t * wx;
-            d2 = l_t * wy;
-        } else if (rho > l_t * g) {
-            d1 = -l_t * wx;
-            d2 = -l_t * wy;
-        } else if (g < kGradIsZero) {
-            d1 = d2 = 0.f;
-        } else {
-            const float fi = -rho / g;
-            d1 = fi * wx;
-            d2 = fi * wy;
-        }
-        const float v1 = u1k + d1, v2 = u2k + d2;
-        // divergence (mask.c:40-90)
-        auto dive = [&](const float* a, const float* c) {
-            const float ax = j == 0 ? a[p] : (j == nx - 1 ? -a[p - 1] : a[p] - a[p - 1]);
-            const float cy = i == 0 ? c[p] : (i == ny - 1 ? -c[p - nx] : c[p] - c[p - nx]);
-            return ax + cy;
-        };
-        const float n1 = v1 + kTheta * dive(b.p11, b.p12);
-        const float n2 = v2 + kTheta * dive(b.p21, b.p22);
-        s.u1[p] = n1;
-        s.u2[p] = n2;
-        e = (n1 - u1k) * (n1 - u1k) + (n2 - u2k) * (n2 - u2k);
+// thresholding step, divergence of p, update of u (tvl1flow_lib.c:171-215); returns the squared update.
+// l11/l21: p11/p21 of the left neighbour, t12/t22: p12/p22 of the upper neighbour (unused at the borders)
+__device__ __forceinline__ float u_px(int i, int j, int nx, int ny, float& u1, float& u2, float wx, float wy, float g, float rho_c,
+                                      float p11, float p12, float p21, float p22, float l11, float t12, float l21, float t22) {
+    const float l_t = kLambda * kTheta;
+    const float u1k = u1, u2k = u2;
+    const float rho = rho_c + (wx * u1k + wy * u2k);
+    float d1, d2;
+    if (rho < -l_t * g) {
+        d1 = l_t * wx;
+        d2 = l_t * wy;
+    } else if (rho > l_t * g) {
+        d1 = -l_t * wx;
+        d2 = -l_t * wy;
+    } else if (g < kGradIsZero) {
+        d1 = d2 = 0.f;
+    } else {
+        const float fi = -rho / g;
+        d1 = fi * wx;
+        d2 = fi * wy;
     }
-    for (int o = 32; o > 0; o >>= 1) e += __shfl_down(e, o);
-    __shared__ float sh[4];
-    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = e;
-    __syncthreads();
-    if (threadIdx.x == 0) partial[blockIdx.y * gridDim.x + blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+    const float v1 = u1k + d1, v2 = u2k + d2;
+    // divergence (mask.c:40-90)
+    const float ax1 = j == 0 ? p11 : (j == nx - 1 ? -l11 : p11 - l11);
+    const float cy1 = i == 0 ? p12 : (i == ny - 1 ? -t12 : p12 - t12);
+    const float ax2 = j == 0 ? p21 : (j == nx - 1 ? -l21 : p21 - l21);
+    const float cy2 = i == 0 ? p22 : (i == ny - 1 ? -t22 : p22 - t22);
+    u1 = v1 + kTheta * (ax1 + cy1);
+    u2 = v2 + kTheta * (ax2 + cy2);
+    return (u1 - u1k) * (u1 - u1k) + (u2 - u2k) * (u2 - u2k);
 }
-
-__global__ void iter_check_kernel(int* __restrict__ ctl, const float* __restrict__ partial, int nblk, int size) {
-    if (ctl[0]) {                 // converged in an earlier pass: this pass did not move u, p must not move either
-        if (threadIdx.x == 0) ctl[3] = 0;
-        return;
-    }
-    double acc = 0.0;
-    for (int i = threadIdx.x; i < nblk; i += 256) acc += (double)partial[i];
-    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
-    __shared__ double sh[4];
-    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const float error = (float)(((sh[0] + sh[1]) + (sh[2] + sh[3])) / (double)size);
-        const int n = ctl[1] + 1;
-        ctl[1] = n;
-        ctl[2] += 1;                                   // total iterations (statistics)
-        ctl[3] = 1;                                    // u moved in this pass -> its p update runs
-        if (!(error > kEps * kEps) || n >= kMaxIter) ctl[0] = 1;
-    }
-}
-
-// forward gradient of u, update of the dual variables (tvl1flow_lib.c:217-234)
-__global__ void iter_p_kernel(Scale s, IterBufs b, const int* __restrict__ ctl) {
-    if (!ctl[3]) return;          // the reference updates p in every pass that updated u, the last one included
-    const int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
-    if (j >= s.nx) return;
-    const int nx = s.nx, ny = s.ny, p = i * nx + j;
+// forward gradient of u, update of the dual variables (tvl1flow_lib.c:217-234).
+// r1/r2: u1/u2 of the right neighbour, d1/d2: of the lower neighbour (unused at the borders)
+__device__ __forceinline__ void p_px(int i, int j, int nx, int ny, float a, float c, float r1, float d1, float r2, float d2, float& p11,
+                                     float& p12, float& p21, float& p22) {
     const float taut = kTau / kTheta;
-    const float a = s.u1[p], c = s.u2[p];
-    const float u1x = j < nx - 1 ? s.u1[p + 1] - a : 0.f, u1y = i < ny - 1 ? s.u1[p + nx] - a : 0.f;
-    const float u2x = j < nx - 1 ? s.u2[p + 1] - c : 0.f, u2y = i < ny - 1 ? s.u2[p + nx] - c : 0.f;
+    const float u1x = j < nx - 1 ? r1 - a : 0.f, u1y = i < ny - 1 ? d1 - a : 0.f;
+    const float u2x = j < nx - 1 ? r2 - c : 0.f, u2y = i < ny - 1 ? d2 - c : 0.f;
     const float g1 = (float)hypot((double)u1x, (double)u1y);
     const float g2 = (float)hypot((double)u2x, (double)u2y);
     const float ng1 = (float)(1.0 + (double)(taut * g1));
     const float ng2 = (float)(1.0 + (double)(taut * g2));
-    b.p11[p] = (b.p11[p] + taut * u1x) / ng1;
-    b.p12[p] = (b.p12[p] + taut * u1y) / ng1;
-    b.p21[p] = (b.p21[p] + taut * u2x) / ng2;
-    b.p22[p] = (b.p22[p] + taut * u2y) / ng2;
+    p11 = (p11 + taut * u1x) / ng1;
+    p12 = (p12 + taut * u1y) / ng1;
+    p21 = (p21 + taut * u2x) / ng2;
+    p22 = (p22 + taut * u2y) / ng2;
+}
+// the convergence test (tvl1flow_lib.c:236-241): fixed-order sum of the per-tile sums, identical in every block
+__device__ __forceinline__ float error_of(const float* partial, int ntiles, int npix, double* shd) {
+    const int tid = threadIdx.x;
+    double acc = 0.0;
+    for (int k = tid; k < ntiles; k += 256) acc += (double)ldc(partial + k);
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
+    if ((tid & 63) == 0) shd[tid >> 6] = acc;
+    __syncthreads();
+    return (float)(((shd[0] + shd[1]) + (shd[2] + shd[3])) / (double)npix);
+}
+
+// Dual_TVL1_optic_flow (tvl1flow_lib.c:91-278) for one scale.  Work items are "tiles" of 256 consecutive pixels
+// (row-major pixel index); block g owns tiles g, g + G, ... -- at most T of them, one pixel of each per thread.
+// Everything a thread needs about ITS pixels lives in registers for the whole scale (u, the four dual fields,
+// the warped gradient, rho_c: 10 floats per pixel); memory only carries what the neighbours read: u (also the
+// result) and p, written with stc, read with ldc, all loads of a phase in flight together so that a phase
+// costs one memory round trip.
+// ctl[2] accumulates the iterations run (statistics), ctl[3] is the abort word of grid_sync.
+template <int T>
+__global__ __launch_bounds__(256) void scale_kernel(Scale s, IterBufs b, int* __restrict__ ctl, float* __restrict__ partial,
+                                                     unsigned* __restrict__ bar) {
+    __shared__ float shf[T][4];
+    __shared__ double shd[4];
+    const int nx = s.nx, ny = s.ny, npix = nx * ny;
+    const int ntiles = (npix + 255) >> 8;
+    const int tid = threadIdx.x;
+    unsigned target = 0;
+    int total = 0;
+    int pp[T], pi[T], pj[T];
+    bool act[T];
+#pragma unroll
+    for (int k = 0; k < T; ++k) {
+        const int q = (blockIdx.x + k * gridDim.x) * 256 + tid;
+        act[k] = q < npix;
+        pp[k] = act[k] ? q : 0;
+        pi[k] = pp[k] / nx;
+        pj[k] = pp[k] - pi[k] * nx;
+    }
+    // gradient of I1 (tvl1flow_lib.c:127), p = 0 (:131-139): plain stores, made visible by the heavy barrier
+#pragma unroll
+    for (int k = 0; k < T; ++k)
+        if (act[k]) {
+            centered_gradient_px(s.I1, b.I1x, b.I1y, nx, ny, pi[k], pj[k]);
+            b.p11[pp[k]] = b.p12[pp[k]] = b.p21[pp[k]] = b.p22[pp[k]] = 0.f;
+        }
+    if (!grid_sync<true>(bar, target, ctl + 3)) return;
+    float u1[T], u2[T], p11[T], p12[T], p21[T], p22[T], wx[T], wy[T], grad[T], rho_c[T];
+#pragma unroll
+    for (int k = 0; k < T; ++k) {
+        u1[k] = act[k] ? s.u1[pp[k]] : 0.f;
+        u2[k] = act[k] ? s.u2[pp[k]] : 0.f;
+        p11[k] = p12[k] = p21[k] = p22[k] = wx[k] = wy[k] = grad[k] = rho_c[k] = 0.f;
+    }
+    for (int wp = 0; wp < kWarps; ++wp) {
+#pragma unroll
+        for (int k = 0; k < T; ++k) {
+            if (act[k]) warp_px(s, b, pi[k], pj[k], pp[k], u1[k], u2[k], wx[k], wy[k], grad[k], rho_c[k]);
+            __builtin_amdgcn_sched_barrier(0);   // one 3 x 16-tap stencil at a time
+        }
+        for (int n = 0; n < kMaxIter;) {
+            float l11[T], t12[T], l21[T], t22[T];
+#pragma unroll
+            for (int k = 0; k < T; ++k) {        // the neighbours' dual values: all loads first
+                const bool hl = act[k] && pj[k] > 0, ht = act[k] && pi[k] > 0;
+                l11[k] = hl ? ldc(b.p11 + pp[k] - 1) : 0.f;
+                l21[k] = hl ? ldc(b.p21 + pp[k] - 1) : 0.f;
+                t12[k] = ht ? ldc(b.p12 + pp[k] - nx) : 0.f;
+                t22[k] = ht ? ldc(b.p22 + pp[k] - nx) : 0.f;
+            }
+#pragma unroll
+            for (int k = 0; k < T; ++k) {
+                float e = 0.f;
+                if (act[k]) {
+                    e = u_px(pi[k], pj[k], nx, ny, u1[k], u2[k], wx[k], wy[k], grad[k], rho_c[k], p11[k], p12[k], p21[k], p22[k],
+                             l11[k], t12[k], l21[k], t22[k]);
+                    stc(s.u1 + pp[k], u1[k]);
+                    stc(s.u2 + pp[k], u2[k]);
+                }
+                for (int o = 32; o > 0; o >>= 1) e += __shfl_down(e, o);
+                if ((tid & 63) == 0) shf[k][tid >> 6] = e;
+            }
+            __syncthreads();
+            if (tid < T) {
+                const int t = blockIdx.x + tid * gridDim.x;
+                if (t < ntiles) stc(partial + t, (shf[tid][0] + shf[tid][1]) + (shf[tid][2] + shf[tid][3]));
+            }
+            if (!grid_sync<false>(bar, target, ctl + 3)) return;
+            float r1[T], d1[T], r2[T], d2[T];    // the u neighbours of the dual update travel with the error sums
+#pragma unroll
+            for (int k = 0; k < T; ++k) {
+                const bool hr = act[k] && pj[k] < nx - 1, hd = act[k] && pi[k] < ny - 1;
+                r1[k] = hr ? ldc(s.u1 + pp[k] + 1) : 0.f;
+                r2[k] = hr ? ldc(s.u2 + pp[k] + 1) : 0.f;
+                d1[k] = hd ? ldc(s.u1 + pp[k] + nx) : 0.f;
+                d2[k] = hd ? ldc(s.u2 + pp[k] + nx) : 0.f;
+            }
+            const float error = error_of(partial, ntiles, npix, shd);
+            ++n;
+            ++total;
+            // the reference updates p in every pass that updated u, the last one included
+#pragma unroll
+            for (int k = 0; k < T; ++k)
+                if (act[k]) {
+                    p_px(pi[k], pj[k], nx, ny, u1[k], u2[k], r1[k], d1[k], r2[k], d2[k], p11[k], p12[k], p21[k], p22[k]);
+                    stc(b.p11 + pp[k], p11[k]);
+                    stc(b.p12 + pp[k], p12[k]);
+                    stc(b.p21 + pp[k], p21[k]);
+                    stc(b.p22 + pp[k], p22[k]);
+                }
+            if (!grid_sync<false>(bar, target, ctl + 3)) return;
+            if (!(error > kEps * kEps)) break;
+        }
+    }
+    if (blockIdx.x == 0 && tid == 0) ctl[2] += total;
+}
+
+// The same scale for images whose pixels do not fit the register slots of one resident grid
+// (> 8 x 256 x #CUs pixels): identical phases, barriers and arithmetic, but a block walks its tiles one after
+// the other and a pixel's state lives in memory (u, p in their exchange arrays; the warped gradient and rho_c in
+// `st`) -- one memory round trip per TILE instead of per phase, about 2.5x slower per pixel.
+struct StateBufs {
+    float *wx, *wy, *grad, *rho_c;
+};
+__global__ __launch_bounds__(256) void scale_kernel_mem(Scale s, IterBufs b, StateBufs st, int* __restrict__ ctl,
+                                                         float* __restrict__ partial, unsigned* __restrict__ bar) {
+    __shared__ float shf[4];
+    __shared__ double shd[4];
+    const int nx = s.nx, ny = s.ny, npix = nx * ny;
+    const int ntiles = (npix + 255) >> 8;
+    const int tid = threadIdx.x;
+    unsigned target = 0;
+    int total = 0;
+#define FOR_TILES(...)                                           \
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {       \
+        const int p = t * 256 + tid;                             \
+        const bool on = p < npix;                                \
+        const int i = on ? p / nx : 0, j = on ? p - i * nx : 0;  \
+        __VA_ARGS__                                              \
+    }
+    FOR_TILES(if (on) {
+        centered_gradient_px(s.I1, b.I1x, b.I1y, nx, ny, i, j);
+        b.p11[p] = b.p12[p] = b.p21[p] = b.p22[p] = 0.f;
+    })
+    if (!grid_sync<true>(bar, target, ctl + 3)) return;
+    for (int wp = 0; wp < kWarps; ++wp) {
+        FOR_TILES(if (on) {
+            float wx, wy, g, rc;
+            warp_px(s, b, i, j, p, s.u1[p], s.u2[p], wx, wy, g, rc);
+            st.wx[p] = wx; st.wy[p] = wy; st.grad[p] = g; st.rho_c[p] = rc;
+        })
+        for (int n = 0; n < kMaxIter;) {
+            FOR_TILES(
+                float e = 0.f;
+                if (on) {
+                    float u1 = s.u1[p], u2 = s.u2[p];
+                    const float l11 = j > 0 ? ldc(b.p11 + p - 1) : 0.f, l21 = j > 0 ? ldc(b.p21 + p - 1) : 0.f;
+                    const float t12 = i > 0 ? ldc(b.p12 + p - nx) : 0.f, t22 = i > 0 ? ldc(b.p22 + p - nx) : 0.f;
+                    e = u_px(i, j, nx, ny, u1, u2, st.wx[p], st.wy[p], st.grad[p], st.rho_c[p], b.p11[p], b.p12[p], b.p21[p], b.p22[p],
+                             l11, t12, l21, t22);
+                    stc(s.u1 + p, u1);
+                    stc(s.u2 + p, u2);
+                }
+                for (int o = 32; o > 0; o >>= 1) e += __shfl_down(e, o);
+                if ((tid & 63) == 0) shf[tid >> 6] = e;
+                __syncthreads();
+                if (tid == 0) stc(partial + t, (shf[0] + shf[1]) + (shf[2] + shf[3]));
+                __syncthreads();
+            )
+            if (!grid_sync<false>(bar, target, ctl + 3)) return;
+            const float error = error_of(partial, ntiles, npix, shd);
+            ++n;
+            ++total;
+            FOR_TILES(if (on) {
+                const float r1 = j < nx - 1 ? ldc(s.u1 + p + 1) : 0.f, r2 = j < nx - 1 ? ldc(s.u2 + p + 1) : 0.f;
+                const float d1 = i < ny - 1 ? ldc(s.u1 + p + nx) : 0.f, d2 = i < ny - 1 ? ldc(s.u2 + p + nx) : 0.f;
+                float p11 = b.p11[p], p12 = b.p12[p], p21 = b.p21[p], p22 = b.p22[p];
+                p_px(i, j, nx, ny, s.u1[p], s.u2[p], r1, d1, r2, d2, p11, p12, p21, p22);
+                stc(b.p11 + p, p11);
+                stc(b.p12 + p, p12);
+                stc(b.p21 + p, p21);
+                stc(b.p22 + p, p22);
+            })
+            if (!grid_sync<false>(bar, target, ctl + 3)) return;
+            if (!(error > kEps * kEps)) break;
+        }
+    }
+#undef FOR_TILES
+    if (blockIdx.x == 0 && tid == 0) ctl[2] += total;
+}
+
+constexpr int kTileSlots[] = {1, 2, 3, 4, 5, 6, 8};
+constexpr int kMaxSlots = 8;
+using ScaleKernel = void (*)(Scale, IterBufs, int*, float*, unsigned*);
+ScaleKernel scale_kernel_for(int slots) {
+    switch (slots) {
+        case 1: return scale_kernel<1>;
+        case 2: return scale_kernel<2>;
+        case 3: return scale_kernel<3>;
+        case 4: return scale_kernel<4>;
+        case 5: return scale_kernel<5>;
+        case 6: return scale_kernel<6>;
+        case 8: return scale_kernel<8>;
+    }
+    return nullptr;
 }
 
 GaussK make_gauss(double sigma) {
@@ -279,6 +491,10 @@ struct Tvl1Workspace {
     IterBufs it{};
     float *tmp = nullptr, *tmp2 = nullptr, *partial = nullptr, *mm = nullptr;
     int* ctl = nullptr;
+    unsigned* bar = nullptr;
+    int max_blocks = 0;         // co-resident blocks of the scale kernels on this device (one per CU)
+    StateBufs state{};          // scale_kernel_mem only: allocated when the finest scale exceeds the register slots
+    bool force_mem = false;     // RVDD_TVL1_MEM=1: take the memory-state kernel at every scale (equivalence tests)
     std::vector<void*> allocs;
 };
 
@@ -325,15 +541,30 @@ hipError_t tvl1_alloc(Tvl1Workspace** out, int nx, int ny) {
         sy = (int)((float)sy * kZoom + 0.5f);
     }
     const size_t n0 = (size_t)nx * ny;
-    float** its[] = {&w->it.I1x, &w->it.I1y, &w->it.I1w, &w->it.I1wx, &w->it.I1wy, &w->it.rho_c, &w->it.grad,
-                     &w->it.p11, &w->it.p12, &w->it.p21, &w->it.p22, &w->tmp, &w->tmp2};
+    float** its[] = {&w->it.I1x, &w->it.I1y, &w->it.I1w, &w->it.p11, &w->it.p12, &w->it.p21, &w->it.p22, &w->tmp, &w->tmp2};
     for (float** p : its) A(p, n0);
-    A(&w->partial, ((size_t)(nx + 255) / 256) * ny);
+    A(&w->partial, (n0 + 255) / 256);
     A(&w->mm, 4);
     if (err == hipSuccess) {
         err = hipMalloc(reinterpret_cast<void**>(&w->ctl), 4 * sizeof(int));
         if (err == hipSuccess) w->allocs.push_back(w->ctl);
     }
+    if (err == hipSuccess) {
+        err = hipMalloc(reinterpret_cast<void**>(&w->bar), sizeof(unsigned));
+        if (err == hipSuccess) w->allocs.push_back(w->bar);
+    }
+    if (err == hipSuccess) {
+        int dev = 0, cus = 0, per_cu = 0;
+        err = hipGetDevice(&dev);
+        if (err == hipSuccess) err = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        if (err == hipSuccess) err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, scale_kernel<kMaxSlots>, 256, 0);
+        w->max_blocks = cus * (per_cu > 0 ? 1 : 0);     // one block per CU: the barrier cost grows with the block count
+        if (err == hipSuccess && w->max_blocks < 1) err = hipErrorLaunchFailure;
+    }
+    const char* fm = std::getenv("RVDD_TVL1_MEM");
+    w->force_mem = fm && fm[0] == '1';
+    if (w->force_mem || (n0 + 255) / 256 > (size_t)w->max_blocks * kMaxSlots)
+        for (float** p : {&w->state.wx, &w->state.wy, &w->state.grad, &w->state.rho_c}) A(p, n0);
     if (err != hipSuccess) {
         tvl1_free(w);
         return err;
@@ -385,25 +616,20 @@ hipError_t tvl1_run(Tvl1Workspace* w, const float* I0, const float* I1, float* u
             sc.u1 = u;
             sc.u2 = u + n0;
         }
-        const size_t n = (size_t)sc.nx * sc.ny;
-        const dim3 g = grid2(sc.nx, sc.ny);
-        const int nblk = g.x * g.y;
-        hipLaunchKernelGGL(centered_gradient_kernel, g, dim3(256), 0, st, sc.I1, w->it.I1x, w->it.I1y, sc.nx, sc.ny);
-        for (float* p : {w->it.p11, w->it.p12, w->it.p21, w->it.p22}) CK(hipMemsetAsync(p, 0, n * sizeof(float), st));
-        for (int wp = 0; wp < kWarps; ++wp) {
-            hipLaunchKernelGGL(warp_rho_kernel, g, dim3(256), 0, st, sc, w->it, w->ctl);
-            for (int it = 0; it < kMaxIter; ++it) {
-                hipLaunchKernelGGL(iter_u_kernel, g, dim3(256), 0, st, sc, w->it, w->ctl, w->partial);
-                hipLaunchKernelGGL(iter_check_kernel, dim3(1), dim3(256), 0, st, w->ctl, w->partial, nblk, (int)n);
-                // later passes are no-ops once the done word is set (ctl[3] gates the p update)
-                hipLaunchKernelGGL(iter_p_kernel, g, dim3(256), 0, st, sc, w->it, w->ctl);
-                if ((it & 7) == 7) {             // peek at the done word to stop launching
-                    int done = 0;
-                    CK(hipMemcpyAsync(&done, w->ctl, sizeof(int), hipMemcpyDeviceToHost, st));
-                    CK(hipStreamSynchronize(st));
-                    if (done) break;
-                }
-            }
+        // the whole scale (gradient, 5 warps x <= 300 iterations) in one cooperative launch
+        const int ntiles = (sc.nx * sc.ny + 255) / 256;
+        CK(hipMemsetAsync(w->bar, 0, sizeof(unsigned), st));
+        if (!w->force_mem && (long)ntiles <= (long)w->max_blocks * kMaxSlots) {
+            int slots = kMaxSlots;
+            for (int c : kTileSlots)
+                if ((long)c * w->max_blocks >= ntiles) { slots = c; break; }
+            const int blocks = (ntiles + slots - 1) / slots;     // <= max_blocks: as few arrivals per barrier as the slots allow
+            void* args[] = {&sc, &w->it, &w->ctl, &w->partial, &w->bar};
+            CK(hipLaunchCooperativeKernel(reinterpret_cast<const void*>(scale_kernel_for(slots)), dim3(blocks), dim3(256), args, 0, st));
+        } else {
+            const int blocks = ntiles < w->max_blocks ? ntiles : w->max_blocks;
+            void* args[] = {&sc, &w->it, &w->state, &w->ctl, &w->partial, &w->bar};
+            CK(hipLaunchCooperativeKernel(reinterpret_cast<const void*>(scale_kernel_mem), dim3(blocks), dim3(256), args, 0, st));
         }
         if (s == 0) break;
         // zoom_in + rescale by 1/zfactor (zoom.c:85-108, tvl1flow_lib.c:424-433)
@@ -412,11 +638,12 @@ hipError_t tvl1_run(Tvl1Workspace* w, const float* I0, const float* I1, float* u
         hipLaunchKernelGGL(resample_kernel, grid2(f.nx, f.ny), dim3(256), 0, st, sc.u1, f.u1, sc.nx, sc.ny, f.nx, f.ny, fx, fy, 1.0f / kZoom);
         hipLaunchKernelGGL(resample_kernel, grid2(f.nx, f.ny), dim3(256), 0, st, sc.u2, f.u2, sc.nx, sc.ny, f.nx, f.ny, fx, fy, 1.0f / kZoom);
     }
-    if (total_iters) {
+    {   // always read the control words back: a grid barrier that gave up (ctl[3]) must not pass as a flow
         int c[4];
         CK(hipMemcpyAsync(c, w->ctl, sizeof c, hipMemcpyDeviceToHost, st));
         CK(hipStreamSynchronize(st));
-        *total_iters = c[2];
+        if (c[3]) return hipErrorLaunchTimeOut;
+        if (total_iters) *total_iters = c[2];
     }
     return hipGetLastError();
 #undef CK

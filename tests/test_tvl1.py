@@ -90,3 +90,26 @@ def test_hip_flow_matches_oracle_and_bridge_surface():
     want = T.TVL1_flow(raw0, raw1)
     _close(flow, want)
     assert abs(np.median(flow[..., 0]) + 1.2) < 0.1 and abs(np.median(flow[..., 1]) - 0.6) < 0.1
+
+
+@pytest.mark.gpu
+def test_hip_register_and_memory_state_kernels_agree():
+    """The persistent per-scale kernel has two forms (pixel state in registers; in memory for images beyond
+    8 x 256 x #CUs pixels).  RVDD_TVL1_MEM=1 forces the second one: same phases, same arithmetic, same
+    fixed-order error sums -> bit-identical flows and iteration counts."""
+    from rvdd_release_amd.util._ops import ops_runtime
+    g = _load("d_90x160")
+    rt = ops_runtime(0)
+    I0, I1 = torch.from_numpy(g["I0"]).cuda(), torch.from_numpy(g["I1"]).cuda()
+    u_reg, it_reg = rt.tvl1flow(I0, I1, want_iterations=True)
+    small = torch.rand(20, 24, device="cuda")
+    os.environ["RVDD_TVL1_MEM"] = "1"
+    try:
+        rt.tvl1flow(small, small)                    # another size: the workspace (and its mode) is rebuilt
+        u_mem, it_mem = rt.tvl1flow(I0, I1, want_iterations=True)
+    finally:
+        del os.environ["RVDD_TVL1_MEM"]
+        rt.tvl1flow(small, small)
+    assert it_mem == it_reg and torch.equal(u_mem, u_reg)
+    u_again = rt.tvl1flow(I0, I1)
+    assert torch.equal(u_again, u_reg)               # and the run itself is deterministic
