@@ -214,10 +214,14 @@ __device__ __forceinline__ void warp_px(const Scale& s, const IterBufs& b, int i
     grad = Ix2 + Iy2;
     rho_c = w - wx * u1 - wy * u2 - s.I0[p];
 }
+// where a pixel sits: the stencils of mask.c switch form in the first / last column and row
+struct Edge {
+    bool c0, cN, r0, rN;      // first column, last column, first row, last row
+};
 // thresholding step, divergence of p, update of u (tvl1flow_lib.c:171-215); returns the squared update.
 // l11/l21: p11/p21 of the left neighbour, t12/t22: p12/p22 of the upper neighbour (unused at the borders)
-__device__ __forceinline__ float u_px(int i, int j, int nx, int ny, float& u1, float& u2, float wx, float wy, float g, float rho_c,
-                                      float p11, float p12, float p21, float p22, float l11, float t12, float l21, float t22) {
+__device__ __forceinline__ float u_px(Edge e, float& u1, float& u2, float wx, float wy, float g, float rho_c, float p11, float p12,
+                                      float p21, float p22, float l11, float t12, float l21, float t22) {
     const float l_t = kLambda * kTheta;
     const float u1k = u1, u2k = u2;
     const float rho = rho_c + (wx * u1k + wy * u2k);
@@ -237,30 +241,35 @@ __device__ __forceinline__ float u_px(int i, int j, int nx, int ny, float& u1, f
     }
     const float v1 = u1k + d1, v2 = u2k + d2;
     // divergence (mask.c:40-90)
-    const float ax1 = j == 0 ? p11 : (j == nx - 1 ? -l11 : p11 - l11);
-    const float cy1 = i == 0 ? p12 : (i == ny - 1 ? -t12 : p12 - t12);
-    const float ax2 = j == 0 ? p21 : (j == nx - 1 ? -l21 : p21 - l21);
-    const float cy2 = i == 0 ? p22 : (i == ny - 1 ? -t22 : p22 - t22);
+    const float ax1 = e.c0 ? p11 : (e.cN ? -l11 : p11 - l11);
+    const float cy1 = e.r0 ? p12 : (e.rN ? -t12 : p12 - t12);
+    const float ax2 = e.c0 ? p21 : (e.cN ? -l21 : p21 - l21);
+    const float cy2 = e.r0 ? p22 : (e.rN ? -t22 : p22 - t22);
     u1 = v1 + kTheta * (ax1 + cy1);
     u2 = v2 + kTheta * (ax2 + cy2);
     return (u1 - u1k) * (u1 - u1k) + (u2 - u2k) * (u2 - u2k);
 }
-// forward gradient of u, update of the dual variables (tvl1flow_lib.c:217-234).
-// r1/r2: u1/u2 of the right neighbour, d1/d2: of the lower neighbour (unused at the borders)
-__device__ __forceinline__ void p_px(int i, int j, int nx, int ny, float a, float c, float r1, float d1, float r2, float d2, float& p11,
-                                     float& p12, float& p21, float& p22) {
+// forward gradient of u at one pixel and the two denominators of the dual update (tvl1flow_lib.c:217-228).
+// a, c: u1, u2 at the pixel; r*: at its right neighbour; d*: at its lower neighbour
+struct DualStep {
+    float u1x, u1y, u2x, u2y, ng1, ng2;
+};
+__device__ __forceinline__ DualStep dual_step(bool last_col, bool last_row, float a, float c, float r1, float d1, float r2, float d2) {
     const float taut = kTau / kTheta;
-    const float u1x = j < nx - 1 ? r1 - a : 0.f, u1y = i < ny - 1 ? d1 - a : 0.f;
-    const float u2x = j < nx - 1 ? r2 - c : 0.f, u2y = i < ny - 1 ? d2 - c : 0.f;
-    const float g1 = (float)hypot((double)u1x, (double)u1y);
-    const float g2 = (float)hypot((double)u2x, (double)u2y);
-    const float ng1 = (float)(1.0 + (double)(taut * g1));
-    const float ng2 = (float)(1.0 + (double)(taut * g2));
-    p11 = (p11 + taut * u1x) / ng1;
-    p12 = (p12 + taut * u1y) / ng1;
-    p21 = (p21 + taut * u2x) / ng2;
-    p22 = (p22 + taut * u2y) / ng2;
+    DualStep o;
+    o.u1x = last_col ? 0.f : r1 - a;
+    o.u1y = last_row ? 0.f : d1 - a;
+    o.u2x = last_col ? 0.f : r2 - c;
+    o.u2y = last_row ? 0.f : d2 - c;
+    const float g1 = (float)hypot((double)o.u1x, (double)o.u1y);
+    const float g2 = (float)hypot((double)o.u2x, (double)o.u2y);
+    o.ng1 = (float)(1.0 + (double)(taut * g1));
+    o.ng2 = (float)(1.0 + (double)(taut * g2));
+    return o;
 }
+// one component of the dual update (tvl1flow_lib.c:230-233)
+__device__ __forceinline__ float dual_upd(float p, float grad, float ng) { return (p + (kTau / kTheta) * grad) / ng; }
+
 // the convergence test (tvl1flow_lib.c:236-241): fixed-order sum of the per-tile sums, identical in every block
 __device__ __forceinline__ float error_of(const float* partial, int ntiles, int npix, double* shd) {
     const int tid = threadIdx.x;
@@ -272,72 +281,84 @@ __device__ __forceinline__ float error_of(const float* partial, int ntiles, int 
     return (float)(((shd[0] + shd[1]) + (shd[2] + shd[3])) / (double)npix);
 }
 
+// what crosses workgroups inside a scale: u, double-buffered by iteration parity, and the per-tile error sums
+struct Xch {
+    float* u;          // [2 parities][2 components][npix of the scale]
+    float* partial;    // [2 parities][ntiles]
+};
+__device__ __forceinline__ float bld(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 16 /* sc1 */));
+}
+__device__ __forceinline__ void bst(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, float v) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voff, soff, 16 /* sc1 */);
+}
+
 // Dual_TVL1_optic_flow (tvl1flow_lib.c:91-278) for one scale.  Work items are "tiles" of 256 consecutive pixels
 // (row-major pixel index); block g owns tiles g, g + G, ... -- at most T of them, one pixel of each per thread.
 // Everything a thread needs about ITS pixels lives in registers for the whole scale (u, the four dual fields,
-// the warped gradient, rho_c: 10 floats per pixel); memory only carries what the neighbours read: u (also the
-// result) and p, written with stc, read with ldc, all loads of a phase in flight together so that a phase
-// costs one memory round trip.
+// the warped gradient, rho_c), and so do the two dual values of the left neighbour and the two of the upper
+// neighbour that its divergence reads: the thread recomputes those neighbours' dual update itself (same inputs,
+// same operations -> the same bits as the neighbour's own copy).  So p never travels; memory only carries u,
+// written once per iteration (write-through, `sc1`) into the buffer of the iteration's parity and read by the
+// neighbours after ONE grid barrier per iteration:
+//     [u update k | store u_k, tile error sums]  barrier  [error_k from the sums; load the 6 neighbours' u_k;
+//      dual update k of own/left/upper pixel | stop? | u update k+1 | store into the other buffer]  barrier ...
 // ctl[2] accumulates the iterations run (statistics), ctl[3] is the abort word of grid_sync.
 template <int T>
-__global__ __launch_bounds__(256) void scale_kernel(Scale s, IterBufs b, int* __restrict__ ctl, float* __restrict__ partial,
-                                                     unsigned* __restrict__ bar) {
+__global__ __launch_bounds__(256) void scale_kernel(Scale s, IterBufs b, Xch x, int* __restrict__ ctl, unsigned* __restrict__ bar) {
     __shared__ float shf[T][4];
     __shared__ double shd[4];
     const int nx = s.nx, ny = s.ny, npix = nx * ny;
     const int ntiles = (npix + 255) >> 8;
     const int tid = threadIdx.x;
+    const unsigned S = (unsigned)npix * 4u, row = (unsigned)nx * 4u;
+    const __amdgpu_buffer_rsrc_t ur = __builtin_amdgcn_make_buffer_rsrc((void*)x.u, 0, (int)(4u * S), 0x00020000);
     unsigned target = 0;
     int total = 0;
-    int pp[T], pi[T], pj[T];
+    unsigned po[T];                       // byte offset of the pixel inside one component array
+    int pi[T], pj[T];
     bool act[T];
 #pragma unroll
     for (int k = 0; k < T; ++k) {
         const int q = (blockIdx.x + k * gridDim.x) * 256 + tid;
         act[k] = q < npix;
-        pp[k] = act[k] ? q : 0;
-        pi[k] = pp[k] / nx;
-        pj[k] = pp[k] - pi[k] * nx;
+        const int p = act[k] ? q : 0;
+        pi[k] = p / nx;
+        pj[k] = p - pi[k] * nx;
+        po[k] = (unsigned)p * 4u;
     }
-    // gradient of I1 (tvl1flow_lib.c:127), p = 0 (:131-139): plain stores, made visible by the heavy barrier
+    // gradient of I1 (tvl1flow_lib.c:127): plain stores, made visible to the other blocks by the heavy barrier
 #pragma unroll
     for (int k = 0; k < T; ++k)
-        if (act[k]) {
-            centered_gradient_px(s.I1, b.I1x, b.I1y, nx, ny, pi[k], pj[k]);
-            b.p11[pp[k]] = b.p12[pp[k]] = b.p21[pp[k]] = b.p22[pp[k]] = 0.f;
-        }
+        if (act[k]) centered_gradient_px(s.I1, b.I1x, b.I1y, nx, ny, pi[k], pj[k]);
     if (!grid_sync<true>(bar, target, ctl + 3)) return;
-    float u1[T], u2[T], p11[T], p12[T], p21[T], p22[T], wx[T], wy[T], grad[T], rho_c[T];
+    float u1[T], u2[T], p11[T], p12[T], p21[T], p22[T], wx[T], wy[T], grad[T], rho_c[T], l11[T], l21[T], t12[T], t22[T];
 #pragma unroll
     for (int k = 0; k < T; ++k) {
-        u1[k] = act[k] ? s.u1[pp[k]] : 0.f;
-        u2[k] = act[k] ? s.u2[pp[k]] : 0.f;
-        p11[k] = p12[k] = p21[k] = p22[k] = wx[k] = wy[k] = grad[k] = rho_c[k] = 0.f;
+        u1[k] = act[k] ? s.u1[po[k] >> 2] : 0.f;
+        u2[k] = act[k] ? s.u2[po[k] >> 2] : 0.f;
+        p11[k] = p12[k] = p21[k] = p22[k] = l11[k] = l21[k] = t12[k] = t22[k] = 0.f;      // tvl1flow_lib.c:131-139
+        wx[k] = wy[k] = grad[k] = rho_c[k] = 0.f;
     }
+    unsigned par = 0;                     // parity of the buffers the next u update writes
     for (int wp = 0; wp < kWarps; ++wp) {
 #pragma unroll
         for (int k = 0; k < T; ++k) {
-            if (act[k]) warp_px(s, b, pi[k], pj[k], pp[k], u1[k], u2[k], wx[k], wy[k], grad[k], rho_c[k]);
+            if (act[k]) warp_px(s, b, pi[k], pj[k], (int)(po[k] >> 2), u1[k], u2[k], wx[k], wy[k], grad[k], rho_c[k]);
             __builtin_amdgcn_sched_barrier(0);   // one 3 x 16-tap stencil at a time
         }
-        for (int n = 0; n < kMaxIter;) {
-            float l11[T], t12[T], l21[T], t22[T];
-#pragma unroll
-            for (int k = 0; k < T; ++k) {        // the neighbours' dual values: all loads first
-                const bool hl = act[k] && pj[k] > 0, ht = act[k] && pi[k] > 0;
-                l11[k] = hl ? ldc(b.p11 + pp[k] - 1) : 0.f;
-                l21[k] = hl ? ldc(b.p21 + pp[k] - 1) : 0.f;
-                t12[k] = ht ? ldc(b.p12 + pp[k] - nx) : 0.f;
-                t22[k] = ht ? ldc(b.p22 + pp[k] - nx) : 0.f;
-            }
+        for (int n = 0;;) {
+            const unsigned so1 = par * 2u * S, so2 = so1 + S;
+            float* part = x.partial + par * ntiles;
 #pragma unroll
             for (int k = 0; k < T; ++k) {
                 float e = 0.f;
                 if (act[k]) {
-                    e = u_px(pi[k], pj[k], nx, ny, u1[k], u2[k], wx[k], wy[k], grad[k], rho_c[k], p11[k], p12[k], p21[k], p22[k],
-                             l11[k], t12[k], l21[k], t22[k]);
-                    stc(s.u1 + pp[k], u1[k]);
-                    stc(s.u2 + pp[k], u2[k]);
+                    const Edge ed{pj[k] == 0, pj[k] == nx - 1, pi[k] == 0, pi[k] == ny - 1};
+                    e = u_px(ed, u1[k], u2[k], wx[k], wy[k], grad[k], rho_c[k], p11[k], p12[k], p21[k], p22[k], l11[k], t12[k], l21[k],
+                             t22[k]);
+                    bst(ur, po[k], so1, u1[k]);
+                    bst(ur, po[k], so2, u2[k]);
                 }
                 for (int o = 32; o > 0; o >>= 1) e += __shfl_down(e, o);
                 if ((tid & 63) == 0) shf[k][tid >> 6] = e;
@@ -345,52 +366,80 @@ __global__ __launch_bounds__(256) void scale_kernel(Scale s, IterBufs b, int* __
             __syncthreads();
             if (tid < T) {
                 const int t = blockIdx.x + tid * gridDim.x;
-                if (t < ntiles) stc(partial + t, (shf[tid][0] + shf[tid][1]) + (shf[tid][2] + shf[tid][3]));
+                if (t < ntiles) stc(part + t, (shf[tid][0] + shf[tid][1]) + (shf[tid][2] + shf[tid][3]));
             }
-            if (!grid_sync<false>(bar, target, ctl + 3)) return;
-            float r1[T], d1[T], r2[T], d2[T];    // the u neighbours of the dual update travel with the error sums
-#pragma unroll
-            for (int k = 0; k < T; ++k) {
-                const bool hr = act[k] && pj[k] < nx - 1, hd = act[k] && pi[k] < ny - 1;
-                r1[k] = hr ? ldc(s.u1 + pp[k] + 1) : 0.f;
-                r2[k] = hr ? ldc(s.u2 + pp[k] + 1) : 0.f;
-                d1[k] = hd ? ldc(s.u1 + pp[k] + nx) : 0.f;
-                d2[k] = hd ? ldc(s.u2 + pp[k] + nx) : 0.f;
-            }
-            const float error = error_of(partial, ntiles, npix, shd);
             ++n;
             ++total;
-            // the reference updates p in every pass that updated u, the last one included
+            if (!grid_sync<false>(bar, target, ctl + 3)) return;
+            // u_n of the neighbours: right, below (own dual update); left, below-left (the left pixel's);
+            // above, above-right (the upper pixel's).  Out-of-image offsets fall outside the buffer and read 0.
+            float r1[T], r2[T], d1[T], d2[T], c1[T], c2[T], e1[T], e2[T], a1[T], a2[T], f1[T], f2[T];
+#pragma unroll
+            for (int k = 0; k < T; ++k) {
+                r1[k] = bld(ur, po[k] + 4u, so1);
+                r2[k] = bld(ur, po[k] + 4u, so2);
+                d1[k] = bld(ur, po[k] + row, so1);
+                d2[k] = bld(ur, po[k] + row, so2);
+                c1[k] = bld(ur, po[k] - 4u, so1);
+                c2[k] = bld(ur, po[k] - 4u, so2);
+                e1[k] = bld(ur, po[k] + row - 4u, so1);
+                e2[k] = bld(ur, po[k] + row - 4u, so2);
+                a1[k] = bld(ur, po[k] - row, so1);
+                a2[k] = bld(ur, po[k] - row, so2);
+                f1[k] = bld(ur, po[k] - row + 4u, so1);
+                f2[k] = bld(ur, po[k] - row + 4u, so2);
+            }
+            const float error = error_of(part, ntiles, npix, shd);
+            // dual update n (tvl1flow_lib.c:217-234); the reference runs it in every pass that updated u, the last included
 #pragma unroll
             for (int k = 0; k < T; ++k)
                 if (act[k]) {
-                    p_px(pi[k], pj[k], nx, ny, u1[k], u2[k], r1[k], d1[k], r2[k], d2[k], p11[k], p12[k], p21[k], p22[k]);
-                    stc(b.p11 + pp[k], p11[k]);
-                    stc(b.p12 + pp[k], p12[k]);
-                    stc(b.p21 + pp[k], p21[k]);
-                    stc(b.p22 + pp[k], p22[k]);
+                    const bool cN = pj[k] == nx - 1, rN = pi[k] == ny - 1;
+                    const DualStep o = dual_step(cN, rN, u1[k], u2[k], r1[k], d1[k], r2[k], d2[k]);
+                    p11[k] = dual_upd(p11[k], o.u1x, o.ng1);
+                    p12[k] = dual_upd(p12[k], o.u1y, o.ng1);
+                    p21[k] = dual_upd(p21[k], o.u2x, o.ng2);
+                    p22[k] = dual_upd(p22[k], o.u2y, o.ng2);
+                    if (pj[k] > 0) {      // the left pixel (never in the last column; same row)
+                        const DualStep l = dual_step(false, rN, c1[k], c2[k], u1[k], e1[k], u2[k], e2[k]);
+                        l11[k] = dual_upd(l11[k], l.u1x, l.ng1);
+                        l21[k] = dual_upd(l21[k], l.u2x, l.ng2);
+                    }
+                    if (pi[k] > 0) {      // the upper pixel (never in the last row; same column)
+                        const DualStep t = dual_step(cN, false, a1[k], a2[k], f1[k], u1[k], f2[k], u2[k]);
+                        t12[k] = dual_upd(t12[k], t.u1y, t.ng1);
+                        t22[k] = dual_upd(t22[k], t.u2y, t.ng2);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);   // one pixel's double-precision hypots at a time (registers)
                 }
-            if (!grid_sync<false>(bar, target, ctl + 3)) return;
-            if (!(error > kEps * kEps)) break;
+            par ^= 1u;
+            if (!(error > kEps * kEps) || n >= kMaxIter) break;
         }
     }
+#pragma unroll
+    for (int k = 0; k < T; ++k)
+        if (act[k]) {
+            s.u1[po[k] >> 2] = u1[k];
+            s.u2[po[k] >> 2] = u2[k];
+        }
     if (blockIdx.x == 0 && tid == 0) ctl[2] += total;
 }
 
 // The same scale for images whose pixels do not fit the register slots of one resident grid
-// (> 8 x 256 x #CUs pixels): identical phases, barriers and arithmetic, but a block walks its tiles one after
-// the other and a pixel's state lives in memory (u, p in their exchange arrays; the warped gradient and rho_c in
-// `st`) -- one memory round trip per TILE instead of per phase, about 2.5x slower per pixel.
+// (> kMaxSlots x 256 x #CUs pixels): the same arithmetic on the same values, but a block walks its tiles one
+// after the other and a pixel's state lives in memory (u in place, p in b.p*, the warped gradient and rho_c in
+// `st`), two grid barriers per iteration -- one memory round trip per TILE and phase: several times slower.
 struct StateBufs {
     float *wx, *wy, *grad, *rho_c;
 };
-__global__ __launch_bounds__(256) void scale_kernel_mem(Scale s, IterBufs b, StateBufs st, int* __restrict__ ctl,
-                                                         float* __restrict__ partial, unsigned* __restrict__ bar) {
+__global__ __launch_bounds__(256) void scale_kernel_mem(Scale s, IterBufs b, StateBufs st, Xch x, int* __restrict__ ctl,
+                                                         unsigned* __restrict__ bar) {
     __shared__ float shf[4];
     __shared__ double shd[4];
     const int nx = s.nx, ny = s.ny, npix = nx * ny;
     const int ntiles = (npix + 255) >> 8;
     const int tid = threadIdx.x;
+    float* partial = x.partial;
     unsigned target = 0;
     int total = 0;
 #define FOR_TILES(...)                                           \
@@ -411,15 +460,16 @@ __global__ __launch_bounds__(256) void scale_kernel_mem(Scale s, IterBufs b, Sta
             warp_px(s, b, i, j, p, s.u1[p], s.u2[p], wx, wy, g, rc);
             st.wx[p] = wx; st.wy[p] = wy; st.grad[p] = g; st.rho_c[p] = rc;
         })
-        for (int n = 0; n < kMaxIter;) {
+        for (int n = 0;;) {
             FOR_TILES(
                 float e = 0.f;
                 if (on) {
                     float u1 = s.u1[p], u2 = s.u2[p];
                     const float l11 = j > 0 ? ldc(b.p11 + p - 1) : 0.f, l21 = j > 0 ? ldc(b.p21 + p - 1) : 0.f;
                     const float t12 = i > 0 ? ldc(b.p12 + p - nx) : 0.f, t22 = i > 0 ? ldc(b.p22 + p - nx) : 0.f;
-                    e = u_px(i, j, nx, ny, u1, u2, st.wx[p], st.wy[p], st.grad[p], st.rho_c[p], b.p11[p], b.p12[p], b.p21[p], b.p22[p],
-                             l11, t12, l21, t22);
+                    const Edge ed{j == 0, j == nx - 1, i == 0, i == ny - 1};
+                    e = u_px(ed, u1, u2, st.wx[p], st.wy[p], st.grad[p], st.rho_c[p], b.p11[p], b.p12[p], b.p21[p], b.p22[p], l11, t12, l21,
+                             t22);
                     stc(s.u1 + p, u1);
                     stc(s.u2 + p, u2);
                 }
@@ -436,15 +486,14 @@ __global__ __launch_bounds__(256) void scale_kernel_mem(Scale s, IterBufs b, Sta
             FOR_TILES(if (on) {
                 const float r1 = j < nx - 1 ? ldc(s.u1 + p + 1) : 0.f, r2 = j < nx - 1 ? ldc(s.u2 + p + 1) : 0.f;
                 const float d1 = i < ny - 1 ? ldc(s.u1 + p + nx) : 0.f, d2 = i < ny - 1 ? ldc(s.u2 + p + nx) : 0.f;
-                float p11 = b.p11[p], p12 = b.p12[p], p21 = b.p21[p], p22 = b.p22[p];
-                p_px(i, j, nx, ny, s.u1[p], s.u2[p], r1, d1, r2, d2, p11, p12, p21, p22);
-                stc(b.p11 + p, p11);
-                stc(b.p12 + p, p12);
-                stc(b.p21 + p, p21);
-                stc(b.p22 + p, p22);
+                const DualStep o = dual_step(j == nx - 1, i == ny - 1, s.u1[p], s.u2[p], r1, d1, r2, d2);
+                stc(b.p11 + p, dual_upd(b.p11[p], o.u1x, o.ng1));
+                stc(b.p12 + p, dual_upd(b.p12[p], o.u1y, o.ng1));
+                stc(b.p21 + p, dual_upd(b.p21[p], o.u2x, o.ng2));
+                stc(b.p22 + p, dual_upd(b.p22[p], o.u2y, o.ng2));
             })
             if (!grid_sync<false>(bar, target, ctl + 3)) return;
-            if (!(error > kEps * kEps)) break;
+            if (!(error > kEps * kEps) || n >= kMaxIter) break;
         }
     }
 #undef FOR_TILES
@@ -453,7 +502,7 @@ __global__ __launch_bounds__(256) void scale_kernel_mem(Scale s, IterBufs b, Sta
 
 constexpr int kTileSlots[] = {1, 2, 3, 4, 5, 6, 8};
 constexpr int kMaxSlots = 8;
-using ScaleKernel = void (*)(Scale, IterBufs, int*, float*, unsigned*);
+using ScaleKernel = void (*)(Scale, IterBufs, Xch, int*, unsigned*);
 ScaleKernel scale_kernel_for(int slots) {
     switch (slots) {
         case 1: return scale_kernel<1>;
@@ -489,7 +538,8 @@ struct Tvl1Workspace {
     int nx = 0, ny = 0, nscales = 0;
     std::vector<Scale> sc;
     IterBufs it{};
-    float *tmp = nullptr, *tmp2 = nullptr, *partial = nullptr, *mm = nullptr;
+    float *tmp = nullptr, *tmp2 = nullptr, *mm = nullptr;
+    Xch xch{};
     int* ctl = nullptr;
     unsigned* bar = nullptr;
     int max_blocks = 0;         // co-resident blocks of the scale kernels on this device (one per CU)
@@ -543,7 +593,8 @@ hipError_t tvl1_alloc(Tvl1Workspace** out, int nx, int ny) {
     const size_t n0 = (size_t)nx * ny;
     float** its[] = {&w->it.I1x, &w->it.I1y, &w->it.I1w, &w->it.p11, &w->it.p12, &w->it.p21, &w->it.p22, &w->tmp, &w->tmp2};
     for (float** p : its) A(p, n0);
-    A(&w->partial, (n0 + 255) / 256);
+    A(&w->xch.partial, 2 * ((n0 + 255) / 256));
+    A(&w->xch.u, 4 * n0);
     A(&w->mm, 4);
     if (err == hipSuccess) {
         err = hipMalloc(reinterpret_cast<void**>(&w->ctl), 4 * sizeof(int));
@@ -624,11 +675,11 @@ hipError_t tvl1_run(Tvl1Workspace* w, const float* I0, const float* I1, float* u
             for (int c : kTileSlots)
                 if ((long)c * w->max_blocks >= ntiles) { slots = c; break; }
             const int blocks = (ntiles + slots - 1) / slots;     // <= max_blocks: as few arrivals per barrier as the slots allow
-            void* args[] = {&sc, &w->it, &w->ctl, &w->partial, &w->bar};
+            void* args[] = {&sc, &w->it, &w->xch, &w->ctl, &w->bar};
             CK(hipLaunchCooperativeKernel(reinterpret_cast<const void*>(scale_kernel_for(slots)), dim3(blocks), dim3(256), args, 0, st));
         } else {
             const int blocks = ntiles < w->max_blocks ? ntiles : w->max_blocks;
-            void* args[] = {&sc, &w->it, &w->state, &w->ctl, &w->partial, &w->bar};
+            void* args[] = {&sc, &w->it, &w->state, &w->xch, &w->ctl, &w->bar};
             CK(hipLaunchCooperativeKernel(reinterpret_cast<const void*>(scale_kernel_mem), dim3(blocks), dim3(256), args, 0, st));
         }
         if (s == 0) break;
