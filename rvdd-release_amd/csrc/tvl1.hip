@@ -261,10 +261,16 @@ __device__ __forceinline__ DualStep dual_step(bool last_col, bool last_row, floa
     o.u1y = last_row ? 0.f : d1 - a;
     o.u2x = last_col ? 0.f : r2 - c;
     o.u2y = last_row ? 0.f : d2 - c;
-    const float g1 = (float)hypot((double)o.u1x, (double)o.u1y);
-    const float g2 = (float)hypot((double)o.u2x, (double)o.u2y);
-    o.ng1 = (float)(1.0 + (double)(taut * g1));
-    o.ng2 = (float)(1.0 + (double)(taut * g2));
+    // The reference calls hypot() in double and adds 1.0 in double (tvl1flow_lib.c:224-227).  The squares of
+    // floats are exact in double, so sqrt(x*x + y*y) carries two roundings at 2^-53: after the conversion to
+    // float it is the same number as any sub-ulp double hypot except on ~2^-28 of the inputs -- at a quarter
+    // of the instructions of the library hypot (no scaling, no special cases: |x|,|y| < 2^60 here).  1 + t in
+    // double then float equals the float sum for t >= 0 (a sum of two floats rounds once either way).
+    const double x1 = (double)o.u1x, y1 = (double)o.u1y, x2 = (double)o.u2x, y2 = (double)o.u2y;
+    const float g1 = (float)__builtin_sqrt(x1 * x1 + y1 * y1);
+    const float g2 = (float)__builtin_sqrt(x2 * x2 + y2 * y2);
+    o.ng1 = 1.0f + taut * g1;
+    o.ng2 = 1.0f + taut * g2;
     return o;
 }
 // one component of the dual update (tvl1flow_lib.c:230-233)

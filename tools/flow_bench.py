@@ -3,6 +3,7 @@
 (oracle/_ref/libBridge.so, built by oracle/Makefile) on the host cores, raw-resolution 640x360 pairs
 (the flow size of a 1280x720 RGB frame).  One JSON line."""
 import ctypes, json, os, sys, time
+os.environ.setdefault("OMP_NUM_THREADS", str(min(len(os.sched_getaffinity(0)), 16)))
 import numpy as np, torch
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
@@ -34,6 +35,6 @@ if os.path.exists(ref):
         lib.tvl1flow(a.ctypes.data, b.ctypes.data, u.ctypes.data, w, h)
         d = np.abs(u.reshape(2, h, w) - flows[t - 1].cpu().numpy()); worst = max(worst, float(d.max())); mean = max(mean, float(d.mean()))
     cpu_s = (time.perf_counter() - t0) / n
-    out.update({"cpu_reference_flows_per_s": round(1 / cpu_s, 3), "cpu_threads": os.cpu_count(), "gpu_over_cpu": round(cpu_s / gpu_s, 1),
+    out.update({"cpu_reference_flows_per_s": round(1 / cpu_s, 3), "cpu_threads": int(os.environ["OMP_NUM_THREADS"]), "gpu_over_cpu": round(cpu_s / gpu_s, 1),
                 "gpu_vs_reference_max_abs_px": worst, "gpu_vs_reference_mean_abs_px": mean})
 print(json.dumps(out))
