@@ -74,13 +74,18 @@ def main():
     if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={os.environ.get('WORLD_SIZE', '1')}: "
                          "launch with torch.distributed.run")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    rank, local_rank, world, dist = shard.init_distributed("nccl", dev)    # nccl = RCCL on ROCm
+    # RVDD_BENCH_ONE_GPU=1: rehearsal of the multi-process path on a one-GPU box -- every rank on GPU 0,
+    # collectives over gloo on host tensors.  Never a measurement.
+    rehearsal = os.environ.get("RVDD_BENCH_ONE_GPU") == "1"
+    dev_index = 0 if rehearsal else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    rank, local_rank, world, dist = shard.init_distributed("gloo" if rehearsal else "nccl", dev)    # nccl = RCCL on ROCm
+    coll_dev = None if rehearsal else dev
 
     B = args.batch
     sd = load_file(os.path.join(REPO, "weights", stem + ".safetensors"))
-    rt = RvddRuntime(arch, fut, B, H, W, local_rank)
+    rt = RvddRuntime(arch, fut, B, H, W, dev_index)
     rt.load_state_dict(sd)
 
     # ---- synthetic inputs, resident in HBM, [T,B,...] so that a time slice is contiguous
@@ -122,13 +127,13 @@ def main():
     prof = rt.profile_read() if not args.no_kernel_events else []
     rt.profile_enable(False)
 
-    elapsed = shard.max_over_ranks(wall, dist, dev)
+    elapsed = shard.max_over_ranks(wall, dist, coll_dev)
     frames_total = args.steps * n_out * B * world
     fps = frames_total / elapsed
 
     # ---- task PSNR of every output frame of the last step (outside the timed region)
     psnr = torch.tensor([[rt.psnr_l1(outs[k], gt[k + 1])[1] for k in range(n_out)]], dtype=torch.float64, device=dev)
-    psnr_mean = float(shard.gather_metrics(psnr, dist).mean().item())    # the one collate collective
+    psnr_mean = float(shard.gather_metrics(psnr.cpu() if rehearsal else psnr, dist).mean().item())    # the one collate collective
 
     if rank != 0:
         if dist is not None:
@@ -206,7 +211,7 @@ def main():
         "metric": "frames/sec (whole job), recurrent video denoise+demosaic inference", "value": round(fps, 3),
         "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic" + (" (REHEARSAL: all ranks on one GPU, not a measurement)" if rehearsal else ""),
         "config": {"workload": f"{args.config}: {DESCR[args.config]}", "arch": arch, "checkpoint": stem,
                    "frame": f"{W}x{H}", "frames_per_sequence": T, "sequences_per_gpu": B,
                    "output_frames_per_step_per_gpu": n_out * B, "parallelism": f"sequences sharded over {world} GPU(s)"},
