@@ -138,6 +138,13 @@ int rvdd_upsample_factor_2(rvdd_t* h, const float* t, int32_t n, int32_t c, int3
 int rvdd_tvl1flow(rvdd_t* h, const float* I0, const float* I1, float* u, int32_t nx, int32_t ny,
                   int32_t* iterations, void* stream);
 
+/* `n` independent pairs of the same size -- what data/base_dataset.py:134-249 computes one call at a time when it
+ * fills the dataset's flow folder.  I0, I1: [n][ny][nx]; u: [n][2][ny][nx]; iterations: HOST [n], nullable.
+ * Two pairs share each cooperative launch (the CUs one pair leaves idle between its memory round trips run the
+ * other); every flow is bit-identical to the one rvdd_tvl1flow returns for that pair.  Synchronous. */
+int rvdd_tvl1flow_batch(rvdd_t* h, const float* I0, const float* I1, float* u, int32_t n, int32_t nx, int32_t ny,
+                        int32_t* iterations, void* stream);
+
 /* dataset/fwd_ppipe.py `ppipe(im, rgb_gain, red_gain, blue_gain, iso)` (:48-77) fused with the range
  * normalisation in front of it (:131-137) and the uint8 conversion behind it (:141): linear camera RGB ->
  * display sRGB (inverse percentile matching per ISO, black level, white-balance gains, inverse CCM,

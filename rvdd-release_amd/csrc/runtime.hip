@@ -836,6 +836,24 @@ int rvdd_srgb_metrics(rvdd_t* h, const uint8_t* a, const uint8_t* b, int32_t n, 
     return RVDD_OK;
 }
 
+int rvdd_tvl1flow_batch(rvdd_t* h, const float* I0, const float* I1, float* u, int32_t n, int32_t nx, int32_t ny,
+                        int32_t* iterations, void* stream) {
+    if (h && n == 0) return RVDD_OK;
+    if (!h || !I0 || !I1 || !u || n < 0 || nx < 16 || ny < 16)
+        return fail(h, RVDD_ERR_ARG, "rvdd_tvl1flow_batch: bad argument (images must be >= 16x16)");
+    if (!h->tvl1 || tvl1_ws_nx(h->tvl1) != nx || tvl1_ws_ny(h->tvl1) != ny) {
+        HIPCHK(h, hipDeviceSynchronize());
+        tvl1_free(h->tvl1);
+        h->tvl1 = nullptr;
+        HIPCHK(h, tvl1_alloc(&h->tvl1, nx, ny));
+    }
+    std::vector<int> it((size_t)n, 0);
+    HIPCHK(h, tvl1_run_batch(h->tvl1, I0, I1, u, n, static_cast<hipStream_t>(stream), iterations ? it.data() : nullptr));
+    if (iterations)
+        for (int i = 0; i < n; ++i) iterations[i] = it[(size_t)i];
+    return RVDD_OK;
+}
+
 int rvdd_profile_enable(rvdd_t* h, int32_t on) {
     if (!h) return RVDD_ERR_ARG;
     RC(prof_flush(h));

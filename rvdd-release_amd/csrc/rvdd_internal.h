@@ -118,5 +118,6 @@ void tvl1_free(Tvl1Workspace* w);
 int tvl1_num_scales(int nx, int ny);
 // I0, I1 [ny][nx] -> u [2][ny][nx]; synchronises the stream every few iterations (convergence peek)
 hipError_t tvl1_run(Tvl1Workspace* w, const float* I0, const float* I1, float* u, hipStream_t st, int* total_iters);
+hipError_t tvl1_run_batch(Tvl1Workspace* w, const float* I0, const float* I1, float* u, int n, hipStream_t st, int* iters);
 int tvl1_ws_nx(const Tvl1Workspace* w);
 int tvl1_ws_ny(const Tvl1Workspace* w);

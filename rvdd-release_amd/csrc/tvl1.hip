@@ -165,7 +165,7 @@ constexpr unsigned kSpinLimit = 1u << 21;      // ~ seconds; a barrier that is n
 //          phases whose plain stores are read by other blocks (the gradient maps); once per scale.
 //   light: only waits for this wave's (write-through) stores; the data exchanged across it is ldc/stc.
 template <bool HEAVY>
-__device__ __forceinline__ bool grid_sync(unsigned* count, unsigned& target, int* abort_word) {
+__device__ __forceinline__ bool grid_sync(unsigned* count, unsigned& target, unsigned nblk, int* abort_word) {
     __shared__ int ok;
     if (HEAVY) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
@@ -174,7 +174,7 @@ __device__ __forceinline__ bool grid_sync(unsigned* count, unsigned& target, int
         __builtin_amdgcn_s_waitcnt(0);                          // vmcnt(0): the sc1 stores of this wave have been acknowledged
     }
     __syncthreads();
-    target += gridDim.x;
+    target += nblk;
     if (threadIdx.x == 0) {
         __hip_atomic_fetch_add(count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         int good = 1;
@@ -292,6 +292,23 @@ struct Xch {
     float* u;          // [2 parities][2 components][npix of the scale]
     float* partial;    // [2 parities][ntiles]
 };
+// Several image pairs (the dataset's offline flow computation) share one launch: lane = blockIdx.x / gp.  The lanes
+// never talk to each other -- each has its own buffers, barrier counter and iteration count -- they only fill the
+// CUs that a single pair leaves idle between its memory round trips (a second cooperative kernel on another stream
+// does not: cooperative launches are serialised).
+constexpr int kMaxLanes = 2;
+struct Lane {
+    Scale s;
+    IterBufs b;
+    Xch x;
+    unsigned* bar;      // grid barrier counter of the lane
+    int* ctl;           // ctl[2] += iterations run
+};
+struct Lanes {
+    Lane l[kMaxLanes];
+    int gp;             // blocks per lane
+    int* abort_word;    // shared: a barrier that gave up in any lane ends the launch
+};
 __device__ __forceinline__ float bld(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 16 /* sc1 */));
 }
@@ -311,9 +328,17 @@ __device__ __forceinline__ void bst(__amdgpu_buffer_rsrc_t r, unsigned voff, uns
 //      dual update k of own/left/upper pixel | stop? | u update k+1 | store into the other buffer]  barrier ...
 // ctl[2] accumulates the iterations run (statistics), ctl[3] is the abort word of grid_sync.
 template <int T>
-__global__ __launch_bounds__(256) void scale_kernel(Scale s, IterBufs b, Xch x, int* __restrict__ ctl, unsigned* __restrict__ bar) {
+__global__ __launch_bounds__(256) void scale_kernel(Lanes lanes) {
     __shared__ float shf[T][4];
     __shared__ double shd[4];
+    const int lane_id = blockIdx.x / lanes.gp, gb = blockIdx.x - lane_id * lanes.gp;
+    const unsigned gp = (unsigned)lanes.gp;
+    const Scale s = lanes.l[lane_id].s;
+    const IterBufs b = lanes.l[lane_id].b;
+    const Xch x = lanes.l[lane_id].x;
+    unsigned* const bar = lanes.l[lane_id].bar;
+    int* const ctl = lanes.l[lane_id].ctl;
+    int* const abort_word = lanes.abort_word;
     const int nx = s.nx, ny = s.ny, npix = nx * ny;
     const int ntiles = (npix + 255) >> 8;
     const int tid = threadIdx.x;
@@ -326,7 +351,7 @@ __global__ __launch_bounds__(256) void scale_kernel(Scale s, IterBufs b, Xch x, 
     bool act[T];
 #pragma unroll
     for (int k = 0; k < T; ++k) {
-        const int q = (blockIdx.x + k * gridDim.x) * 256 + tid;
+        const int q = (gb + k * (int)gp) * 256 + tid;
         act[k] = q < npix;
         const int p = act[k] ? q : 0;
         pi[k] = p / nx;
@@ -337,7 +362,7 @@ __global__ __launch_bounds__(256) void scale_kernel(Scale s, IterBufs b, Xch x, 
 #pragma unroll
     for (int k = 0; k < T; ++k)
         if (act[k]) centered_gradient_px(s.I1, b.I1x, b.I1y, nx, ny, pi[k], pj[k]);
-    if (!grid_sync<true>(bar, target, ctl + 3)) return;
+    if (!grid_sync<true>(bar, target, gp, abort_word)) return;
     float u1[T], u2[T], p11[T], p12[T], p21[T], p22[T], wx[T], wy[T], grad[T], rho_c[T], l11[T], l21[T], t12[T], t22[T];
 #pragma unroll
     for (int k = 0; k < T; ++k) {
@@ -371,12 +396,12 @@ __global__ __launch_bounds__(256) void scale_kernel(Scale s, IterBufs b, Xch x, 
             }
             __syncthreads();
             if (tid < T) {
-                const int t = blockIdx.x + tid * gridDim.x;
+                const int t = gb + tid * (int)gp;
                 if (t < ntiles) stc(part + t, (shf[tid][0] + shf[tid][1]) + (shf[tid][2] + shf[tid][3]));
             }
             ++n;
             ++total;
-            if (!grid_sync<false>(bar, target, ctl + 3)) return;
+            if (!grid_sync<false>(bar, target, gp, abort_word)) return;
             // u_n of the neighbours: right, below (own dual update); left, below-left (the left pixel's);
             // above, above-right (the upper pixel's).  Out-of-image offsets fall outside the buffer and read 0.
             float r1[T], r2[T], d1[T], d2[T], c1[T], c2[T], e1[T], e2[T], a1[T], a2[T], f1[T], f2[T];
@@ -428,7 +453,7 @@ __global__ __launch_bounds__(256) void scale_kernel(Scale s, IterBufs b, Xch x, 
             s.u1[po[k] >> 2] = u1[k];
             s.u2[po[k] >> 2] = u2[k];
         }
-    if (blockIdx.x == 0 && tid == 0) ctl[2] += total;
+    if (gb == 0 && tid == 0) ctl[2] += total;
 }
 
 // The same scale for images whose pixels do not fit the register slots of one resident grid
@@ -438,10 +463,17 @@ __global__ __launch_bounds__(256) void scale_kernel(Scale s, IterBufs b, Xch x, 
 struct StateBufs {
     float *wx, *wy, *grad, *rho_c;
 };
-__global__ __launch_bounds__(256) void scale_kernel_mem(Scale s, IterBufs b, StateBufs st, Xch x, int* __restrict__ ctl,
-                                                         unsigned* __restrict__ bar) {
+__global__ __launch_bounds__(256) void scale_kernel_mem(Lanes lanes, StateBufs st) {
     __shared__ float shf[4];
     __shared__ double shd[4];
+    const int gb = blockIdx.x;                        // one lane only: this form is the fallback for very large images
+    const unsigned gp = (unsigned)lanes.gp;
+    const Scale s = lanes.l[0].s;
+    const IterBufs b = lanes.l[0].b;
+    const Xch x = lanes.l[0].x;
+    unsigned* const bar = lanes.l[0].bar;
+    int* const ctl = lanes.l[0].ctl;
+    int* const abort_word = lanes.abort_word;
     const int nx = s.nx, ny = s.ny, npix = nx * ny;
     const int ntiles = (npix + 255) >> 8;
     const int tid = threadIdx.x;
@@ -449,7 +481,7 @@ __global__ __launch_bounds__(256) void scale_kernel_mem(Scale s, IterBufs b, Sta
     unsigned target = 0;
     int total = 0;
 #define FOR_TILES(...)                                           \
-    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {       \
+    for (int t = gb; t < ntiles; t += (int)gp) {               \
         const int p = t * 256 + tid;                             \
         const bool on = p < npix;                                \
         const int i = on ? p / nx : 0, j = on ? p - i * nx : 0;  \
@@ -459,7 +491,7 @@ __global__ __launch_bounds__(256) void scale_kernel_mem(Scale s, IterBufs b, Sta
         centered_gradient_px(s.I1, b.I1x, b.I1y, nx, ny, i, j);
         b.p11[p] = b.p12[p] = b.p21[p] = b.p22[p] = 0.f;
     })
-    if (!grid_sync<true>(bar, target, ctl + 3)) return;
+    if (!grid_sync<true>(bar, target, gp, abort_word)) return;
     for (int wp = 0; wp < kWarps; ++wp) {
         FOR_TILES(if (on) {
             float wx, wy, g, rc;
@@ -485,7 +517,7 @@ __global__ __launch_bounds__(256) void scale_kernel_mem(Scale s, IterBufs b, Sta
                 if (tid == 0) stc(partial + t, (shf[0] + shf[1]) + (shf[2] + shf[3]));
                 __syncthreads();
             )
-            if (!grid_sync<false>(bar, target, ctl + 3)) return;
+            if (!grid_sync<false>(bar, target, gp, abort_word)) return;
             const float error = error_of(partial, ntiles, npix, shd);
             ++n;
             ++total;
@@ -498,17 +530,17 @@ __global__ __launch_bounds__(256) void scale_kernel_mem(Scale s, IterBufs b, Sta
                 stc(b.p21 + p, dual_upd(b.p21[p], o.u2x, o.ng2));
                 stc(b.p22 + p, dual_upd(b.p22[p], o.u2y, o.ng2));
             })
-            if (!grid_sync<false>(bar, target, ctl + 3)) return;
+            if (!grid_sync<false>(bar, target, gp, abort_word)) return;
             if (!(error > kEps * kEps) || n >= kMaxIter) break;
         }
     }
 #undef FOR_TILES
-    if (blockIdx.x == 0 && tid == 0) ctl[2] += total;
+    if (gb == 0 && tid == 0) ctl[2] += total;
 }
 
 constexpr int kTileSlots[] = {1, 2, 3, 4, 5, 6, 8};
 constexpr int kMaxSlots = 8;
-using ScaleKernel = void (*)(Scale, IterBufs, Xch, int*, unsigned*);
+using ScaleKernel = void (*)(Lanes);
 ScaleKernel scale_kernel_for(int slots) {
     switch (slots) {
         case 1: return scale_kernel<1>;
@@ -539,16 +571,20 @@ dim3 grid2(int nx, int ny) { return dim3((nx + 255) / 256, ny); }
 
 }  // namespace
 
-// Workspace: every buffer the pyramid needs for one (nx, ny); owned by the caller (runtime.hip).
-struct Tvl1Workspace {
-    int nx = 0, ny = 0, nscales = 0;
+// Workspace: every buffer the pyramid needs for one (nx, ny), per lane; owned by the caller (runtime.hip).
+struct Tvl1LaneBufs {
     std::vector<Scale> sc;
     IterBufs it{};
     float *tmp = nullptr, *tmp2 = nullptr, *mm = nullptr;
     Xch xch{};
-    int* ctl = nullptr;
+    int* ctl = nullptr;         // {unused, unused, iterations, unused}
     unsigned* bar = nullptr;
-    int max_blocks = 0;         // co-resident blocks of the scale kernels on this device (one per CU)
+};
+struct Tvl1Workspace {
+    int nx = 0, ny = 0, nscales = 0;
+    std::vector<Tvl1LaneBufs> lanes;     // lane 0 at allocation, lane 1 with the first batch call
+    int* abort_word = nullptr;
+    int cus = 0;
     StateBufs state{};          // scale_kernel_mem only: allocated when the finest scale exceeds the register slots
     bool force_mem = false;     // RVDD_TVL1_MEM=1: take the memory-state kernel at every scale (equivalence tests)
     std::vector<void*> allocs;
@@ -570,11 +606,7 @@ int tvl1_num_scales(int nx, int ny) {
     return ns < 1 ? 1 : ns;
 }
 
-hipError_t tvl1_alloc(Tvl1Workspace** out, int nx, int ny) {
-    Tvl1Workspace* w = new Tvl1Workspace();
-    w->nx = nx;
-    w->ny = ny;
-    w->nscales = tvl1_num_scales(nx, ny);
+static hipError_t tvl1_add_lane(Tvl1Workspace* w) {
     hipError_t err = hipSuccess;
     auto A = [&](float** p, size_t n) {
         if (err == hipSuccess) {
@@ -582,7 +614,8 @@ hipError_t tvl1_alloc(Tvl1Workspace** out, int nx, int ny) {
             if (err == hipSuccess) w->allocs.push_back(*p);
         }
     };
-    int sx = nx, sy = ny;
+    Tvl1LaneBufs L;
+    int sx = w->nx, sy = w->ny;
     for (int s = 0; s < w->nscales; ++s) {
         Scale sc{};
         sc.nx = sx;
@@ -592,36 +625,49 @@ hipError_t tvl1_alloc(Tvl1Workspace** out, int nx, int ny) {
         A(&sc.I1, n);
         A(&sc.u1, n);
         A(&sc.u2, n);
-        w->sc.push_back(sc);
+        L.sc.push_back(sc);
         sx = (int)((float)sx * kZoom + 0.5f);       // zoom_size (zoom.c:22-34)
         sy = (int)((float)sy * kZoom + 0.5f);
     }
-    const size_t n0 = (size_t)nx * ny;
-    float** its[] = {&w->it.I1x, &w->it.I1y, &w->it.I1w, &w->it.p11, &w->it.p12, &w->it.p21, &w->it.p22, &w->tmp, &w->tmp2};
+    const size_t n0 = (size_t)w->nx * w->ny;
+    float** its[] = {&L.it.I1x, &L.it.I1y, &L.it.I1w, &L.it.p11, &L.it.p12, &L.it.p21, &L.it.p22, &L.tmp, &L.tmp2};
     for (float** p : its) A(p, n0);
-    A(&w->xch.partial, 2 * ((n0 + 255) / 256));
-    A(&w->xch.u, 4 * n0);
-    A(&w->mm, 4);
+    A(&L.xch.partial, 2 * ((n0 + 255) / 256));
+    A(&L.xch.u, 4 * n0);
+    A(&L.mm, 4);
+    float* words = nullptr;
+    A(&words, 8);                                    // 4 control ints + the barrier counter
+    L.ctl = reinterpret_cast<int*>(words);
+    L.bar = reinterpret_cast<unsigned*>(words) + 4;
+    if (err == hipSuccess) w->lanes.push_back(L);
+    return err;
+}
+
+hipError_t tvl1_alloc(Tvl1Workspace** out, int nx, int ny) {
+    Tvl1Workspace* w = new Tvl1Workspace();
+    w->nx = nx;
+    w->ny = ny;
+    w->nscales = tvl1_num_scales(nx, ny);
+    hipError_t err = tvl1_add_lane(w);
     if (err == hipSuccess) {
-        err = hipMalloc(reinterpret_cast<void**>(&w->ctl), 4 * sizeof(int));
-        if (err == hipSuccess) w->allocs.push_back(w->ctl);
+        err = hipMalloc(reinterpret_cast<void**>(&w->abort_word), sizeof(int));
+        if (err == hipSuccess) w->allocs.push_back(w->abort_word);
     }
     if (err == hipSuccess) {
-        err = hipMalloc(reinterpret_cast<void**>(&w->bar), sizeof(unsigned));
-        if (err == hipSuccess) w->allocs.push_back(w->bar);
-    }
-    if (err == hipSuccess) {
-        int dev = 0, cus = 0, per_cu = 0;
+        int dev = 0;
         err = hipGetDevice(&dev);
-        if (err == hipSuccess) err = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        if (err == hipSuccess) err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, scale_kernel<kMaxSlots>, 256, 0);
-        w->max_blocks = cus * (per_cu > 0 ? 1 : 0);     // one block per CU: the barrier cost grows with the block count
-        if (err == hipSuccess && w->max_blocks < 1) err = hipErrorLaunchFailure;
+        if (err == hipSuccess) err = hipDeviceGetAttribute(&w->cus, hipDeviceAttributeMultiprocessorCount, dev);
+        if (err == hipSuccess && w->cus < 1) err = hipErrorLaunchFailure;
     }
+    const size_t n0 = (size_t)nx * ny;
     const char* fm = std::getenv("RVDD_TVL1_MEM");
     w->force_mem = fm && fm[0] == '1';
-    if (w->force_mem || (n0 + 255) / 256 > (size_t)w->max_blocks * kMaxSlots)
-        for (float** p : {&w->state.wx, &w->state.wy, &w->state.grad, &w->state.rho_c}) A(p, n0);
+    if (err == hipSuccess && (w->force_mem || (n0 + 255) / 256 > (size_t)w->cus * kMaxSlots))
+        for (float** p : {&w->state.wx, &w->state.wy, &w->state.grad, &w->state.rho_c})
+            if (err == hipSuccess) {
+                err = hipMalloc(reinterpret_cast<void**>(p), n0 * sizeof(float));
+                if (err == hipSuccess) w->allocs.push_back(*p);
+            }
     if (err != hipSuccess) {
         tvl1_free(w);
         return err;
@@ -630,78 +676,124 @@ hipError_t tvl1_alloc(Tvl1Workspace** out, int nx, int ny) {
     return hipSuccess;
 }
 
-// Dual_TVL1_optic_flow_multiscale (tvl1flow_lib.c:343-472).  u = [u(ny*nx), v(ny*nx)] as libBridge.cpp:150.
-hipError_t tvl1_run(Tvl1Workspace* w, const float* I0, const float* I1, float* u, hipStream_t st, int* total_iters) {
+// Dual_TVL1_optic_flow_multiscale (tvl1flow_lib.c:343-472) for `np` (1..kMaxLanes) pairs of the same size in one set
+// of launches.  I0, I1: [np][ny][nx]; u: [np][2][ny][nx] = per pair u(ny*nx) then v(ny*nx) as libBridge.cpp:150.
+static hipError_t tvl1_run_lanes(Tvl1Workspace* w, const float* I0, const float* I1, float* u, int np, hipStream_t st, int* iters) {
 #define CK(e)                                 \
     do {                                      \
         hipError_t e__ = (e);                 \
         if (e__ != hipSuccess) return e__;    \
     } while (0)
     const int nx = w->nx, ny = w->ny, n0 = nx * ny;
-    // normalisation to [0,255] and pre-smoothing
-    const int init[2] = {0x7f7fffff, (int)0x80000000};   // order-preserving keys of +FLT_MAX / -FLT_MAX
-    CK(hipMemcpyAsync(w->mm, init, sizeof init, hipMemcpyHostToDevice, st));
-    CK(hipMemsetAsync(w->ctl, 0, 4 * sizeof(int), st));
-    hipLaunchKernelGGL(minmax_kernel, dim3(256), dim3(256), 0, st, I0, I1, n0, w->mm);
-    hipLaunchKernelGGL(normalize_kernel, dim3((n0 + 255) / 256), dim3(256), 0, st, I0, I1, w->tmp, w->tmp2, n0, w->mm);
-    auto gauss = [&](const float* in, float* outp, int gx, int gy, double sigma, float* scratch) {
-        const GaussK k = make_gauss(sigma);
-        hipLaunchKernelGGL(gauss_kernel, grid2(gx, gy), dim3(256), 0, st, in, scratch, gx, gy, k, 0);
-        hipLaunchKernelGGL(gauss_kernel, grid2(gx, gy), dim3(256), 0, st, scratch, outp, gx, gy, k, 1);
-    };
-    gauss(w->tmp, w->sc[0].I0, nx, ny, kPresmooth, w->it.I1w);
-    gauss(w->tmp2, w->sc[0].I1, nx, ny, kPresmooth, w->it.I1w);
-    // pyramid (zoom_out, zoom.c:41-78)
+    while ((int)w->lanes.size() < np) CK(tvl1_add_lane(w));
+    CK(hipMemsetAsync(w->abort_word, 0, sizeof(int), st));
     const double zsigma = (double)(float)(kZoomSigma0 * std::sqrt(1.0 / ((double)kZoom * (double)kZoom) - 1.0));
-    for (int s = 1; s < w->nscales; ++s) {
-        const Scale& a = w->sc[s - 1];
-        const Scale& b = w->sc[s];
-        gauss(a.I0, w->tmp, a.nx, a.ny, zsigma, w->it.I1w);
-        hipLaunchKernelGGL(resample_kernel, grid2(b.nx, b.ny), dim3(256), 0, st, w->tmp, b.I0, a.nx, a.ny, b.nx, b.ny, kZoom, kZoom, 1.f);
-        gauss(a.I1, w->tmp, a.nx, a.ny, zsigma, w->it.I1w);
-        hipLaunchKernelGGL(resample_kernel, grid2(b.nx, b.ny), dim3(256), 0, st, w->tmp, b.I1, a.nx, a.ny, b.nx, b.ny, kZoom, kZoom, 1.f);
-    }
-    Scale& top = w->sc[w->nscales - 1];
-    CK(hipMemsetAsync(top.u1, 0, (size_t)top.nx * top.ny * sizeof(float), st));
-    CK(hipMemsetAsync(top.u2, 0, (size_t)top.nx * top.ny * sizeof(float), st));
-
-    for (int s = w->nscales - 1; s >= 0; --s) {
-        Scale sc = w->sc[s];
-        if (s == 0) {        // the finest flow is the caller's buffer
-            CK(hipMemcpyAsync(u, sc.u1, (size_t)n0 * sizeof(float), hipMemcpyDeviceToDevice, st));
-            CK(hipMemcpyAsync(u + n0, sc.u2, (size_t)n0 * sizeof(float), hipMemcpyDeviceToDevice, st));
-            sc.u1 = u;
-            sc.u2 = u + n0;
+    for (int q = 0; q < np; ++q) {
+        Tvl1LaneBufs& L = w->lanes[q];
+        const float *a0 = I0 + (size_t)q * n0, *a1 = I1 + (size_t)q * n0;
+        // normalisation to [0,255] and pre-smoothing
+        const int init[2] = {0x7f7fffff, (int)0x80000000};   // order-preserving keys of +FLT_MAX / -FLT_MAX
+        CK(hipMemcpyAsync(L.mm, init, sizeof init, hipMemcpyHostToDevice, st));
+        CK(hipMemsetAsync(L.ctl, 0, 8 * sizeof(int), st));
+        hipLaunchKernelGGL(minmax_kernel, dim3(256), dim3(256), 0, st, a0, a1, n0, L.mm);
+        hipLaunchKernelGGL(normalize_kernel, dim3((n0 + 255) / 256), dim3(256), 0, st, a0, a1, L.tmp, L.tmp2, n0, L.mm);
+        auto gauss = [&](const float* in, float* outp, int gx, int gy, double sigma, float* scratch) {
+            const GaussK k = make_gauss(sigma);
+            hipLaunchKernelGGL(gauss_kernel, grid2(gx, gy), dim3(256), 0, st, in, scratch, gx, gy, k, 0);
+            hipLaunchKernelGGL(gauss_kernel, grid2(gx, gy), dim3(256), 0, st, scratch, outp, gx, gy, k, 1);
+        };
+        gauss(L.tmp, L.sc[0].I0, nx, ny, kPresmooth, L.it.I1w);
+        gauss(L.tmp2, L.sc[0].I1, nx, ny, kPresmooth, L.it.I1w);
+        // pyramid (zoom_out, zoom.c:41-78)
+        for (int s = 1; s < w->nscales; ++s) {
+            const Scale& a = L.sc[s - 1];
+            const Scale& b = L.sc[s];
+            gauss(a.I0, L.tmp, a.nx, a.ny, zsigma, L.it.I1w);
+            hipLaunchKernelGGL(resample_kernel, grid2(b.nx, b.ny), dim3(256), 0, st, L.tmp, b.I0, a.nx, a.ny, b.nx, b.ny, kZoom, kZoom, 1.f);
+            gauss(a.I1, L.tmp, a.nx, a.ny, zsigma, L.it.I1w);
+            hipLaunchKernelGGL(resample_kernel, grid2(b.nx, b.ny), dim3(256), 0, st, L.tmp, b.I1, a.nx, a.ny, b.nx, b.ny, kZoom, kZoom, 1.f);
         }
-        // the whole scale (gradient, 5 warps x <= 300 iterations) in one cooperative launch
-        const int ntiles = (sc.nx * sc.ny + 255) / 256;
-        CK(hipMemsetAsync(w->bar, 0, sizeof(unsigned), st));
-        if (!w->force_mem && (long)ntiles <= (long)w->max_blocks * kMaxSlots) {
-            int slots = kMaxSlots;
-            for (int c : kTileSlots)
-                if ((long)c * w->max_blocks >= ntiles) { slots = c; break; }
-            const int blocks = (ntiles + slots - 1) / slots;     // <= max_blocks: as few arrivals per barrier as the slots allow
-            void* args[] = {&sc, &w->it, &w->xch, &w->ctl, &w->bar};
-            CK(hipLaunchCooperativeKernel(reinterpret_cast<const void*>(scale_kernel_for(slots)), dim3(blocks), dim3(256), args, 0, st));
+        const Scale& top = L.sc[w->nscales - 1];
+        CK(hipMemsetAsync(top.u1, 0, (size_t)top.nx * top.ny * sizeof(float), st));
+        CK(hipMemsetAsync(top.u2, 0, (size_t)top.nx * top.ny * sizeof(float), st));
+    }
+    for (int s = w->nscales - 1; s >= 0; --s) {
+        Lanes lanes{};
+        lanes.abort_word = w->abort_word;
+        for (int q = 0; q < np; ++q) {
+            Tvl1LaneBufs& L = w->lanes[q];
+            Scale sc = L.sc[s];
+            if (s == 0) {        // the finest flow is the caller's buffer
+                float* uq = u + (size_t)q * 2 * n0;
+                CK(hipMemcpyAsync(uq, sc.u1, (size_t)n0 * sizeof(float), hipMemcpyDeviceToDevice, st));
+                CK(hipMemcpyAsync(uq + n0, sc.u2, (size_t)n0 * sizeof(float), hipMemcpyDeviceToDevice, st));
+                sc.u1 = uq;
+                sc.u2 = uq + n0;
+            }
+            lanes.l[q] = Lane{sc, L.it, L.xch, L.bar, L.ctl};
+            CK(hipMemsetAsync(L.bar, 0, sizeof(unsigned), st));
+        }
+        // the whole scale (gradient, 5 warps x <= 300 iterations) of every lane in one cooperative launch
+        const Scale& ref = w->lanes[0].sc[s];
+        const int ntiles = (ref.nx * ref.ny + 255) / 256;
+        // register-state kernel: the smallest slot count T such that a lane has at most one block per CU and all
+        // lanes together are co-resident
+        int slots = 0, gp = 0;
+        if (!w->force_mem)
+            for (int c : kTileSlots) {
+                const int g = (ntiles + c - 1) / c;
+                int per_cu = 0;
+                CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, scale_kernel_for(c), 256, 0));
+                if (g <= w->cus && (long)np * g <= (long)w->cus * per_cu) { slots = c; gp = g; break; }
+            }
+        if (slots) {
+            lanes.gp = gp;
+            void* args[] = {&lanes};
+            CK(hipLaunchCooperativeKernel(reinterpret_cast<const void*>(scale_kernel_for(slots)), dim3(gp * np), dim3(256), args, 0, st));
         } else {
-            const int blocks = ntiles < w->max_blocks ? ntiles : w->max_blocks;
-            void* args[] = {&sc, &w->it, &w->state, &w->xch, &w->ctl, &w->bar};
-            CK(hipLaunchCooperativeKernel(reinterpret_cast<const void*>(scale_kernel_mem), dim3(blocks), dim3(256), args, 0, st));
+            if (!w->state.wx) return hipErrorInvalidValue;       // lanes of this size were not provisioned at allocation
+            lanes.gp = ntiles < w->cus ? ntiles : w->cus;
+            for (int q = 0; q < np; ++q) {                        // one lane per launch
+                Lanes one = lanes;
+                one.l[0] = lanes.l[q];
+                void* args[] = {&one, &w->state};
+                CK(hipLaunchCooperativeKernel(reinterpret_cast<const void*>(scale_kernel_mem), dim3(lanes.gp), dim3(256), args, 0, st));
+            }
         }
         if (s == 0) break;
         // zoom_in + rescale by 1/zfactor (zoom.c:85-108, tvl1flow_lib.c:424-433)
-        const Scale& f = w->sc[s - 1];
-        const float fx = (float)f.nx / sc.nx, fy = (float)f.ny / sc.ny;
-        hipLaunchKernelGGL(resample_kernel, grid2(f.nx, f.ny), dim3(256), 0, st, sc.u1, f.u1, sc.nx, sc.ny, f.nx, f.ny, fx, fy, 1.0f / kZoom);
-        hipLaunchKernelGGL(resample_kernel, grid2(f.nx, f.ny), dim3(256), 0, st, sc.u2, f.u2, sc.nx, sc.ny, f.nx, f.ny, fx, fy, 1.0f / kZoom);
+        for (int q = 0; q < np; ++q) {
+            const Scale& sc = w->lanes[q].sc[s];
+            const Scale& f = w->lanes[q].sc[s - 1];
+            const float fx = (float)f.nx / sc.nx, fy = (float)f.ny / sc.ny;
+            hipLaunchKernelGGL(resample_kernel, grid2(f.nx, f.ny), dim3(256), 0, st, sc.u1, f.u1, sc.nx, sc.ny, f.nx, f.ny, fx, fy, 1.0f / kZoom);
+            hipLaunchKernelGGL(resample_kernel, grid2(f.nx, f.ny), dim3(256), 0, st, sc.u2, f.u2, sc.nx, sc.ny, f.nx, f.ny, fx, fy, 1.0f / kZoom);
+        }
     }
-    {   // always read the control words back: a grid barrier that gave up (ctl[3]) must not pass as a flow
-        int c[4];
-        CK(hipMemcpyAsync(c, w->ctl, sizeof c, hipMemcpyDeviceToHost, st));
+    {   // always read the control words back: a grid barrier that gave up must not pass as a flow
+        int ab = 0, c[kMaxLanes][8] = {};
+        CK(hipMemcpyAsync(&ab, w->abort_word, sizeof ab, hipMemcpyDeviceToHost, st));
+        for (int q = 0; q < np; ++q) CK(hipMemcpyAsync(c[q], w->lanes[q].ctl, 4 * sizeof(int), hipMemcpyDeviceToHost, st));
         CK(hipStreamSynchronize(st));
-        if (c[3]) return hipErrorLaunchTimeOut;
-        if (total_iters) *total_iters = c[2];
+        if (ab) return hipErrorLaunchTimeOut;
+        if (iters)
+            for (int q = 0; q < np; ++q) iters[q] = c[q][2];
     }
     return hipGetLastError();
 #undef CK
+}
+
+hipError_t tvl1_run(Tvl1Workspace* w, const float* I0, const float* I1, float* u, hipStream_t st, int* total_iters) {
+    return tvl1_run_lanes(w, I0, I1, u, 1, st, total_iters);
+}
+
+// n pairs of the same size, kMaxLanes at a time
+hipError_t tvl1_run_batch(Tvl1Workspace* w, const float* I0, const float* I1, float* u, int n, hipStream_t st, int* iters) {
+    const size_t n0 = (size_t)w->nx * w->ny;
+    for (int q = 0; q < n; q += kMaxLanes) {
+        const int np = n - q < kMaxLanes ? n - q : kMaxLanes;
+        hipError_t e = tvl1_run_lanes(w, I0 + q * n0, I1 + q * n0, u + q * 2 * n0, np, st, iters ? iters + q : nullptr);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
 }

@@ -86,54 +86,71 @@ class infer4recDataset:
                     self.videos_flow_path.append(f_path)
 
     # -- flow files (data/base_dataset.py:134-249) ---------------------------------------------------
-    def _flow_and_warp(self, img1, img2, want_warp):
+    # The reference computes one flow per loop iteration; here the missing pairs of a pass are collected and handed
+    # to the device several at a time (rvdd_tvl1flow_batch).  Same files, same contents.
+    FLOW_BATCH = 8
+
+    def _bridge_get(self):
         from ..library import CPPbridge
-        from ..util.flow_utils import single_warp
         if self._bridge is None:
             self._bridge = CPPbridge('./build/libBridge.so')
-        flow = self._bridge.TVL1_flow(img2, img1)                                       # util/flow_utils.py:144-145
-        return (single_warp(img1, flow) if want_warp else None), flow
+        return self._bridge
 
-    def _ensure(self, img2_path, from_path, gen_warp):
-        from ..util.flow_utils import single_warp
+    def _files(self, img2_path, from_path):
         toCode = os.path.splitext(os.path.basename(img2_path))[0]
         fromCode = os.path.splitext(os.path.basename(from_path))[0]
         wfolder = os.path.join(self.w_paths, pathdiff(img2_path, self.n_paths))
         ffolder = os.path.join(self.flow_paths, pathdiff(img2_path, self.n_paths))
+        return wfolder, ffolder, warpedimagefile(wfolder, fromCode, toCode), warpedimagefile(ffolder, fromCode, toCode)
+
+    def _flush(self, pending, gen_warp):
+        """pending: (img2_path, from_path) pairs whose flow file is missing."""
+        from ..util.flow_utils import single_warp
+        for k in range(0, len(pending), self.FLOW_BATCH):
+            chunk = pending[k:k + self.FLOW_BATCH]
+            img2 = [iio_read(a).astype(np.float32) for a, _ in chunk]
+            img1 = [iio_read(b).astype(np.float32) for _, b in chunk]
+            flows = self._bridge_get().TVL1_flow_batch(img2, img1)                  # util/flow_utils.py:144-145, per pair
+            for (a, b), i1, flow in zip(chunk, img1, flows):
+                wfolder, ffolder, wimagefile, fimagefile = self._files(a, b)
+                iio_write(flow.astype(np.float32), fimagefile)
+                if gen_warp and not os.path.isfile(wimagefile):
+                    iio_write(single_warp(i1, flow).astype(np.float32), wimagefile)
+
+    def _ensure(self, img2_path, from_path, gen_warp, pending):
+        from ..util.flow_utils import single_warp
+        wfolder, ffolder, wimagefile, fimagefile = self._files(img2_path, from_path)
         mkdir(ffolder)
         if gen_warp:
             mkdir(wfolder)
-        wimagefile, fimagefile = warpedimagefile(wfolder, fromCode, toCode), warpedimagefile(ffolder, fromCode, toCode)
-        need_w = gen_warp and not os.path.isfile(wimagefile)
-        if os.path.isfile(fimagefile) and not need_w:
-            return
-        img1 = iio_read(from_path).astype(np.float32)
         if not os.path.isfile(fimagefile):
-            img2 = iio_read(img2_path).astype(np.float32)
-            warped, flow = self._flow_and_warp(img1, img2, need_w)
-            iio_write(flow.astype(np.float32), fimagefile)
-        else:
-            warped = single_warp(img1, iio_read(fimagefile).astype(np.float32))
-        if need_w:
-            iio_write(warped.astype(np.float32), wimagefile)
+            if (img2_path, from_path) not in pending:
+                pending.append((img2_path, from_path))
+        elif gen_warp and not os.path.isfile(wimagefile):
+            img1 = iio_read(from_path).astype(np.float32)
+            iio_write(single_warp(img1, iio_read(fimagefile).astype(np.float32)).astype(np.float32), wimagefile)
 
     def createWarpedInputData(self, gen_warp=False):
         if not self.opt.check_data:
             return
+        pending = []
         for video2_path in self.noise_paths_list:
             img2_paths = list_video_files_at_dir(video2_path)
             for z in range(len(img2_paths) - self.patch_depth + 1):
                 for n in range(self.patch_depth - 1):
-                    self._ensure(img2_paths[z + self.patch_depth - 1], img2_paths[z + n], gen_warp)
+                    self._ensure(img2_paths[z + self.patch_depth - 1], img2_paths[z + n], gen_warp, pending)
+        self._flush(pending, gen_warp)
 
     def createFutureWarpedInputData(self, gen_warp=False):
         if (not self.opt.check_data) or self.future_patch_depth == 0:
             return
+        pending = []
         for video2_path in self.noise_paths_list:
             img2_paths = list_video_files_at_dir(video2_path)
             for z in range(len(img2_paths) - self.future_patch_depth):
                 for n in range(self.future_patch_depth):
-                    self._ensure(img2_paths[z], img2_paths[z + n + 1], gen_warp)
+                    self._ensure(img2_paths[z], img2_paths[z + n + 1], gen_warp, pending)
+        self._flush(pending, gen_warp)
 
     # -- samples -------------------------------------------------------------------------------------
     def __len__(self):

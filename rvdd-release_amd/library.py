@@ -33,6 +33,27 @@ class CPPbridge(object):
         flow = self.rt.tvl1flow(g1, g2)
         return flow.permute(1, 2, 0).contiguous().cpu().numpy()
 
+    def TVL1_flow_batch(self, Im1s, Im2s):
+        """Several pairs of the same size at once (not in the reference: its dataset code calls TVL1_flow in a
+        loop, data/base_dataset.py:134-249): lists of [h,w,c] images -> list of [h,w,2] flows, each identical to
+        what TVL1_flow returns for that pair."""
+        if len(Im1s) != len(Im2s):
+            raise AssertionError("TVL1_flow_batch: the two lists differ in length")
+        if len(Im1s) == 0:
+            return []
+        dev = torch.device("cuda", self.device)
+
+        def gray(ims):
+            out = []
+            for im in ims:
+                a = im if torch.is_tensor(im) else torch.as_tensor(np.asarray(im))
+                if a.dim() != 3 or a.shape[2] not in (1, 4):
+                    raise NotImplementedError("rvdd TVL1_flow: pass [h,w,1] gray or [h,w,4] packed raw images")
+                out.append(a.to(dev, torch.float32).mean(dim=2))
+            return torch.stack(out, 0).contiguous()
+        flows = self.rt.tvl1flow_batch(gray(Im1s), gray(Im2s))
+        return [f.permute(1, 2, 0).contiguous().cpu().numpy() for f in flows]
+
 
 # ---- file helpers of library.py (host side; no arithmetic beyond the [0,1] scaling) -----------------
 import fnmatch  # noqa: E402

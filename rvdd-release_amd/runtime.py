@@ -181,6 +181,17 @@ class RvddRuntime:
                                            C.byref(it) if want_iterations else None, self._stream()), "rvdd_tvl1flow")
         return (u, int(it.value)) if want_iterations else u
 
+    def tvl1flow_batch(self, I0: torch.Tensor, I1: torch.Tensor, want_iterations: bool = False):
+        """[n,ny,nx] x2 -> flows [n,2,ny,nx]: n independent pairs, two per cooperative launch."""
+        n, ny, nx = I0.shape
+        I0 = _chk_dev(I0, (n, ny, nx), "I0")
+        I1 = _chk_dev(I1, (n, ny, nx), "I1")
+        u = torch.empty(n, 2, ny, nx, dtype=torch.float32, device=I0.device)
+        it = (C.c_int32 * max(n, 1))()
+        self._check(self.lib.rvdd_tvl1flow_batch(self.h, _ptr(I0), _ptr(I1), _ptr(u), n, nx, ny,
+                                                 it if want_iterations else None, self._stream()), "rvdd_tvl1flow_batch")
+        return (u, list(it)[:n]) if want_iterations else u
+
     def ppipe(self, img: torch.Tensor, rgb_gain: float, red_gain: float, blue_gain: float, iso: int,
               bit_depth: int, layout: str = "nchw", want_float: bool = False):
         """dataset/fwd_ppipe.py:48-77,131-141.  img [n,3,H,W] ("nchw") or [n,H,W,3] ("hwc"), any strides.

@@ -113,3 +113,31 @@ def test_hip_register_and_memory_state_kernels_agree():
     assert it_mem == it_reg and torch.equal(u_mem, u_reg)
     u_again = rt.tvl1flow(I0, I1)
     assert torch.equal(u_again, u_reg)               # and the run itself is deterministic
+
+
+@pytest.mark.gpu
+def test_hip_flow_batch_equals_single_flows():
+    """rvdd_tvl1flow_batch: two pairs per cooperative launch, an odd count, pairs that converge after different
+    numbers of iterations -- every flow bit-identical to the single-pair call."""
+    from rvdd_release_amd.library import CPPbridge
+    from rvdd_release_amd.util._ops import ops_runtime
+    rt = ops_runtime(0)
+    g = [_load(n) for n in ("a_48x64",)]
+    rng = np.random.default_rng(3)
+    I0 = np.stack([g[0]["I0"], g[0]["I1"], g[0]["I0"] + 0.05 * rng.standard_normal(g[0]["I0"].shape).astype(np.float32)])
+    I1 = np.stack([g[0]["I1"], g[0]["I0"], g[0]["I1"]])
+    a, b = torch.from_numpy(I0).cuda(), torch.from_numpy(I1).cuda()
+    singles = [rt.tvl1flow(a[i], b[i], want_iterations=True) for i in range(3)]
+    flows, iters = rt.tvl1flow_batch(a, b, want_iterations=True)
+    assert flows.shape == (3, 2, 48, 64)
+    assert len({it for _, it in singles}) > 1                      # the lanes of one launch stop at different times
+    for i in range(3):
+        assert iters[i] == singles[i][1]
+        assert torch.equal(flows[i], singles[i][0])
+    _close(flows[0].cpu().numpy(), g[0]["flow"])
+    assert rt.tvl1flow_batch(a[:0], b[:0]).shape == (0, 2, 48, 64)
+    # the bridge-level call used by the dataset
+    raw = [np.repeat(I0[i][:, :, None], 4, axis=2) for i in range(3)], [np.repeat(I1[i][:, :, None], 4, axis=2) for i in range(3)]
+    out = CPPbridge().TVL1_flow_batch(*raw)
+    assert len(out) == 3 and out[1].shape == (48, 64, 2)
+    assert np.array_equal(out[1], flows[1].permute(1, 2, 0).cpu().numpy())

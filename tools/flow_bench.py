@@ -25,6 +25,12 @@ torch.cuda.synchronize()
 gpu_s = (time.perf_counter() - t0) / npairs
 out = {"metric": "TV-L1 flows/sec, 640x360 pairs", "gpu_flows_per_s": round(1 / gpu_s, 2), "gpu_ms_per_flow": round(1e3 * gpu_s, 2),
        "mean_iterations": float(np.mean(iters)), "median_flow_px": [float(flows[0][0].median()), float(flows[0][1].median())]}
+# the dataset's offline case: independent pairs, two per cooperative launch
+torch.cuda.synchronize(); t0 = time.perf_counter()
+fb = rt.tvl1flow_batch(gray[1:npairs + 1].contiguous(), gray[0:npairs].contiguous())
+torch.cuda.synchronize(); bat_s = (time.perf_counter() - t0) / npairs
+out.update({"gpu_batched_flows_per_s": round(1 / bat_s, 2), "gpu_batched_ms_per_flow": round(1e3 * bat_s, 2),
+            "batched_equals_single": bool(all(torch.equal(fb[i], flows[i]) for i in range(npairs)))})
 ref = os.path.join(REPO, "oracle", "_ref", "libBridge.so")
 if os.path.exists(ref):
     lib = ctypes.CDLL(ref); lib.tvl1flow.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int] * 2; lib.tvl1flow.restype = None
