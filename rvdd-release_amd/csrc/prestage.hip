@@ -209,23 +209,24 @@ __global__ void warp3_kernel(const float* __restrict__ src4, const float* __rest
     o[2] = acc[2];
 }
 
-// 192 threads = 16 pixels x 12 float4 chunks.  The 16 taps of a pixel (flow upsample, coordinate
-// round trip, cubic weights: ~150 VALU instructions) are computed ONCE per pixel by the first 16
-// threads and shared through LDS; computed by each of the 12 lanes of a pixel they cost as much
-// SIMD time as the gather itself.
+// grid = (ceil(W/32), H, B), 192 threads = 16 PAIRS of horizontally adjacent pixels x 12 float4 chunks.
+//  * The 16 taps of a pixel (flow upsample, coordinate round trip, cubic weights: ~150 VALU instructions) are
+//    computed ONCE per pixel by the first 32 threads and shared through LDS; computed by each of the 12 lanes of
+//    a pixel they cost as much SIMD time as the gather itself.
+//  * The gather is bound by the texture-address path (16 x 16-B loads per lane and pixel, not by HBM: neighbouring
+//    pixels re-read the same lines from L1).  Where the flow is smooth the 4x4 footprints of the two pixels of a
+//    pair are the same rows and columns shifted by one: 20 loads serve both instead of 32.  Pairs whose footprints
+//    do not line up (flow discontinuities, the clamped image border) take the plain 2 x 16 path; the arithmetic of
+//    a pixel is the same in both.
 __global__ __launch_bounds__(192) void warp48_kernel(const float* __restrict__ src,
                                                      const float* __restrict__ flow_raw,
                                                      float* __restrict__ dst, int B, int H, int W) {
-    __shared__ int s_i[16][8];      // xi[4], yi[4]
-    __shared__ float s_w[16][8];    // wx[4], wy[4]
-    const size_t npix = (size_t)B * H * W;
-    const size_t pix0 = (size_t)blockIdx.x * 16;
-    if (threadIdx.x < 16) {
-        const size_t pix = pix0 + threadIdx.x;
-        if (pix < npix) {
-            const int x = pix % W;
-            const int y = (pix / W) % H;
-            const int b = pix / ((size_t)W * H);
+    __shared__ int s_i[32][8];      // xi[4], yi[4] * W
+    __shared__ float s_w[32][8];    // wx[4], wy[4]
+    const int y = blockIdx.y, b = blockIdx.z, x0 = blockIdx.x * 32;
+    if (threadIdx.x < 32) {
+        const int x = x0 + threadIdx.x;
+        if (x < W) {
             const int h = H / 2, w = W / 2;
             float fx, fy;
             flow_at(flow_raw + (size_t)b * 2 * h * w, h, w, H, W, y, x, fx, fy);
@@ -243,19 +244,52 @@ __global__ __launch_bounds__(192) void warp48_kernel(const float* __restrict__ s
     __syncthreads();
     const int p = threadIdx.x / 12;
     const int c4 = threadIdx.x - p * 12;
-    const size_t pix = pix0 + p;
-    if (pix >= npix) return;
-    const int b = pix / ((size_t)W * H);
+    const int pa = 2 * p, pb = 2 * p + 1, xa = x0 + pa;
+    if (xa >= W) return;
+    const bool has_b = xa + 1 < W;
     const f32x4* s = reinterpret_cast<const f32x4*>(src) + (size_t)b * H * W * 12 + c4;
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    f32x4* o = reinterpret_cast<f32x4*>(dst) + (((size_t)b * H + y) * W + xa) * 12 + c4;
+    int xia[4], yia[4], xib[4], yib[4];
+    float wxa[4], wya[4], wxb[4], wyb[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        f32x4 row = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int i = 0; i < 4; ++i) row = row + s[(size_t)(s_i[p][4 + j] + s_i[p][i]) * 12] * s_w[p][i];
-        acc = acc + row * s_w[p][4 + j];
+    for (int k = 0; k < 4; ++k) {
+        xia[k] = s_i[pa][k]; yia[k] = s_i[pa][4 + k]; wxa[k] = s_w[pa][k]; wya[k] = s_w[pa][4 + k];
+        xib[k] = s_i[pb][k]; yib[k] = s_i[pb][4 + k]; wxb[k] = s_w[pb][k]; wyb[k] = s_w[pb][4 + k];
     }
-    reinterpret_cast<f32x4*>(dst)[pix * 12 + c4] = acc;
+    const bool lined_up = has_b && yib[0] == yia[0] && yib[1] == yia[1] && yib[2] == yia[2] && yib[3] == yia[3] &&
+                          xib[0] == xia[1] && xib[1] == xia[2] && xib[2] == xia[3];
+    f32x4 acca = {0.f, 0.f, 0.f, 0.f}, accb = {0.f, 0.f, 0.f, 0.f};
+    if (lined_up) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const f32x4 v0 = s[(yia[j] + xia[0]) * 12], v1 = s[(yia[j] + xia[1]) * 12], v2 = s[(yia[j] + xia[2]) * 12];
+            const f32x4 v3 = s[(yia[j] + xia[3]) * 12], v4 = s[(yia[j] + xib[3]) * 12];
+            f32x4 ra = {0.f, 0.f, 0.f, 0.f}, rb = {0.f, 0.f, 0.f, 0.f};
+            ra = ra + v0 * wxa[0]; ra = ra + v1 * wxa[1]; ra = ra + v2 * wxa[2]; ra = ra + v3 * wxa[3];
+            rb = rb + v1 * wxb[0]; rb = rb + v2 * wxb[1]; rb = rb + v3 * wxb[2]; rb = rb + v4 * wxb[3];
+            acca = acca + ra * wya[j];
+            accb = accb + rb * wyb[j];
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            f32x4 ra = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) ra = ra + s[(yia[j] + xia[i]) * 12] * wxa[i];
+            acca = acca + ra * wya[j];
+        }
+        if (has_b) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                f32x4 rb = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) rb = rb + s[(yib[j] + xib[i]) * 12] * wxb[i];
+                accb = accb + rb * wyb[j];
+            }
+        }
+    }
+    o[0] = acca;
+    if (has_b) o[12] = accb;
 }
 
 __global__ void warp_nchw_kernel(const float* __restrict__ xin, const float* __restrict__ flow,
@@ -308,15 +342,13 @@ __global__ void upsample_flow_kernel(const float* __restrict__ t, float* __restr
 // nn.Upsample(scale_factor=2, mode="bilinear"[, align_corners]) on NHWC48,
 // 12 threads per output pixel.  ATen upsample_bilinear2d source index:
 //   align_corners=False: src = max(0.5*(dst+0.5)-0.5, 0);  True: src = dst*(in-1)/(out-1)
-__global__ void upsample2x_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int h,
-                                  int w, int Hout, int Wout, int oy, int ox, int align) {
-    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const size_t pix = gid / 12;
-    const int c4 = gid - pix * 12;
-    if (pix >= (size_t)B * Hout * Wout) return;
-    const int X = pix % Wout;
-    const int Y = (pix / Wout) % Hout;
-    const int b = pix / ((size_t)Wout * Hout);
+// grid = (ceil(Wout/16), Hout, B), 192 threads = 16 output pixels of one row x 12 float4 chunks: the row terms
+// (source rows, vertical weights) depend on blockIdx only and stay in scalar registers, no 64-bit divisions
+__global__ __launch_bounds__(192) void upsample2x_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int h,
+                                                         int w, int Hout, int Wout, int oy, int ox, int align) {
+    const int p = threadIdx.x / 12, c4 = threadIdx.x - p * 12;
+    const int X = blockIdx.x * 16 + p, Y = blockIdx.y, b = blockIdx.z;
+    if (X >= Wout) return;
     const int y = Y - oy, x = X - ox;
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
     if ((unsigned)y < (unsigned)(2 * h) && (unsigned)x < (unsigned)(2 * w)) {
@@ -335,11 +367,11 @@ __global__ void upsample2x_kernel(const float* __restrict__ in, float* __restric
         const float ly1 = py - (float)y0, lx1 = px - (float)x0;
         const float ly0 = 1.f - ly1, lx0 = 1.f - lx1;
         const f32x4* s = reinterpret_cast<const f32x4*>(in) + (size_t)b * h * w * 12 + c4;
-        const f32x4 v00 = s[((size_t)y0 * w + x0) * 12], v01 = s[((size_t)y0 * w + x1) * 12];
-        const f32x4 v10 = s[((size_t)y1 * w + x0) * 12], v11 = s[((size_t)y1 * w + x1) * 12];
+        const f32x4 v00 = s[(y0 * w + x0) * 12], v01 = s[(y0 * w + x1) * 12];
+        const f32x4 v10 = s[(y1 * w + x0) * 12], v11 = s[(y1 * w + x1) * 12];
         v = (v00 * lx0 + v01 * lx1) * ly0 + (v10 * lx0 + v11 * lx1) * ly1;
     }
-    reinterpret_cast<f32x4*>(out)[gid] = v;
+    reinterpret_cast<f32x4*>(out)[(((size_t)b * Hout + Y) * Wout + X) * 12 + c4] = v;
 }
 
 __global__ void maxpool2_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int H,
@@ -486,8 +518,8 @@ hipError_t launch_warp3(const float* src4, const float* flow_raw, float* dst, in
 
 hipError_t launch_warp48(const float* src, const float* flow_raw, float* dst, int B, int H, int W,
                          hipStream_t s) {
-    const size_t npix = (size_t)B * H * W;
-    hipLaunchKernelGGL(warp48_kernel, dim3(nblocks(npix, 16)), dim3(192), 0, s, src, flow_raw, dst, B, H, W);
+    if (!B || !H || !W) return hipSuccess;
+    hipLaunchKernelGGL(warp48_kernel, dim3((W + 31) / 32, H, B), dim3(192), 0, s, src, flow_raw, dst, B, H, W);
     return hipGetLastError();
 }
 
@@ -508,8 +540,8 @@ hipError_t launch_upsample_flow(const float* t, float* out, int nc, int h, int w
 
 hipError_t launch_upsample2x(const float* in, float* out, int B, int h, int w, int Hout, int Wout, int oy,
                              int ox, bool align_corners, hipStream_t s) {
-    const size_t n = (size_t)B * Hout * Wout * 12;
-    hipLaunchKernelGGL(upsample2x_kernel, dim3(nblocks(n, 192)), dim3(192), 0, s, in, out, B, h, w, Hout, Wout,
+    if (!B || !Hout || !Wout) return hipSuccess;
+    hipLaunchKernelGGL(upsample2x_kernel, dim3((Wout + 15) / 16, Hout, B), dim3(192), 0, s, in, out, B, h, w, Hout, Wout,
                        oy, ox, align_corners ? 1 : 0);
     return hipGetLastError();
 }
