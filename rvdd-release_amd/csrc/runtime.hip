@@ -151,12 +151,15 @@ std::vector<float> arrange_conv3x3(const HostTensor& t, int c0, int cn, int cin_
 
 // OIHW [48][cin_total][3][3], channels [c0, c0+48) -> U = G g G^T per (cout, cin), stored
 // [pos 16][j 3][m 3][cout&15][g 4][i 4] with channel = c0 + 16j+4g+i: the A-fragment order of wino3x3.hip.
-std::vector<float> arrange_wino3x3(const HostTensor& t, int c0) {
+// nj = 3: input channels c0 .. c0+47 of the filter; nj = 1: the first layer, channels 0 .. cin_total-1 (6 or 9)
+// zero-padded to 16
+std::vector<float> arrange_wino3x3(const HostTensor& t, int c0, int nj = 3) {
     const int cin_total = (int)t.shape[1];
+    const int nc = nj == 3 ? 48 : (cin_total < 16 ? cin_total : 16);
     static const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
-    std::vector<float> out((size_t)16 * 3 * 3 * 256, 0.f);
+    std::vector<float> out((size_t)16 * nj * 3 * 256, 0.f);
     for (int co = 0; co < 48; ++co)
-        for (int c = 0; c < 48; ++c) {
+        for (int c = 0; c < nc; ++c) {
             const float* gk = &t.data[((size_t)co * cin_total + c0 + c) * 9];
             double tmp[4][3], u[4][4];
             for (int i = 0; i < 4; ++i)
@@ -165,7 +168,7 @@ std::vector<float> arrange_wino3x3(const HostTensor& t, int c0) {
                 for (int k = 0; k < 4; ++k) u[i][k] = tmp[i][0] * G[k][0] + tmp[i][1] * G[k][1] + tmp[i][2] * G[k][2];
             const int j = c / 16, g = (c % 16) / 4, ii = c % 4, m = co / 16, lr = co % 16;
             for (int pos = 0; pos < 16; ++pos)
-                out[((((size_t)(pos * 3 + j) * 3 + m) * 16 + lr) * 4 + g) * 4 + ii] = (float)u[pos / 4][pos % 4];
+                out[((((size_t)(pos * nj + j) * 3 + m) * 16 + lr) * 4 + g) * 4 + ii] = (float)u[pos / 4][pos % 4];
         }
     return out;
 }
@@ -393,10 +396,12 @@ int run_conv(rvdd_t* h, const Conv3& L, const ConvCall& c, hipStream_t s) {
     a.b3 = h->b_out;
     a.out3_nchw = c.out3_nchw;
     a.out3_nhwc4 = c.out3_nhwc4;
-    if (cin == 48 && L.wu[c.src] && wino_applies(h, c.H, c.W)) {
+    const bool c16_ok = cin != 48 && !c.acc_in && (c.epi == EPI_NONE || c.epi == EPI_RELU);
+    if ((cin == 48 || c16_ok) && L.wu[c.src] && wino_applies(h, c.H, c.W)) {
         a.w = L.wu[c.src];
-        Scope sc(h, s, wino_name(c.epi, c.acc_in != nullptr), flops, bytes);
-        HIPCHK(h, launch_wino3x3(a, c.epi, s));
+        Scope sc(h, s, cin == 48 ? wino_name(c.epi, c.acc_in != nullptr)
+                                 : (c.epi == EPI_NONE ? "wino3x3_c16_kernel<0>" : "wino3x3_c16_kernel<1>"), flops, bytes);
+        HIPCHK(h, launch_wino3x3(a, cin == 48 ? 48 : 16, c.epi, s));
         return RVDD_OK;
     }
     Scope sc(h, s, conv_name(cin, c.epi, c.acc_in != nullptr), flops, bytes);
@@ -654,7 +659,7 @@ int rvdd_finalize_weights(rvdd_t* h) {
                 L.cin_real[0] = cin;
                 L.cin_pad[0] = cin == 48 ? 48 : kNetInC;
                 RC(upload(h, &L.w[0], arrange_conv3x3(wt, 0, cin, L.cin_pad[0])));
-                if (cin == 48) RC(upload(h, &L.wu[0], arrange_wino3x3(wt, 0)));
+                RC(upload(h, &L.wu[0], cin == 48 ? arrange_wino3x3(wt, 0) : arrange_wino3x3(wt, 0, 1)));
             }
             RC(upload(h, &L.bias, h->staged.at(n + ".bias").data));
             h->conv3[n] = L;

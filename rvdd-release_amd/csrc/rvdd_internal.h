@@ -38,7 +38,7 @@ struct ConvArgs {
 hipError_t launch_conv3x3(const ConvArgs& a, int cin, int epi, hipStream_t s);
 size_t conv3x3_weight_floats(int cin);
 // Winograd F(2x2,3x3) variant for 48 -> 48 layers; a.w = bank arranged by arrange_wino3x3 (runtime.hip)
-hipError_t launch_wino3x3(const ConvArgs& a, int epi, hipStream_t s);
+hipError_t launch_wino3x3(const ConvArgs& a, int cin, int epi, hipStream_t s);   // cin: 48, or 16 = the zero-padded network input
 size_t wino3x3_weight_floats();
 void conv3x3_set_variant(int v);   // A/B switch used by rvdd_debug_conv_bench only
 

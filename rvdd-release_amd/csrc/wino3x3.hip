@@ -27,8 +27,10 @@
 
 namespace {
 
-constexpr int U_FLOATS = 16 * 3 * 3 * 256;        // 36864 floats = 147456 B
-constexpr size_t U_LDS_BYTES = (size_t)U_FLOATS * 4;
+// transformed filter bank: 16 positions x NJ 16-channel input chunks x 3 cout blocks x 256 floats
+// (NJ = 3: 48 -> 48, 144 KiB; NJ = 1: the first layer, 16 (6 or 9 real) -> 48, 48 KiB)
+constexpr int u_floats(int nj) { return 16 * nj * 3 * 256; }
+constexpr int U_FLOATS = u_floats(3);
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void lds_void;
 
@@ -75,9 +77,11 @@ struct UnitPos {
     int b, ty, tx;
 };
 
-template <int EPI, bool ACC_IN>
-__global__ __launch_bounds__(256, 1) void wino3x3_kernel(ConvArgs a) {
+template <int EPI, bool ACC_IN, int NJ>
+__device__ __forceinline__ void wino_body(const ConvArgs& a) {
     extern __shared__ __attribute__((aligned(16))) float U[];
+    constexpr int CIN = 16 * NJ;          // channels per input pixel (NHWC); outputs and side inputs are always kF wide
+    constexpr int UF = u_floats(NJ);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -85,8 +89,8 @@ __global__ __launch_bounds__(256, 1) void wino3x3_kernel(ConvArgs a) {
     const int g = lane >> 4;
 
     {   // transformed filter bank -> LDS (linear copy of the host arrangement)
-        __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, U_FLOATS * 4, 0x00020000);
-        for (int k = wave; k < U_FLOATS / 256; k += 4)
+        __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, UF * 4, 0x00020000);
+        for (int k = wave; k < UF / 256; k += 4)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lds_void*)(U + k * 256), 16, (unsigned)(k * 1024 + lane * 16),
                                                      0, 0, 0);
     }
@@ -94,9 +98,10 @@ __global__ __launch_bounds__(256, 1) void wino3x3_kernel(ConvArgs a) {
     __syncthreads();
 
     const int units_per_img = a.tiles_x * a.tiles_y;
-    const unsigned in_bytes = (unsigned)(a.H * a.W * kF * 4);
+    const unsigned in_bytes = (unsigned)(a.H * a.W * CIN * 4);      // the conv input
+    const unsigned map_bytes = (unsigned)(a.H * a.W * kF * 4);      // 48-channel maps of the input's size (partial sums, residuals)
     const unsigned out_bytes = (unsigned)(a.Hout * a.Wout * kF * 4);
-    const int row_bytes = a.W * kF * 4;
+    const int row_bytes = a.W * CIN * 4;
 
     auto locate = [&](int unit, UnitPos& u) {
         // integer division runs on the VALU: tell hipcc the results are wave-uniform, or every
@@ -113,16 +118,16 @@ __global__ __launch_bounds__(256, 1) void wino3x3_kernel(ConvArgs a) {
     // (a few VALU ops) instead of being kept in 16 registers.
     auto load_patch = [&](f32x4 (&p)[16], const UnitPos& u, int j) {
         __amdgpu_buffer_rsrc_t r =
-            __builtin_amdgcn_make_buffer_rsrc((void*)(a.in + (size_t)u.b * a.H * a.W * kF), 0, in_bytes, 0x00020000);
+            __builtin_amdgcn_make_buffer_rsrc((void*)(a.in + (size_t)u.b * a.H * a.W * CIN), 0, in_bytes, 0x00020000);
         const int y0 = 2 * u.ty - 1, x0 = 2 * u.tx - 1;
-        const int base = (y0 * a.W + x0) * (kF * 4) + (16 * j + 4 * g) * 4;
+        const int base = (y0 * a.W + x0) * (CIN * 4) + (16 * j + 4 * g) * 4;
         // branch-free validity: an invalid row / column adds 2^30 to the offset, which pushes it
         // past num_records (< 2^31) whatever the (possibly negative) base is
         int ro[4], co[4];
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
             ro[d] = (unsigned)(y0 + d) < (unsigned)a.H ? d * row_bytes : 0x40000000;
-            co[d] = (unsigned)(x0 + d) < (unsigned)a.W ? d * (kF * 4) : 0x40000000;
+            co[d] = (unsigned)(x0 + d) < (unsigned)a.W ? d * (CIN * 4) : 0x40000000;
         }
 #pragma unroll
         for (int dy = 0; dy < 4; ++dy)
@@ -134,7 +139,7 @@ __global__ __launch_bounds__(256, 1) void wino3x3_kernel(ConvArgs a) {
     f32x4 pb[2][16];      // ping-pong patch buffers (raw patch -> transformed in place)
     f32x4 acc[16][3];
     auto ldsA = [&](int j, int pos, int m) {
-        return *reinterpret_cast<const f32x4*>(ub + ((pos * 3 + j) * 3 + m) * 256);
+        return *reinterpret_cast<const f32x4*>(ub + ((pos * NJ + j) * 3 + m) * 256);
     };
 
     // One pipeline stage = chunk J of the current unit: 16 steps (positions) of 3 A fragments and
@@ -207,7 +212,7 @@ __global__ __launch_bounds__(256, 1) void wino3x3_kernel(ConvArgs a) {
         // seeds of this unit's accumulators (see the position order in `stage`)
         if constexpr (ACC_IN) {
             __amdgpu_buffer_rsrc_t pr = __builtin_amdgcn_make_buffer_rsrc(
-                (void*)(a.acc_in + (size_t)cur.b * a.H * a.W * kF), 0, in_bytes, 0x00020000);
+                (void*)(a.acc_in + (size_t)cur.b * a.H * a.W * kF), 0, map_bytes, 0x00020000);
             constexpr int corner[4] = {0, 3, 12, 15};
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -220,17 +225,21 @@ __global__ __launch_bounds__(256, 1) void wino3x3_kernel(ConvArgs a) {
 #pragma unroll
             for (int m = 0; m < 3; ++m) acc[5][m] = *reinterpret_cast<const f32x4*>(a.bias + 16 * m + 4 * g);
         }
-        stage(I0{}, XP{}, true, cur, 1);
-        stage(I1{}, XQ{}, false, cur, 2);
-        stage(I2{}, XP{}, false, nxt, 0);
+        if constexpr (NJ == 3) {
+            stage(I0{}, XP{}, true, cur, 1);
+            stage(I1{}, XQ{}, false, cur, 2);
+            stage(I2{}, XP{}, false, nxt, 0);
+        } else {
+            stage(I0{}, XP{}, true, nxt, 0);     // one chunk per unit: the next unit's patch is the one in flight
+        }
 
         // ---- output transform A^T M A, epilogue, stores
         __amdgpu_buffer_rsrc_t orr = __builtin_amdgcn_make_buffer_rsrc(
             (void*)(a.out + (size_t)cur.b * a.Hout * a.Wout * kF), 0, out_bytes, 0x00020000);
         __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(
-            (void*)((EPI == EPI_RELU_ADD2 ? a.res1 : a.in) + (size_t)cur.b * a.H * a.W * kF), 0, in_bytes, 0x00020000);
+            (void*)((EPI == EPI_RELU_ADD2 ? a.res1 : a.out) + (size_t)cur.b * a.H * a.W * kF), 0, map_bytes, 0x00020000);
         __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc(
-            (void*)((EPI == EPI_RELU_ADD2 ? a.res2 : a.in) + (size_t)cur.b * a.H * a.W * kF), 0, in_bytes, 0x00020000);
+            (void*)((EPI == EPI_RELU_ADD2 ? a.res2 : a.out) + (size_t)cur.b * a.H * a.W * kF), 0, map_bytes, 0x00020000);
         const int oy = 2 * cur.ty, ox = 2 * cur.tx;
         unsigned po[4], so[4];     // per output pixel q = 2*row+col: offsets in the input-size map / in `out`
 #pragma unroll
@@ -331,9 +340,22 @@ __global__ __launch_bounds__(256, 1) void wino3x3_kernel(ConvArgs a) {
 }
 
 template <int EPI, bool ACC_IN>
+__global__ __launch_bounds__(256, 1) void wino3x3_kernel(ConvArgs a) {
+    wino_body<EPI, ACC_IN, 3>(a);
+}
+// the first layer: 16-channel (zero-padded 6 / 9) network input
+template <int EPI>
+__global__ __launch_bounds__(256, 1) void wino3x3_c16_kernel(ConvArgs a) {
+    wino_body<EPI, false, 1>(a);
+}
+
+template <int EPI, bool ACC_IN, int NJ>
 hipError_t launch_w(const ConvArgs& a0, hipStream_t s) {
     static bool attr_done = false;
-    auto kern = wino3x3_kernel<EPI, ACC_IN>;
+    void (*kern)(ConvArgs);
+    if constexpr (NJ == 3) kern = wino3x3_kernel<EPI, ACC_IN>;
+    else kern = wino3x3_c16_kernel<EPI>;
+    constexpr size_t U_LDS_BYTES = (size_t)u_floats(NJ) * 4;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)U_LDS_BYTES);
@@ -356,22 +378,29 @@ hipError_t launch_w(const ConvArgs& a0, hipStream_t s) {
 
 size_t wino3x3_weight_floats() { return U_FLOATS; }
 
-hipError_t launch_wino3x3(const ConvArgs& a, int epi, hipStream_t s) {
+hipError_t launch_wino3x3(const ConvArgs& a, int cin, int epi, hipStream_t s) {
     if (a.ntiles <= 0) return hipSuccess;
+    if (cin == 16) {
+        if (a.acc_in || (size_t)a.H * a.W * kF * 4 >= 0x80000000ull) return hipErrorInvalidValue;
+        if (epi == EPI_NONE) return launch_w<EPI_NONE, false, 1>(a, s);
+        if (epi == EPI_RELU) return launch_w<EPI_RELU, false, 1>(a, s);
+        return hipErrorInvalidValue;
+    }
+    if (cin != 48) return hipErrorInvalidValue;
     if ((size_t)a.H * a.W * kF * 4 >= 0x80000000ull || (size_t)a.Hout * a.Wout * kF * 4 >= 0x80000000ull)
         return hipErrorInvalidValue;
     const bool acc = a.acc_in != nullptr;
     switch (epi) {
         case EPI_NONE:
-            return acc ? launch_w<EPI_NONE, true>(a, s) : launch_w<EPI_NONE, false>(a, s);
+            return acc ? launch_w<EPI_NONE, true, 3>(a, s) : launch_w<EPI_NONE, false, 3>(a, s);
         case EPI_RELU:
-            return acc ? launch_w<EPI_RELU, true>(a, s) : launch_w<EPI_RELU, false>(a, s);
+            return acc ? launch_w<EPI_RELU, true, 3>(a, s) : launch_w<EPI_RELU, false, 3>(a, s);
         case EPI_POOL:
-            return acc ? hipErrorInvalidValue : launch_w<EPI_POOL, false>(a, s);
+            return acc ? hipErrorInvalidValue : launch_w<EPI_POOL, false, 3>(a, s);
         case EPI_RELU_ADD2:
-            return acc ? hipErrorInvalidValue : launch_w<EPI_RELU_ADD2, false>(a, s);
+            return acc ? hipErrorInvalidValue : launch_w<EPI_RELU_ADD2, false, 3>(a, s);
         case EPI_RELU_OUT3:
-            return acc ? hipErrorInvalidValue : launch_w<EPI_RELU_OUT3, false>(a, s);
+            return acc ? hipErrorInvalidValue : launch_w<EPI_RELU_OUT3, false, 3>(a, s);
     }
     return hipErrorInvalidValue;
 }
