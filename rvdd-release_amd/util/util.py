@@ -16,28 +16,26 @@ def psnr(input, target, max_val):
 
 
 def tensor2im(input_image, imtype=None, clip=False, iT=None, force3chan=False):
-    """util/util.py:23-49: [1,C,H,W] tensor in [-1,1] -> float32 [H,W,C] image in [0,255] (what
-    `save_images` writes).  The conversion is three fp32 operations on the host copy, as there."""
+    """util/util.py:23-49 of the reference: first item of a [N,C,H,W] tensor in [-1,1] -> [H,W,C] image in [0,255]
+    (float32 unless `imtype` says otherwise): what `save_images` writes.  NumPy input passes through, anything that
+    is neither a tensor nor an array is returned untouched.  Three fp32 operations on the host copy, as there."""
     import numpy as np
-    imtype = np.float32 if imtype is None else imtype
-    if not isinstance(input_image, np.ndarray):
-        if not isinstance(input_image, torch.Tensor):
-            return input_image
-        image_tensor = input_image.data
-        if iT is None:
-            image_numpy = image_tensor[0].cpu().float().numpy()
-            if image_numpy.shape[0] == 1:
-                image_numpy = np.tile(image_numpy, (3, 1, 1))
-            image_numpy = (np.transpose(image_numpy, (1, 2, 0)) + 1) / 2.0 * 255.0
+    if torch.is_tensor(input_image):
+        item = input_image.detach()[0].cpu()
+        if iT is not None:
+            img = iT(item) * 255.0
         else:
-            image_numpy = iT(image_tensor[0].cpu()) * 255.0
+            chw = item.float().numpy()
+            chw = np.tile(chw, (3, 1, 1)) if chw.shape[0] == 1 else chw        # gray -> three equal channels
+            img = (chw.transpose(1, 2, 0) + 1) / 2.0 * 255.0
+    elif isinstance(input_image, np.ndarray):
+        img = input_image
     else:
-        image_numpy = input_image
-    if clip:
-        image_numpy = np.clip(image_numpy, 0, 255)
-    if force3chan and np.shape(image_numpy)[2] == 4:
-        image_numpy = image_numpy[:, :, :3]
-    return image_numpy.astype(imtype)
+        return input_image
+    img = np.clip(img, 0, 255) if clip else img
+    if force3chan and img.shape[2] == 4:
+        img = img[:, :, :3]
+    return img.astype(np.float32 if imtype is None else imtype)
 
 
 def save_image(image_numpy, image_path):
