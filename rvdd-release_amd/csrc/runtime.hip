@@ -773,6 +773,7 @@ int rvdd_unet_forward(rvdd_t* h, const float* x, const float* feat_in, float* ou
 }
 
 int rvdd_demosaic_ha(rvdd_t* h, const float* raw, int32_t n, int32_t hh, int32_t ww, float* rgb, void* stream) {
+    if (h && n == 0) return RVDD_OK;       // an empty batch is valid and launches nothing
     if (!h || !raw || !rgb || n < 0 || hh < 1 || ww < 1) return fail(h, RVDD_ERR_ARG, "rvdd_demosaic_ha: bad argument");
     hipStream_t s = static_cast<hipStream_t>(stream);
     RC(ensure_scratch(h, (size_t)n * 4 * hh * ww * sizeof(float)));
@@ -783,6 +784,7 @@ int rvdd_demosaic_ha(rvdd_t* h, const float* raw, int32_t n, int32_t hh, int32_t
 
 int rvdd_warp_bicubic(rvdd_t* h, const float* x, const float* flow, int32_t n, int32_t c, int32_t H, int32_t W,
                       float* y, void* stream) {
+    if (h && n == 0) return RVDD_OK;
     if (!h || !x || !flow || !y || n < 0 || c < 1 || H < 2 || W < 2) return fail(h, RVDD_ERR_ARG, "rvdd_warp_bicubic: bad argument");
     HIPCHK(h, launch_warp_nchw(x, flow, y, n, c, H, W, static_cast<hipStream_t>(stream)));
     return RVDD_OK;
@@ -790,6 +792,7 @@ int rvdd_warp_bicubic(rvdd_t* h, const float* x, const float* flow, int32_t n, i
 
 int rvdd_upsample_factor_2(rvdd_t* h, const float* t, int32_t n, int32_t c, int32_t hh, int32_t ww,
                            float multiply_by, float* out, void* stream) {
+    if (h && n == 0) return RVDD_OK;
     if (!h || !t || !out || n < 0 || c < 1 || hh < 1 || ww < 1) return fail(h, RVDD_ERR_ARG, "rvdd_upsample_factor_2: bad argument");
     HIPCHK(h, launch_upsample_flow(t, out, n * c, hh, ww, multiply_by, static_cast<hipStream_t>(stream)));
     return RVDD_OK;
@@ -798,6 +801,8 @@ int rvdd_upsample_factor_2(rvdd_t* h, const float* t, int32_t n, int32_t c, int3
 int rvdd_tvl1flow(rvdd_t* h, const float* I0, const float* I1, float* u, int32_t nx, int32_t ny, int32_t* iterations,
                   void* stream) {
     if (!h || !I0 || !I1 || !u || nx < 16 || ny < 16) return fail(h, RVDD_ERR_ARG, "rvdd_tvl1flow: bad argument (images must be >= 16x16)");
+    if (!tvl1_size_ok(nx, ny))
+        return fail(h, RVDD_ERR_ARG, "rvdd_tvl1flow: image too skinny for its pyramid (the reference reads out of bounds at this size)");
     if (!h->tvl1 || tvl1_ws_nx(h->tvl1) != nx || tvl1_ws_ny(h->tvl1) != ny) {
         HIPCHK(h, hipDeviceSynchronize());
         tvl1_free(h->tvl1);
@@ -813,6 +818,7 @@ int rvdd_tvl1flow(rvdd_t* h, const float* I0, const float* I1, float* u, int32_t
 int rvdd_ppipe(rvdd_t* h, const float* img, int32_t n, int32_t H, int32_t W, int64_t sn, int64_t sc, int64_t sy, int64_t sx,
                int32_t bit_depth, double rgb_gain, double red_gain, double blue_gain, int32_t iso, uint8_t* out_u8,
                float* out_f32, void* stream) {
+    if (h && n == 0) return RVDD_OK;
     if (!h || !img || !out_u8 || n < 0 || H < 1 || W < 1) return fail(h, RVDD_ERR_ARG, "rvdd_ppipe: bad argument");
     if (!(rgb_gain != 0.0) || !(red_gain != 0.0) || !(blue_gain != 0.0)) return fail(h, RVDD_ERR_ARG, "rvdd_ppipe: zero gain");
     // fwd_ppipe.py:29: a float32 tensor of Python-double quotients
@@ -846,6 +852,8 @@ int rvdd_tvl1flow_batch(rvdd_t* h, const float* I0, const float* I1, float* u, i
     if (h && n == 0) return RVDD_OK;
     if (!h || !I0 || !I1 || !u || n < 0 || nx < 16 || ny < 16)
         return fail(h, RVDD_ERR_ARG, "rvdd_tvl1flow_batch: bad argument (images must be >= 16x16)");
+    if (!tvl1_size_ok(nx, ny))
+        return fail(h, RVDD_ERR_ARG, "rvdd_tvl1flow_batch: image too skinny for its pyramid (the reference reads out of bounds at this size)");
     if (!h->tvl1 || tvl1_ws_nx(h->tvl1) != nx || tvl1_ws_ny(h->tvl1) != ny) {
         HIPCHK(h, hipDeviceSynchronize());
         tvl1_free(h->tvl1);

@@ -116,6 +116,7 @@ struct Tvl1Workspace;
 hipError_t tvl1_alloc(Tvl1Workspace** out, int nx, int ny);
 void tvl1_free(Tvl1Workspace* w);
 int tvl1_num_scales(int nx, int ny);
+bool tvl1_size_ok(int nx, int ny);   // false where the reference's own pyramid reads out of bounds (very skinny images)
 // I0, I1 [ny][nx] -> u [2][ny][nx]; synchronises the stream every few iterations (convergence peek)
 hipError_t tvl1_run(Tvl1Workspace* w, const float* I0, const float* I1, float* u, hipStream_t st, int* total_iters);
 hipError_t tvl1_run_batch(Tvl1Workspace* w, const float* I0, const float* I1, float* u, int n, hipStream_t st, int* iters);

@@ -606,6 +606,21 @@ int tvl1_num_scales(int nx, int ny) {
     return ns < 1 ? 1 : ns;
 }
 
+// The zoom-out Gaussian (sigma 0.6*sqrt(3): 6 taps a side) is applied to every scale but the coarsest.  The
+// reference sizes its pyramid from the image DIAGONAL (tvl1flow_lib.c / libBridge.cpp:131-136), so a very skinny image
+// gets scales whose short side is below the filter's reach and the reference then reads outside its buffers
+// (mask.c:262-325 has no guard).  Those sizes are refused here instead of reproducing undefined behaviour.
+bool tvl1_size_ok(int nx, int ny) {
+    const int ns = tvl1_num_scales(nx, ny);
+    int sx = nx, sy = ny;
+    for (int s = 0; s + 1 < ns; ++s) {
+        if ((sx < sy ? sx : sy) < 6) return false;
+        sx = (int)((float)sx * kZoom + 0.5f);
+        sy = (int)((float)sy * kZoom + 0.5f);
+    }
+    return nx >= 16 && ny >= 16;
+}
+
 static hipError_t tvl1_add_lane(Tvl1Workspace* w) {
     hipError_t err = hipSuccess;
     auto A = [&](float** p, size_t n) {

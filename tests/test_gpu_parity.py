@@ -278,3 +278,19 @@ def test_full_size_720p_vs_oracle_and_invariants():
     finally:
         del os.environ["RVDD_CONV"]
     assert (direct[0] - alone[0]).abs().max() < 1e-4 and parity_psnr(direct[0].cpu(), alone[0].cpu()) > 120.0
+
+
+def test_empty_and_odd_inputs(ops):
+    """Zero-sized batches are accepted and launch nothing; odd (non multiple of the tile) sizes of the single ops."""
+    assert ops.demosaic(torch.zeros(0, 4, 8, 12).cuda()).shape == (0, 3, 16, 24)
+    assert ops.warp(torch.zeros(0, 3, 9, 11).cuda(), torch.zeros(0, 2, 9, 11).cuda()).shape == (0, 3, 9, 11)
+    assert ops.upsample_factor_2(torch.zeros(0, 2, 5, 7).cuda(), 2.0).shape == (0, 2, 10, 14)
+    u8 = ops.ppipe(torch.zeros(0, 3, 6, 10).cuda(), 1.2, 2.0, 3.0, 3200, -1)
+    assert u8.shape == (0, 6, 10, 3)
+    gen = torch.Generator().manual_seed(9)
+    x = torch.rand(2, 3, 7, 13, generator=gen) * 2 - 1                       # odd H and W, C = 3
+    fl = (torch.rand(2, 2, 7, 13, generator=gen) - 0.5) * 6
+    got = ops.warp(x.cuda(), fl.cuda()).cpu()
+    assert (got - O.warp(x, fl)).abs().max() < 2e-5
+    raw = torch.rand(3, 8, 5, 9, generator=gen) * 2 - 1                      # two packed frames, odd raw size
+    assert torch.equal(ops.demosaic(raw.cuda()).cpu(), O.hamilton_adams(raw))

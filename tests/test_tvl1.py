@@ -141,3 +141,23 @@ def test_hip_flow_batch_equals_single_flows():
     out = CPPbridge().TVL1_flow_batch(*raw)
     assert len(out) == 3 and out[1].shape == (48, 64, 2)
     assert np.array_equal(out[1], flows[1].permute(1, 2, 0).cpu().numpy())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("h,w", [(16, 16), (17, 20), (16, 40)])
+def test_hip_flow_smallest_and_skinny_sizes(h, w):
+    """16x16 is the smallest image the reference's scale count admits (one scale, one 256-pixel tile); a skinny
+    image puts every pixel of a tile in a few rows."""
+    from rvdd_release_amd.util._ops import ops_runtime
+    rng = np.random.default_rng(h * 100 + w)
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
+    I0 = (np.sin(0.5 * xx) + np.cos(0.4 * yy) + 0.02 * rng.standard_normal((h, w))).astype(np.float32)
+    I1 = (np.sin(0.5 * (xx + 0.6)) + np.cos(0.4 * (yy - 0.4)) + 0.02 * rng.standard_normal((h, w))).astype(np.float32)
+    u = ops_runtime(0).tvl1flow(torch.from_numpy(I0).cuda(), torch.from_numpy(I1).cuda())
+    _close(u.cpu().numpy(), T.tvl1flow(I0, I1))
+    with pytest.raises(RuntimeError, match="16x16"):
+        ops_runtime(0).tvl1flow(torch.zeros(15, 40, device="cuda"), torch.zeros(15, 40, device="cuda"))
+    # 16 x 300: five scales by the diagonal rule, the 4-pixel-high one is smaller than the 6-tap Gaussian -- the
+    # reference reads out of bounds there (mask.c:262-325); refused instead of reproduced
+    with pytest.raises(RuntimeError, match="skinny"):
+        ops_runtime(0).tvl1flow(torch.zeros(16, 300, device="cuda"), torch.zeros(16, 300, device="cuda"))
