@@ -202,7 +202,7 @@ __device__ __forceinline__ float gelu_erf(float v) {
     return fmaf(hv, e, hv);
 }
 
-__global__ __launch_bounds__(256, 2) void mlp_kernel(const float* __restrict__ ln, const float* __restrict__ x,
+__global__ __launch_bounds__(768) void mlp_kernel(const float* __restrict__ ln, const float* __restrict__ x,
                                                      const float* __restrict__ fc1_w,
                                                      const float* __restrict__ fc1_b,
                                                      const float* __restrict__ fc2_w,
@@ -219,7 +219,8 @@ __global__ __launch_bounds__(256, 2) void mlp_kernel(const float* __restrict__ l
     {
         __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc((void*)fc1_w, 0, M_W_FLOATS * 4, 0x00020000);
         __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc((void*)fc2_w, 0, M_W_FLOATS * 4, 0x00020000);
-        for (int k = wave; k < M_W_FLOATS / 256; k += 4) {
+        const int nw = blockDim.x >> 6;
+        for (int k = wave; k < M_W_FLOATS / 256; k += nw) {
             dma16(r1, W1 + k * 256, (unsigned)(k * 1024 + lane * 16));
             dma16(r2, W2 + k * 256, (unsigned)(k * 1024 + lane * 16));
         }
@@ -230,8 +231,8 @@ __global__ __launch_bounds__(256, 2) void mlp_kernel(const float* __restrict__ l
     const float* w1b = W1 + lr * 16 + g * 4;
     const float* w2b = W2 + lr * 16 + g * 4;
     const long nblk = (npix + 16 * M_NPB - 1) / (16 * M_NPB);
-    const long wave_global = (long)blockIdx.x * 4 + wave;
-    const long nwaves = (long)gridDim.x * 4;
+    const long wave_global = (long)blockIdx.x * (blockDim.x >> 6) + wave;
+    const long nwaves = (long)gridDim.x * (blockDim.x >> 6);
     for (long blk = wave_global; blk < nblk; blk += nwaves) {
         long pix[M_NPB];
         f32x4 xb[M_NPB][3];
@@ -378,10 +379,12 @@ hipError_t launch_next_mlp(const float* ln, const float* x, float* out, const Ne
     }
     if (npix <= 0) return hipSuccess;
     const long nblk = (npix + 16 * M_NPB - 1) / (16 * M_NPB);
-    long blocks = (nblk + 3) / 4;
-    const long cap = (long)num_cus() * 2;
+    // one workgroup of 12 waves per CU: three waves per SIMD share one LDS copy of the two weight matrices
+    constexpr int kMlpWaves = 12;
+    long blocks = (nblk + kMlpWaves - 1) / kMlpWaves;
+    const long cap = (long)num_cus();
     if (blocks > cap) blocks = cap;
-    hipLaunchKernelGGL(mlp_kernel, dim3((unsigned)blocks), dim3(256), M_LDS_BYTES, s, ln, x, w.fc1_w, w.fc1_b, w.fc2_w,
+    hipLaunchKernelGGL(mlp_kernel, dim3((unsigned)blocks), dim3(64 * kMlpWaves), M_LDS_BYTES, s, ln, x, w.fc1_w, w.fc1_b, w.fc2_w,
                        w.fc2_b, w.ls, out, (long)npix);
     return hipGetLastError();
 }
