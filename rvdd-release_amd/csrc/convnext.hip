@@ -201,6 +201,26 @@ __device__ __forceinline__ float gelu_erf(float v) {
     const float hv = 0.5f * v;
     return fmaf(hv, e, hv);
 }
+// the same function on two values at once: the polynomial and the two products on v_pk_fma_f32 / v_pk_mul_f32
+// (bit-identical results; a packed op occupies the fp32 lanes as long as two scalar ones, but takes one issue slot
+// between MFMAs instead of two)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 gelu_erf2(f32x2 v) {
+    const f32x2 t = {fminf(fabsf(v[0]), 6.36f), fminf(fabsf(v[1]), 6.36f)};
+    auto K = [](float c) { return f32x2{c, c}; };
+    f32x2 p = K(-2.116853238476324e-06f);
+    p = __builtin_elementwise_fma(p, t, K(3.1051968107931316e-05f));
+    p = __builtin_elementwise_fma(p, t, K(-0.0001479804632253945f));
+    p = __builtin_elementwise_fma(p, t, K(-0.00022579463256988674f));
+    p = __builtin_elementwise_fma(p, t, K(0.007174866273999214f));
+    p = __builtin_elementwise_fma(p, t, K(-0.05256997048854828f));
+    p = __builtin_elementwise_fma(p, t, K(-0.45918503403663635f));
+    p = __builtin_elementwise_fma(p, t, K(-1.1511077880859375f));
+    const f32x2 tp = t * p;
+    const f32x2 e = {copysignf(1.0f - __builtin_amdgcn_exp2f(tp[0]), v[0]), copysignf(1.0f - __builtin_amdgcn_exp2f(tp[1]), v[1])};
+    const f32x2 hv = v * K(0.5f);
+    return __builtin_elementwise_fma(hv, e, hv);
+}
 
 __global__ __launch_bounds__(768) void mlp_kernel(const float* __restrict__ ln, const float* __restrict__ x,
                                                      const float* __restrict__ fc1_w,
@@ -271,9 +291,13 @@ __global__ __launch_bounds__(768) void mlp_kernel(const float* __restrict__ ln, 
 #pragma unroll
             for (int n = 0; n < M_NPB; ++n)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    hid[m][n][r] = gelu_erf(hid[m][n][r]);
-                    hid[m + 1][n][r] = gelu_erf(hid[m + 1][n][r]);
+                for (int r = 0; r < 4; r += 2) {
+                    const f32x2 a = gelu_erf2(f32x2{hid[m][n][r], hid[m][n][r + 1]});
+                    const f32x2 c = gelu_erf2(f32x2{hid[m + 1][n][r], hid[m + 1][n][r + 1]});
+                    hid[m][n][r] = a[0];
+                    hid[m][n][r + 1] = a[1];
+                    hid[m + 1][n][r] = c[0];
+                    hid[m + 1][n][r + 1] = c[1];
                 }
             __builtin_amdgcn_sched_barrier(0);   // keep hipcc from hoisting every fragment read (it spills)
         }
