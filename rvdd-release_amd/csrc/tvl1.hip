@@ -65,8 +65,15 @@ struct Bicubic {       // the 4x4 stencil of bicubic_interpolation_at (:133-231)
 };
 
 // zoom_out / zoom_in resampling (zoom.c:63-74, 98-107): out(i1,j1) = in at (j1/fx, i1/fy), times mul
-__global__ void resample_kernel(const float* __restrict__ in, float* __restrict__ out, int nx, int ny, int nxx,
-                                int nyy, float fx, float fy, float mul) {
+// The images of a pair (I0/I1, or the two flow components) go through every pre- and post-processing kernel together:
+// blockIdx.z picks the image.
+struct Two {
+    const float* in[2];
+    float* out[2];
+};
+__global__ void resample_kernel(Two io, int nx, int ny, int nxx, int nyy, float fx, float fy, float mul) {
+    const float* __restrict__ in = io.in[blockIdx.z];
+    float* __restrict__ out = io.out[blockIdx.z];
     const int j1 = blockIdx.x * blockDim.x + threadIdx.x, i1 = blockIdx.y;
     if (j1 >= nxx) return;
     Bicubic b;
@@ -81,8 +88,9 @@ struct GaussK {
 };
 // one line direction of the in-place Gaussian (mask.c:262-325): reflecting boundary that repeats
 // the edge sample on the high side only; double accumulation in the reference's order
-__global__ void gauss_kernel(const float* __restrict__ in, float* __restrict__ out, int nx, int ny, GaussK k,
-                             int vertical) {
+__global__ void gauss_kernel(Two io, int nx, int ny, GaussK k, int vertical) {
+    const float* __restrict__ in = io.in[blockIdx.z];
+    float* __restrict__ out = io.out[blockIdx.z];
     const int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
     if (j >= nx) return;
     const int n = vertical ? ny : nx, pos = vertical ? i : j;
@@ -712,21 +720,21 @@ static hipError_t tvl1_run_lanes(Tvl1Workspace* w, const float* I0, const float*
         CK(hipMemsetAsync(L.ctl, 0, 8 * sizeof(int), st));
         hipLaunchKernelGGL(minmax_kernel, dim3(256), dim3(256), 0, st, a0, a1, n0, L.mm);
         hipLaunchKernelGGL(normalize_kernel, dim3((n0 + 255) / 256), dim3(256), 0, st, a0, a1, L.tmp, L.tmp2, n0, L.mm);
-        auto gauss = [&](const float* in, float* outp, int gx, int gy, double sigma, float* scratch) {
+        // both images of the pair per launch; scratch of the separable Gaussian: I1w and I1x (free until the scale kernels)
+        auto grid3 = [](int gx, int gy) { return dim3((gx + 255) / 256, gy, 2); };
+        auto gauss2 = [&](const float* in0, const float* in1, float* out0, float* out1, int gx, int gy, double sigma) {
             const GaussK k = make_gauss(sigma);
-            hipLaunchKernelGGL(gauss_kernel, grid2(gx, gy), dim3(256), 0, st, in, scratch, gx, gy, k, 0);
-            hipLaunchKernelGGL(gauss_kernel, grid2(gx, gy), dim3(256), 0, st, scratch, outp, gx, gy, k, 1);
+            hipLaunchKernelGGL(gauss_kernel, grid3(gx, gy), dim3(256), 0, st, Two{{in0, in1}, {L.it.I1w, L.it.I1x}}, gx, gy, k, 0);
+            hipLaunchKernelGGL(gauss_kernel, grid3(gx, gy), dim3(256), 0, st, Two{{L.it.I1w, L.it.I1x}, {out0, out1}}, gx, gy, k, 1);
         };
-        gauss(L.tmp, L.sc[0].I0, nx, ny, kPresmooth, L.it.I1w);
-        gauss(L.tmp2, L.sc[0].I1, nx, ny, kPresmooth, L.it.I1w);
+        gauss2(L.tmp, L.tmp2, L.sc[0].I0, L.sc[0].I1, nx, ny, kPresmooth);
         // pyramid (zoom_out, zoom.c:41-78)
         for (int s = 1; s < w->nscales; ++s) {
             const Scale& a = L.sc[s - 1];
             const Scale& b = L.sc[s];
-            gauss(a.I0, L.tmp, a.nx, a.ny, zsigma, L.it.I1w);
-            hipLaunchKernelGGL(resample_kernel, grid2(b.nx, b.ny), dim3(256), 0, st, L.tmp, b.I0, a.nx, a.ny, b.nx, b.ny, kZoom, kZoom, 1.f);
-            gauss(a.I1, L.tmp, a.nx, a.ny, zsigma, L.it.I1w);
-            hipLaunchKernelGGL(resample_kernel, grid2(b.nx, b.ny), dim3(256), 0, st, L.tmp, b.I1, a.nx, a.ny, b.nx, b.ny, kZoom, kZoom, 1.f);
+            gauss2(a.I0, a.I1, L.tmp, L.tmp2, a.nx, a.ny, zsigma);
+            hipLaunchKernelGGL(resample_kernel, grid3(b.nx, b.ny), dim3(256), 0, st, Two{{L.tmp, L.tmp2}, {b.I0, b.I1}}, a.nx, a.ny,
+                               b.nx, b.ny, kZoom, kZoom, 1.f);
         }
         const Scale& top = L.sc[w->nscales - 1];
         CK(hipMemsetAsync(top.u1, 0, (size_t)top.nx * top.ny * sizeof(float), st));
@@ -781,8 +789,8 @@ static hipError_t tvl1_run_lanes(Tvl1Workspace* w, const float* I0, const float*
             const Scale& sc = w->lanes[q].sc[s];
             const Scale& f = w->lanes[q].sc[s - 1];
             const float fx = (float)f.nx / sc.nx, fy = (float)f.ny / sc.ny;
-            hipLaunchKernelGGL(resample_kernel, grid2(f.nx, f.ny), dim3(256), 0, st, sc.u1, f.u1, sc.nx, sc.ny, f.nx, f.ny, fx, fy, 1.0f / kZoom);
-            hipLaunchKernelGGL(resample_kernel, grid2(f.nx, f.ny), dim3(256), 0, st, sc.u2, f.u2, sc.nx, sc.ny, f.nx, f.ny, fx, fy, 1.0f / kZoom);
+            hipLaunchKernelGGL(resample_kernel, dim3((f.nx + 255) / 256, f.ny, 2), dim3(256), 0, st, Two{{sc.u1, sc.u2}, {f.u1, f.u2}},
+                               sc.nx, sc.ny, f.nx, f.ny, fx, fy, 1.0f / kZoom);
         }
     }
     {   // always read the control words back: a grid barrier that gave up must not pass as a flow
