@@ -167,6 +167,12 @@ int rvdd_ppipe(rvdd_t* h, const float* img, int32_t n, int32_t height, int32_t w
 int rvdd_srgb_metrics(rvdd_t* h, const uint8_t* a, const uint8_t* b, int32_t n, int32_t height, int32_t width,
                       double* psnr, double* ssim, void* stream);
 
+/* Options of recurrentModel that change what a step does (models/recurrent_model.py:27-36).  Known names:
+ *   "no_warp"  (--no_warp, :137-159): the previous output, the previous features and the next frame enter the net
+ *              unwarped; rvdd_step then ignores flow_prev / flow_next (they may be NULL).
+ * Unknown names are an error. */
+int rvdd_set_option(rvdd_t* h, const char* name, int32_t value);
+
 /* ---- measurement ----------------------------------------------------------- */
 
 /* When enabled, every launch of the U-Net kernels is bracketed by HIP events

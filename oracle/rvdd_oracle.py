@@ -424,7 +424,8 @@ class RecurrentOracle:
     frames in [-1,1] at raw resolution and raw-resolution flows.
     """
 
-    def __init__(self, sd: Dict[str, Tensor], future: int = 0, threads: Optional[int] = None):
+    def __init__(self, sd: Dict[str, Tensor], future: int = 0, threads: Optional[int] = None, no_warp: bool = False):
+        self.no_warp = bool(no_warp)                                        # --no_warp: warp_frame returns its input (:137-159)
         self.sd = {k: v.float() for k, v in sd.items()}
         self.feat = net_has_feat(self.sd)
         self.future = int(future)
@@ -441,21 +442,24 @@ class RecurrentOracle:
              flow_prev: Tensor, flow_next: Optional[Tensor], first: bool) -> Tensor:
         """raw_* [B,4,h,w]; flow_* [B,2,h,w] (cur->prev, cur->next). -> [B,3,2h,2w]."""
         n_cur = hamilton_adams(raw_cur)                                    # :125-126
-        fl_prev = upsample_factor_2(flow_prev, multiply_by=2)              # :128-129
+        fl_prev = None if self.no_warp else upsample_factor_2(flow_prev, multiply_by=2)   # :128-129
         B, _, H, W = n_cur.shape
         if first or self.lastden is None:                                   # :233-245
             self.lastden = hamilton_adams(raw_prev)
             if self.feat:
                 self.lastfeat = torch.zeros(B, 48, H, W)
-        warped = warp(self.lastden, fl_prev)                               # :281-287
+        warped = self.lastden if self.no_warp else warp(self.lastden, fl_prev)            # :281-287
         feat_in = None
         if self.feat:
-            feat_in = warp(self.lastfeat, fl_prev)                         # :290-297
+            feat_in = self.lastfeat if self.no_warp else warp(self.lastfeat, fl_prev)     # :290-297
         parts = [warped, n_cur]                                            # :299-311
         if self.future:
             n_next = hamilton_adams(raw_next)
-            fl_next = upsample_factor_2(flow_next, multiply_by=2)
-            parts.append(warp(n_next, fl_next))                            # :314-324
+            if self.no_warp:
+                parts.append(n_next)
+            else:
+                fl_next = upsample_factor_2(flow_next, multiply_by=2)
+                parts.append(warp(n_next, fl_next))                        # :314-324
         netinput = torch.cat(parts, 1)
         den, f = net_forward(self.sd, netinput, feat_in)                   # :327
         self.lastden = den.clone()                                         # :335-337

@@ -190,11 +190,19 @@ __global__ void warp3_kernel(const float* __restrict__ src4, const float* __rest
     const int y = (idx / W) % H;
     const int b = idx / ((size_t)W * H);
     const int h = H / 2, w = W / 2;
+    const f32x4* s = reinterpret_cast<const f32x4*>(src4) + (size_t)b * H * W;
+    if (!flow_raw) {        // --no_warp: warp_frame returns its input (models/recurrent_model.py:156-158)
+        const f32x4 v = s[(size_t)y * W + x];
+        float* o = dst + idx * dpstride;
+        o[0] = v[0];
+        o[1] = v[1];
+        o[2] = v[2];
+        return;
+    }
     float fx, fy;
     flow_at(flow_raw + (size_t)b * 2 * h * w, h, w, H, W, y, x, fx, fy);
     Taps t;
     make_taps(fx, fy, x, y, H, W, t);
-    const f32x4* s = reinterpret_cast<const f32x4*>(src4) + (size_t)b * H * W;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < 4; ++j) {

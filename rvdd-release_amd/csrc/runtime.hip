@@ -57,6 +57,7 @@ struct rvdd_handle {
     bool finalized = false;
     bool need_init = true;
     bool force_wino = false;      // measurement hook: Winograd at every size
+    bool no_warp = false;         // --no_warp (rvdd_set_option): previous output / features / next frame enter the net unwarped
     bool use_wino = true;         // 48->48 3x3 convs: Winograd F(2x2,3x3) (RVDD_CONV=direct selects the direct kernel)
     std::map<std::string, HostTensor> staged;
     std::vector<void*> allocs;
@@ -674,6 +675,15 @@ int rvdd_finalize_weights(rvdd_t* h) {
     return RVDD_OK;
 }
 
+int rvdd_set_option(rvdd_t* h, const char* name, int32_t value) {
+    if (!h || !name) return RVDD_ERR_ARG;
+    if (std::strcmp(name, "no_warp") == 0) {
+        h->no_warp = value != 0;
+        return RVDD_OK;
+    }
+    return fail(h, RVDD_ERR_ARG, "rvdd_set_option: unknown option '%s' (known: no_warp)", name);
+}
+
 int rvdd_reset(rvdd_t* h) {
     if (!h) return RVDD_ERR_ARG;
     h->need_init = true;
@@ -684,9 +694,11 @@ int rvdd_step(rvdd_t* h, const float* raw_prev, const float* raw_cur, const floa
               const float* flow_prev, const float* flow_next, float* out_rgb, void* stream) {
     if (!h) return RVDD_ERR_ARG;
     if (!h->finalized) return fail(h, RVDD_ERR_STATE, "rvdd_step: weights not finalized");
-    if (!raw_cur || !flow_prev || !out_rgb) return fail(h, RVDD_ERR_ARG, "rvdd_step: raw_cur, flow_prev and out_rgb are required");
+    const bool nw = h->no_warp;
+    if (!raw_cur || (!flow_prev && !nw) || !out_rgb) return fail(h, RVDD_ERR_ARG, "rvdd_step: raw_cur, flow_prev and out_rgb are required");
     if (h->need_init && !raw_prev) return fail(h, RVDD_ERR_ARG, "rvdd_step: raw_prev is required on the first step of a video");
-    if (h->cfg.future && (!raw_next || !flow_next)) return fail(h, RVDD_ERR_ARG, "rvdd_step: raw_next and flow_next are required when future=1");
+    if (h->cfg.future && (!raw_next || (!flow_next && !nw))) return fail(h, RVDD_ERR_ARG, "rvdd_step: raw_next and flow_next are required when future=1");
+    if (nw) flow_prev = flow_next = nullptr;      // the flows are not looked at (the reference's dataset does not even load them)
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int B = h->cfg.batch, H = h->cfg.height, W = h->cfg.width;
     const size_t npix = (size_t)B * H * W;
@@ -709,11 +721,13 @@ int rvdd_step(rvdd_t* h, const float* raw_prev, const float* raw_cur, const floa
         HIPCHK(h, launch_demosaic(raw_next, h->green, h->next4, B, H / 2, W / 2, (int64_t)H * W * 4, 4, 1, s));
         HIPCHK(h, launch_warp3(h->next4, flow_next, h->netin + 6, kNetInC, B, H, W, s));
     }
-    if (h->has_feat()) {
+    if (h->has_feat() && !nw) {
         Scope sc(h, s, "warp48_kernel", 0.0, npix * (384.0 + 2.0));
         HIPCHK(h, launch_warp48(h->lastfeat, flow_prev, h->featw, B, H, W, s));
     }
-    return run_net(h, h->netin, h->featw, h->lastfeat, out_rgb, h->lastden4, s);
+    // without warping the previous features are read in place: the net consumes them in its first layer and only
+    // its last one writes the new ones
+    return run_net(h, h->netin, nw ? h->lastfeat : h->featw, h->lastfeat, out_rgb, h->lastden4, s);
 }
 
 int rvdd_get_state(rvdd_t* h, float* lastden, float* lastfeat, void* stream) {

@@ -26,7 +26,7 @@ class recurrentModel(BaseModel):
 
     def __init__(self, opt):
         BaseModel.__init__(self, opt)
-        for flag in ('no_warp', 'no_predemosaic', 'warp_raw', 'prev_noisy_frame', 'raw_gt'):
+        for flag in ('no_predemosaic', 'warp_raw', 'prev_noisy_frame', 'raw_gt'):
             if getattr(opt, flag, False):
                 raise NotImplementedError(f"rvdd: --{flag} is outside the built hot path "
                                           "(no BASELINE configuration uses it)")
@@ -59,7 +59,8 @@ class recurrentModel(BaseModel):
         self.gt = self.to_device(input['gt'])
         self.image_paths = input['n_path']
         self.first_frame = False if self.isTrain else input['FirstOfVideo']
-        self.flow = self.to_device(input['flow'])
+        # --no_warp: the dataset yields no flows and the reference never reads them (recurrent_model.py:117-122)
+        self.flow = None if self.opt.no_warp else self.to_device(input['flow'])
 
     def forward(self):
         if self.isTrain:
@@ -67,18 +68,20 @@ class recurrentModel(BaseModel):
                                       "(validate.py:137-138) before test()")
         B, C, h, w = self.n.shape
         fD = self.opt.future_patch_depth
-        if C != 4 * (2 + fD) or self.flow.shape[1] != 1 + fD:
-            raise RuntimeError(f"input 'n' has {C} channels / 'flow' {tuple(self.flow.shape)}; expected "
-                               f"{4 * (2 + fD)} raw channels and {1 + fD} flows")
+        no_warp = bool(self.opt.no_warp)
+        if C != 4 * (2 + fD) or (not no_warp and self.flow.shape[1] != 1 + fD):
+            raise RuntimeError(f"input 'n' has {C} channels / 'flow' {None if no_warp else tuple(self.flow.shape)}; "
+                               f"expected {4 * (2 + fD)} raw channels and {1 + fD} flows")
         rt = self._netDenoise.runtime_for(B, 2 * h, 2 * w)
         if rt is not self._rt:
             self._rt = rt
+            rt.set_option("no_warp", int(no_warp))
             rt.reset()
         if self.training_unrollings == 1 or self.first_frame:
             rt.reset()
         n, fl = self.n, self.flow
         self.denoised = rt.step(n[:, 0:4], n[:, 4:8], n[:, 8:12] if fD else None,
-                                fl[:, 0], fl[:, 1] if fD else None)
+                                None if no_warp else fl[:, 0], fl[:, 1] if (fD and not no_warp) else None)
 
     def compute_losses(self):
         """Test branch of recurrent_model.py:512-525."""

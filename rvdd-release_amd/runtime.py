@@ -85,11 +85,21 @@ class RvddRuntime:
     def reset(self):
         self._check(self.lib.rvdd_reset(self.h), "rvdd_reset")
 
+    def set_option(self, name: str, value: int):
+        """Options of recurrentModel that change what a step does; "no_warp" = --no_warp (flows then unused)."""
+        self._check(self.lib.rvdd_set_option(self.h, name.encode(), int(value)), "rvdd_set_option")
+        if name == "no_warp":
+            self.no_warp = bool(value)
+
     def step(self, raw_prev, raw_cur, raw_next, flow_prev, flow_next, out=None) -> torch.Tensor:
         B, H, W = self.B, self.H, self.W
         rs, fs = (B, 4, H // 2, W // 2), (B, 2, H // 2, W // 2)
         raw_cur = _chk_dev(raw_cur, rs, "raw_cur")
-        flow_prev = _chk_dev(flow_prev, fs, "flow_prev")
+        if getattr(self, "no_warp", False):
+            flow_prev = flow_next = None
+        elif flow_prev is None:
+            raise RuntimeError("rvdd_step: flow_prev is required (no --no_warp option set on this runtime)")
+        flow_prev = None if flow_prev is None else _chk_dev(flow_prev, fs, "flow_prev")
         raw_prev = None if raw_prev is None else _chk_dev(raw_prev, rs, "raw_prev")
         raw_next = None if raw_next is None else _chk_dev(raw_next, rs, "raw_next")
         flow_next = None if flow_next is None else _chk_dev(flow_next, fs, "flow_next")

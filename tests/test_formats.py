@@ -377,3 +377,28 @@ def test_fwd_ppipe_script(tmp_path):
     png = iio_read(str(res / "000" / "00000003_processed_pipeline.png"))
     assert png.dtype == np.uint8 and png.shape == (24, 40, 3)
     assert (res / "PSNR.txt").read_text().rstrip().endswith("dB  ###")
+
+
+@pytest.mark.gpu
+def test_validate_main_no_warp(tmp_path):
+    """scripts/test-non_recurrent-no_warp-convunet.sh: `--no_warp`: no flow folder is needed, none is created."""
+    from rvdd_release_amd import synth, validate
+    from rvdd_release_amd.data import create_dataset
+    name = "non_recurrent-convunet-no_warp-iso3200"
+    seqs = [synth.make_sequence(4, 64, 96, iso=3200, seed=95)]
+    root = tmp_path / "validation"
+    write_dataset(str(root), seqs, with_flows=False)
+    ck = tmp_path / "checkpoints"
+    validate.main(["--netDenoiser", "convunet-mode=fixedfeatures", "--path2epoch", os.path.join(WEIGHTS, name), "--val_dataroot",
+                   str(root), "--gtFolder", "gt_iso3200", "--nFolder", "noisy_iso3200", "--gt_linear_RGB_Folder",
+                   "gt_raw_linear_RGB_iso3200", "--no_warp", "--suffix", "t", "--checkpoints_dir", str(ck), "--val_videos", "000"])
+    assert os.listdir(root / "flow" / "noisy_iso3200" / "tvl1" / "noisyinputs" / "000") == []     # write_dataset made the folder only
+    items = list(create_dataset(_opt(root, videos="000", no_warp=True)))
+    assert items[0]["flow"] == [] and len(items) == 3
+    rec = O.RecurrentOracle(load_weights(name), future=0, no_warp=True)
+    out_dir = ck / "recurrent-convunet-mode=fixedfeatures-i3o3-t" / "val_visuals" / "000"
+    for k, it in enumerate(items):
+        w = rec.step(it["n"][:, 0:4], it["n"][:, 4:8], None, None, None, first=(k == 0))
+        got = tiffio.read(str(out_dir / (os.path.splitext(os.path.basename(it["n_path"][0]))[0] + "_denoised.tif")))
+        ref = ((w[0].permute(1, 2, 0).numpy() + 1) / 2.0 * 255.0).astype(np.float32)
+        assert np.abs(got - ref).max() < 1e-4 * 127.5

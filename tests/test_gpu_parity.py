@@ -294,3 +294,39 @@ def test_empty_and_odd_inputs(ops):
     assert (got - O.warp(x, fl)).abs().max() < 2e-5
     raw = torch.rand(3, 8, 5, 9, generator=gen) * 2 - 1                      # two packed frames, odd raw size
     assert torch.equal(ops.demosaic(raw.cuda()).cpu(), O.hamilton_adams(raw))
+
+
+@pytest.mark.parametrize("name,stem,fut", [("nowarp-iso3200", "non_recurrent-convunet-no_warp-iso3200", 0),
+                                           ("nowarp-future-iso3200", "non_recurrent-convunet-no_warp-future-iso3200", 1)])
+def test_no_warp_model_surface(name, stem, fut):
+    """scripts/test-non_recurrent-no_warp-*.sh: `--no_warp`, the dataset hands over no flows."""
+    from rvdd_release_amd.models import create_model
+    from rvdd_release_amd.options import make_opt
+    g = _npz(f"seq_{name}.npz")
+    opt = make_opt(netDenoiser="convunet-mode=fixedfeatures", future_patch_depth=fut, no_warp=True,
+                   path2epoch=os.path.join(WEIGHTS, stem), gpu_ids=[0])
+    assert opt.name == "recurrent-convunet-mode=fixedfeatures-i3o3"          # no "-warp" in the run name (base_options.py:131)
+    model = create_model(opt)
+    model.setup(opt)
+    opt.isTrain = model.isTrain = False
+    model.eval()
+    T = g["raw"].shape[0]
+    for k, t in enumerate(range(1, T - fut)):
+        frames = [g["raw"][t - 1], g["raw"][t]] + ([g["raw"][t + 1]] if fut else [])
+        data = {"n": torch.cat(frames, 0)[None], "flow": [], "gt": torch.cat((g["gt"][t - 1], g["gt"][t]), 0)[None],
+                "n_path": [f"seq/{t:03d}.tif"], "gt_path": [f"seq/{t:03d}.tif"], "FirstOfVideo": t == 1}
+        model.set_input(data)
+        model.test()
+        model.compute_losses()
+        den = model.get_current_visuals()["denoised"][0].cpu()
+        assert (den - g["denoised"][k]).abs().max() < 1e-4
+        assert abs(model.get_current_losses()["PSNR"] - float(g["PSNR"][k])) < 0.01
+    # the option is per runtime: a warping model on another runtime still insists on its flows
+    from rvdd_release_amd.runtime import RvddRuntime
+    rt = RvddRuntime("convunet", 0, 1, 32, 48, 0)
+    rt.load_state_dict(load_weights("recurrent-convunet-iso3200"))
+    z = g["raw"][0][None].cuda()
+    with pytest.raises(RuntimeError, match="flow_prev is required"):
+        rt.step(z, z, None, None, None)
+    with pytest.raises(RuntimeError, match="unknown option"):
+        rt.set_option("bogus", 1)

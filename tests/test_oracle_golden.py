@@ -67,3 +67,16 @@ def test_sequence(name):
         gt = g["gt"][i + 1][None]
         assert abs(O.psnr(outs[i][None], gt) - float(g["PSNR"][i])) < 1e-3
         assert abs(O.l1_loss(outs[i][None], gt) - float(g["L1"][i])) < 1e-4
+
+
+@pytest.mark.parametrize("name,stem,fut", [("nowarp-iso3200", "non_recurrent-convunet-no_warp-iso3200", 0),
+                                           ("nowarp-future-iso3200", "non_recurrent-convunet-no_warp-future-iso3200", 1)])
+def test_no_warp_sequence_matches_reference(name, stem, fut):
+    """--no_warp (scripts/test-non_recurrent-no_warp-*.sh): previous output and next frame enter the net unwarped."""
+    g = {k: torch.from_numpy(v) for k, v in np.load(os.path.join(GOLDEN, f"seq_{name}.npz")).items()}
+    rec = O.RecurrentOracle(load_weights(stem), future=fut, no_warp=True)
+    T = g["raw"].shape[0]
+    for k, t in enumerate(range(1, T - fut)):
+        den = rec.step(g["raw"][t - 1][None], g["raw"][t][None], g["raw"][t + 1][None] if fut else None, None, None, first=(t == 1))
+        assert (den[0] - g["denoised"][k]).abs().max() < 2e-5
+        assert abs(O.psnr(den, g["gt"][t][None]) - float(g["PSNR"][k])) < 1e-3

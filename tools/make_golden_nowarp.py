@@ -1,0 +1,73 @@
+#!/usr/bin/env python3
+"""Golden sequences for the `--no_warp` checkpoints (scripts/test-non_recurrent-no_warp-*.sh of the reference),
+captured from the reference itself like tools/make_golden.py does for the warping variants (build container only):
+
+    python3 tools/make_golden_nowarp.py
+
+Writes weights/non_recurrent-convunet-no_warp[-future]-iso3200.safetensors and tests/golden/seq_nowarp*.npz."""
+import os
+import sys
+import tempfile
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(REPO, "tools"))
+import make_golden as MG  # noqa: E402
+
+CASES = {"nowarp-iso3200": ("convunet-mode=fixedfeatures", 0, "non_recurrent-convunet-no_warp-iso3200"),
+         "nowarp-future-iso3200": ("convunet-mode=fixedfeatures", 1, "non_recurrent-convunet-no_warp-future-iso3200")}
+
+
+def main():
+    os.environ["PYTHONDONTWRITEBYTECODE"] = "1"
+    sys.dont_write_bytecode = True
+    MG._install_standins()
+    sys.path.insert(0, MG.REF)
+    tmp = tempfile.mkdtemp(prefix="rvdd_golden_")
+    os.chdir(tmp)
+    torch.manual_seed(4321)
+    torch.set_num_threads(8)
+    from safetensors.torch import save_file
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("rvdd_synth", os.path.join(REPO, "rvdd-release_amd", "synth.py"))
+    synth = importlib.util.module_from_spec(spec)
+    sys.modules["rvdd_synth"] = synth        # dataclasses look the module up by name
+    spec.loader.exec_module(synth)
+    from options.train_options import TrainOptions
+    from models import create_model
+    for name, (netstr, fut, stem) in CASES.items():
+        sys.argv = ["x", "--gpu_ids", "-1", "--netDenoiser", netstr, "--path2epoch", os.path.join(MG.REF, "trained-nets", stem),
+                    "--checkpoints_dir", tmp, "--no_warp"] + (["--future_patch_depth", "1"] if fut else [])
+        opt = TrainOptions().parse()
+        model = create_model(opt)
+        model.setup(opt)
+        opt.isTrain = model.isTrain = False
+        model.eval()
+        sd = {k: v.detach().clone().contiguous() for k, v in model._netDenoise.state_dict().items()}
+        save_file(sd, os.path.join(MG.WDIR, stem + ".safetensors"),
+                  metadata={"netDenoiser": netstr, "feature_rec": "0", "future_patch_depth": str(fut), "no_warp": "1",
+                            "source": stem + "_net_Denoise.pth"})
+        T, H, W = 6, 32, 48
+        seq = synth.make_sequence(T, H, W, iso=3200, seed=2000 + len(name))
+        outs, l1s, psnrs = [], [], []
+        for t in range(1, T - fut):
+            frames = [seq.raw[t - 1], seq.raw[t]] + ([seq.raw[t + 1]] if fut else [])
+            data = {"n": torch.cat(frames, 0)[None], "flow": [],                       # the dataset yields [] with --no_warp
+                    "gt": torch.cat((seq.gt[t - 1], seq.gt[t]), 0)[None],
+                    "n_path": [f"seq/{t:03d}.tif"], "gt_path": [f"seq/{t:03d}.tif"], "FirstOfVideo": t == 1}
+            model.set_input(data)
+            model.test()
+            model.compute_losses()
+            losses = model.get_current_losses()
+            outs.append(model.denoised[0].numpy().copy())
+            l1s.append(losses["L1"])
+            psnrs.append(losses["PSNR"])
+        np.savez(os.path.join(MG.GOLD, f"seq_{name}.npz"), raw=seq.raw.numpy(), gt=seq.gt.numpy(), denoised=np.stack(outs, 0),
+                 L1=np.array(l1s, np.float64), PSNR=np.array(psnrs, np.float64))
+        print(f"[golden] {name}: {len(outs)} frames, PSNR {psnrs}")
+
+
+if __name__ == "__main__":
+    main()
