@@ -170,6 +170,8 @@ int rvdd_srgb_metrics(rvdd_t* h, const uint8_t* a, const uint8_t* b, int32_t n, 
 /* Options of recurrentModel that change what a step does (models/recurrent_model.py:27-36).  Known names:
  *   "no_warp"  (--no_warp, :137-159): the previous output, the previous features and the next frame enter the net
  *              unwarped; rvdd_step then ignores flow_prev / flow_next (they may be NULL).
+ *   "prev_noisy_frame" (--prev_noisy_frame, :33, :335-337): the frame handed to the next step as "previous" is the
+ *              demosaiced NOISY current frame, not the denoised one (the feature recurrence is unaffected).
  * Unknown names are an error. */
 int rvdd_set_option(rvdd_t* h, const char* name, int32_t value);
 

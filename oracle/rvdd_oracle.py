@@ -424,7 +424,9 @@ class RecurrentOracle:
     frames in [-1,1] at raw resolution and raw-resolution flows.
     """
 
-    def __init__(self, sd: Dict[str, Tensor], future: int = 0, threads: Optional[int] = None, no_warp: bool = False):
+    def __init__(self, sd: Dict[str, Tensor], future: int = 0, threads: Optional[int] = None, no_warp: bool = False,
+                 prev_noisy_frame: bool = False):
+        self.prev_noisy_frame = bool(prev_noisy_frame)                      # --prev_noisy_frame (:335-337)
         self.no_warp = bool(no_warp)                                        # --no_warp: warp_frame returns its input (:137-159)
         self.sd = {k: v.float() for k, v in sd.items()}
         self.feat = net_has_feat(self.sd)
@@ -462,7 +464,7 @@ class RecurrentOracle:
                 parts.append(warp(n_next, fl_next))                        # :314-324
         netinput = torch.cat(parts, 1)
         den, f = net_forward(self.sd, netinput, feat_in)                   # :327
-        self.lastden = den.clone()                                         # :335-337
+        self.lastden = n_cur.clone() if self.prev_noisy_frame else den.clone()   # :335-337
         if self.feat:
             self.lastfeat = f                                              # :339-345
         return den

@@ -57,6 +57,7 @@ struct rvdd_handle {
     bool finalized = false;
     bool need_init = true;
     bool force_wino = false;      // measurement hook: Winograd at every size
+    bool prev_noisy = false;      // --prev_noisy_frame (rvdd_set_option): the next step's "previous frame" is the demosaiced noisy one
     bool no_warp = false;         // --no_warp (rvdd_set_option): previous output / features / next frame enter the net unwarped
     bool use_wino = true;         // 48->48 3x3 convs: Winograd F(2x2,3x3) (RVDD_CONV=direct selects the direct kernel)
     std::map<std::string, HostTensor> staged;
@@ -681,7 +682,11 @@ int rvdd_set_option(rvdd_t* h, const char* name, int32_t value) {
         h->no_warp = value != 0;
         return RVDD_OK;
     }
-    return fail(h, RVDD_ERR_ARG, "rvdd_set_option: unknown option '%s' (known: no_warp)", name);
+    if (std::strcmp(name, "prev_noisy_frame") == 0) {
+        h->prev_noisy = value != 0;
+        return RVDD_OK;
+    }
+    return fail(h, RVDD_ERR_ARG, "rvdd_set_option: unknown option '%s' (known: no_warp, prev_noisy_frame)", name);
 }
 
 int rvdd_reset(rvdd_t* h) {
@@ -727,7 +732,10 @@ int rvdd_step(rvdd_t* h, const float* raw_prev, const float* raw_cur, const floa
     }
     // without warping the previous features are read in place: the net consumes them in its first layer and only
     // its last one writes the new ones
-    return run_net(h, h->netin, nw ? h->lastfeat : h->featw, h->lastfeat, out_rgb, h->lastden4, s);
+    const int rc = run_net(h, h->netin, nw ? h->lastfeat : h->featw, h->lastfeat, out_rgb, h->lastden4, s);
+    if (rc == RVDD_OK && h->prev_noisy)     // store_frame = the noisy current frame (models/recurrent_model.py:335-337)
+        HIPCHK(h, launch_demosaic(raw_cur, h->green, h->lastden4, B, H / 2, W / 2, (int64_t)H * W * 4, 4, 1, s));
+    return rc;
 }
 
 int rvdd_get_state(rvdd_t* h, float* lastden, float* lastfeat, void* stream) {

@@ -330,3 +330,28 @@ def test_no_warp_model_surface(name, stem, fut):
         rt.step(z, z, None, None, None)
     with pytest.raises(RuntimeError, match="unknown option"):
         rt.set_option("bogus", 1)
+
+
+def test_prev_noisy_frame_model_surface():
+    from rvdd_release_amd.models import create_model
+    from rvdd_release_amd.options import make_opt
+    g = _npz("seq_prevnoisy-feat-iso3200.npz")
+    opt = make_opt(netDenoiser="convunet-mode=fixedfeatures+feat", feature_rec=True, prev_noisy_frame=True,
+                   path2epoch=os.path.join(WEIGHTS, "recurrent-convunet+feat-iso3200"), gpu_ids=[0])
+    model = create_model(opt)
+    model.setup(opt)
+    opt.isTrain = model.isTrain = False
+    model.eval()
+    for k, t in enumerate(range(1, g["raw"].shape[0])):
+        data = {"n": torch.cat((g["raw"][t - 1], g["raw"][t]), 0)[None], "flow": g["flow_prev"][t][None, None],
+                "gt": torch.cat((g["gt"][t - 1], g["gt"][t]), 0)[None], "n_path": [f"seq/{t:03d}.tif"],
+                "gt_path": [f"seq/{t:03d}.tif"], "FirstOfVideo": t == 1}
+        model.set_input(data)
+        model.test()
+        model.compute_losses()
+        den = model.get_current_visuals()["denoised"][0].cpu()
+        assert (den - g["denoised"][k]).abs().max() < 1e-4
+        assert abs(model.get_current_losses()["PSNR"] - float(g["PSNR"][k])) < 0.01
+    # the state that is handed on is the noisy frame: Hamilton-Adams of the last raw frame, bit for bit
+    lastden, _ = model._rt.get_state()
+    assert torch.equal(lastden.cpu(), O.hamilton_adams(g["raw"][-1][None]))

@@ -80,3 +80,12 @@ def test_no_warp_sequence_matches_reference(name, stem, fut):
         den = rec.step(g["raw"][t - 1][None], g["raw"][t][None], g["raw"][t + 1][None] if fut else None, None, None, first=(t == 1))
         assert (den[0] - g["denoised"][k]).abs().max() < 2e-5
         assert abs(O.psnr(den, g["gt"][t][None]) - float(g["PSNR"][k])) < 1e-3
+
+
+def test_prev_noisy_frame_sequence_matches_reference():
+    """--prev_noisy_frame: the previous frame of step t+1 is the demosaiced noisy frame t (features stay recurrent)."""
+    g = {k: torch.from_numpy(v) for k, v in np.load(os.path.join(GOLDEN, "seq_prevnoisy-feat-iso3200.npz")).items()}
+    rec = O.RecurrentOracle(load_weights("recurrent-convunet+feat-iso3200"), future=0, prev_noisy_frame=True)
+    for k, t in enumerate(range(1, g["raw"].shape[0])):
+        den = rec.step(g["raw"][t - 1][None], g["raw"][t][None], None, g["flow_prev"][t][None], None, first=(t == 1))
+        assert (den[0] - g["denoised"][k]).abs().max() < 2e-5

@@ -16,8 +16,11 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(REPO, "tools"))
 import make_golden as MG  # noqa: E402
 
-CASES = {"nowarp-iso3200": ("convunet-mode=fixedfeatures", 0, "non_recurrent-convunet-no_warp-iso3200"),
-         "nowarp-future-iso3200": ("convunet-mode=fixedfeatures", 1, "non_recurrent-convunet-no_warp-future-iso3200")}
+# name: (netDenoiser, future, checkpoint stem, extra flags, feature_rec)
+CASES = {"nowarp-iso3200": ("convunet-mode=fixedfeatures", 0, "non_recurrent-convunet-no_warp-iso3200", ["--no_warp"], False),
+         "nowarp-future-iso3200": ("convunet-mode=fixedfeatures", 1, "non_recurrent-convunet-no_warp-future-iso3200", ["--no_warp"], False),
+         # --prev_noisy_frame (recurrent_model.py:33, :335-337): no checkpoint was trained with it; any one runs with it
+         "prevnoisy-feat-iso3200": ("convunet-mode=fixedfeatures+feat", 0, "recurrent-convunet+feat-iso3200", ["--prev_noisy_frame", "--feature_rec"], True)}
 
 
 def main():
@@ -37,24 +40,27 @@ def main():
     spec.loader.exec_module(synth)
     from options.train_options import TrainOptions
     from models import create_model
-    for name, (netstr, fut, stem) in CASES.items():
+    for name, (netstr, fut, stem, extra, feat) in CASES.items():
         sys.argv = ["x", "--gpu_ids", "-1", "--netDenoiser", netstr, "--path2epoch", os.path.join(MG.REF, "trained-nets", stem),
-                    "--checkpoints_dir", tmp, "--no_warp"] + (["--future_patch_depth", "1"] if fut else [])
+                    "--checkpoints_dir", tmp] + extra + (["--future_patch_depth", "1"] if fut else [])
         opt = TrainOptions().parse()
         model = create_model(opt)
         model.setup(opt)
         opt.isTrain = model.isTrain = False
         model.eval()
         sd = {k: v.detach().clone().contiguous() for k, v in model._netDenoise.state_dict().items()}
-        save_file(sd, os.path.join(MG.WDIR, stem + ".safetensors"),
-                  metadata={"netDenoiser": netstr, "feature_rec": "0", "future_patch_depth": str(fut), "no_warp": "1",
-                            "source": stem + "_net_Denoise.pth"})
+        if "--no_warp" in extra:
+            save_file(sd, os.path.join(MG.WDIR, stem + ".safetensors"),
+                      metadata={"netDenoiser": netstr, "feature_rec": "0", "future_patch_depth": str(fut), "no_warp": "1",
+                                "source": stem + "_net_Denoise.pth"})
+        no_warp = "--no_warp" in extra
         T, H, W = 6, 32, 48
         seq = synth.make_sequence(T, H, W, iso=3200, seed=2000 + len(name))
         outs, l1s, psnrs = [], [], []
         for t in range(1, T - fut):
             frames = [seq.raw[t - 1], seq.raw[t]] + ([seq.raw[t + 1]] if fut else [])
-            data = {"n": torch.cat(frames, 0)[None], "flow": [],                       # the dataset yields [] with --no_warp
+            flows = [] if no_warp else torch.stack([seq.flow_prev[t]] + ([seq.flow_next[t]] if fut else []), 0)[None]
+            data = {"n": torch.cat(frames, 0)[None], "flow": flows,                    # the dataset yields [] with --no_warp
                     "gt": torch.cat((seq.gt[t - 1], seq.gt[t]), 0)[None],
                     "n_path": [f"seq/{t:03d}.tif"], "gt_path": [f"seq/{t:03d}.tif"], "FirstOfVideo": t == 1}
             model.set_input(data)
@@ -65,6 +71,7 @@ def main():
             l1s.append(losses["L1"])
             psnrs.append(losses["PSNR"])
         np.savez(os.path.join(MG.GOLD, f"seq_{name}.npz"), raw=seq.raw.numpy(), gt=seq.gt.numpy(), denoised=np.stack(outs, 0),
+                 flow_prev=seq.flow_prev.numpy(), flow_next=seq.flow_next.numpy(),
                  L1=np.array(l1s, np.float64), PSNR=np.array(psnrs, np.float64))
         print(f"[golden] {name}: {len(outs)} frames, PSNR {psnrs}")
 
