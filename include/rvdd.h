@@ -170,6 +170,9 @@ int rvdd_srgb_metrics(rvdd_t* h, const uint8_t* a, const uint8_t* b, int32_t n, 
 /* Options of recurrentModel that change what a step does (models/recurrent_model.py:27-36).  Known names:
  *   "no_warp"  (--no_warp, :137-159): the previous output, the previous features and the next frame enter the net
  *              unwarped; rvdd_step then ignores flow_prev / flow_next (they may be NULL).
+ *   "warp_raw" (--warp_raw, :149-152): the previous output is re-mosaicked, warped at RAW resolution with the
+ *              raw-resolution flow and demosaicked again (the next frame: warped as packed raw, then demosaicked).
+ *              Not defined with feature recurrence (the reference fails on the shapes there): error.
  *   "prev_noisy_frame" (--prev_noisy_frame, :33, :335-337): the frame handed to the next step as "previous" is the
  *              demosaiced NOISY current frame, not the denoised one (the feature recurrence is unaffected).
  * Unknown names are an error. */

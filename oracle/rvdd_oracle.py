@@ -425,7 +425,8 @@ class RecurrentOracle:
     """
 
     def __init__(self, sd: Dict[str, Tensor], future: int = 0, threads: Optional[int] = None, no_warp: bool = False,
-                 prev_noisy_frame: bool = False):
+                 prev_noisy_frame: bool = False, warp_raw: bool = False):
+        self.warp_raw = bool(warp_raw)                                      # --warp_raw (:149-152, :128: the flow is NOT upsampled)
         self.prev_noisy_frame = bool(prev_noisy_frame)                      # --prev_noisy_frame (:335-337)
         self.no_warp = bool(no_warp)                                        # --no_warp: warp_frame returns its input (:137-159)
         self.sd = {k: v.float() for k, v in sd.items()}
@@ -444,13 +445,18 @@ class RecurrentOracle:
              flow_prev: Tensor, flow_next: Optional[Tensor], first: bool) -> Tensor:
         """raw_* [B,4,h,w]; flow_* [B,2,h,w] (cur->prev, cur->next). -> [B,3,2h,2w]."""
         n_cur = hamilton_adams(raw_cur)                                    # :125-126
-        fl_prev = None if self.no_warp else upsample_factor_2(flow_prev, multiply_by=2)   # :128-129
+        fl_prev = None if self.no_warp else (flow_prev if self.warp_raw else upsample_factor_2(flow_prev, multiply_by=2))   # :128-129
         B, _, H, W = n_cur.shape
         if first or self.lastden is None:                                   # :233-245
             self.lastden = hamilton_adams(raw_prev)
             if self.feat:
                 self.lastfeat = torch.zeros(B, 48, H, W)
-        warped = self.lastden if self.no_warp else warp(self.lastden, fl_prev)            # :281-287
+        if self.no_warp:
+            warped = self.lastden
+        elif self.warp_raw:
+            warped = hamilton_adams(warp(remosaick(self.lastden), fl_prev))
+        else:
+            warped = warp(self.lastden, fl_prev)                           # :281-287
         feat_in = None
         if self.feat:
             feat_in = self.lastfeat if self.no_warp else warp(self.lastfeat, fl_prev)     # :290-297
@@ -459,6 +465,8 @@ class RecurrentOracle:
             n_next = hamilton_adams(raw_next)
             if self.no_warp:
                 parts.append(n_next)
+            elif self.warp_raw:
+                parts.append(hamilton_adams(warp(remosaick(n_next), flow_next)))
             else:
                 fl_next = upsample_factor_2(flow_next, multiply_by=2)
                 parts.append(warp(n_next, fl_next))                        # :314-324

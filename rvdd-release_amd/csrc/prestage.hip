@@ -516,6 +516,28 @@ hipError_t launch_demosaic(const float* raw, float* green_scratch, float* out, i
     return hipGetLastError();
 }
 
+// HamiltonAdam.remosaick (util/Hamilton_Adam_demo.py:237-246) from the NHWC4 previous output: packed GBRG planes
+// [B][4][H/2][W/2] = G(even row, even col), B(even, odd), R(odd, even), G(odd, odd).  Pure indexing.
+__global__ void remosaick4_kernel(const float* __restrict__ rgb4, float* __restrict__ raw, int B, int H, int W) {
+    const int h = H / 2, w = W / 2;
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)B * 4 * h * w) return;
+    const int x = idx % w;
+    const int y = (idx / w) % h;
+    const int c = (idx / ((size_t)w * h)) % 4;
+    const int b = idx / ((size_t)4 * w * h);
+    const int yy = 2 * y + (c >> 1), xx = 2 * x + (c & 1);
+    const int ch = c == 0 || c == 3 ? 1 : (c == 1 ? 2 : 0);
+    raw[idx] = rgb4[(((size_t)b * H + yy) * W + xx) * 4 + ch];
+}
+
+hipError_t launch_remosaick4(const float* rgb4, float* raw, int B, int H, int W, hipStream_t s) {
+    const size_t n = (size_t)B * H * W;
+    if (!n) return hipSuccess;
+    hipLaunchKernelGGL(remosaick4_kernel, dim3(nblocks(n, 256)), dim3(256), 0, s, rgb4, raw, B, H, W);
+    return hipGetLastError();
+}
+
 hipError_t launch_warp3(const float* src4, const float* flow_raw, float* dst, int dpstride, int B, int H,
                         int W, hipStream_t s) {
     const size_t n = (size_t)B * H * W;

@@ -57,6 +57,7 @@ struct rvdd_handle {
     bool finalized = false;
     bool need_init = true;
     bool force_wino = false;      // measurement hook: Winograd at every size
+    bool warp_raw = false;        // --warp_raw (rvdd_set_option): warp the re-mosaicked frames at raw resolution, demosaic afterwards
     bool prev_noisy = false;      // --prev_noisy_frame (rvdd_set_option): the next step's "previous frame" is the demosaiced noisy one
     bool no_warp = false;         // --no_warp (rvdd_set_option): previous output / features / next frame enter the net unwarped
     bool use_wino = true;         // 48->48 3x3 convs: Winograd F(2x2,3x3) (RVDD_CONV=direct selects the direct kernel)
@@ -682,11 +683,17 @@ int rvdd_set_option(rvdd_t* h, const char* name, int32_t value) {
         h->no_warp = value != 0;
         return RVDD_OK;
     }
+    if (std::strcmp(name, "warp_raw") == 0) {
+        // the reference warps the full-resolution features with the raw-resolution flow in this mode and fails on the shapes
+        if (value && h->has_feat()) return fail(h, RVDD_ERR_ARG, "rvdd_set_option: warp_raw is not defined with feature recurrence (the reference fails there too)");
+        h->warp_raw = value != 0;
+        return RVDD_OK;
+    }
     if (std::strcmp(name, "prev_noisy_frame") == 0) {
         h->prev_noisy = value != 0;
         return RVDD_OK;
     }
-    return fail(h, RVDD_ERR_ARG, "rvdd_set_option: unknown option '%s' (known: no_warp, prev_noisy_frame)", name);
+    return fail(h, RVDD_ERR_ARG, "rvdd_set_option: unknown option '%s' (known: no_warp, warp_raw, prev_noisy_frame)", name);
 }
 
 int rvdd_reset(rvdd_t* h) {
@@ -718,13 +725,28 @@ int rvdd_step(rvdd_t* h, const float* raw_prev, const float* raw_cur, const floa
         Scope sc(h, s, "demosaic(ha_green+ha_rb)", 0.0, npix * 16.0);
         HIPCHK(h, launch_demosaic(raw_cur, h->green, h->netin + 3, B, H / 2, W / 2, (int64_t)H * W * kNetInC, kNetInC, 1, s));
     }
-    {
-        Scope sc(h, s, "warp3_kernel", 0.0, npix * 32.0);
-        HIPCHK(h, launch_warp3(h->lastden4, flow_prev, h->netin + 0, kNetInC, B, H, W, s));
-    }
-    if (h->cfg.future) {
-        HIPCHK(h, launch_demosaic(raw_next, h->green, h->next4, B, H / 2, W / 2, (int64_t)H * W * 4, 4, 1, s));
-        HIPCHK(h, launch_warp3(h->next4, flow_next, h->netin + 6, kNetInC, B, H, W, s));
+    if (h->warp_raw && !nw) {
+        // warp_frame with --warp_raw (models/recurrent_model.py:149-152): HA(warp(remosaick(frame), raw-resolution flow)).
+        // remosaick(HA(raw)) is raw itself, so the next frame is warped as it came.  next4 is free in this mode: its
+        // first quarter holds the re-mosaicked previous output, the second the warped planes.
+        float* packed = h->next4;
+        float* warped = h->next4 + npix;
+        HIPCHK(h, launch_remosaick4(h->lastden4, packed, B, H, W, s));
+        HIPCHK(h, launch_warp_nchw(packed, flow_prev, warped, B, 4, H / 2, W / 2, s));
+        HIPCHK(h, launch_demosaic(warped, h->green, h->netin + 0, B, H / 2, W / 2, (int64_t)H * W * kNetInC, kNetInC, 1, s));
+        if (h->cfg.future) {
+            HIPCHK(h, launch_warp_nchw(raw_next, flow_next, warped, B, 4, H / 2, W / 2, s));
+            HIPCHK(h, launch_demosaic(warped, h->green, h->netin + 6, B, H / 2, W / 2, (int64_t)H * W * kNetInC, kNetInC, 1, s));
+        }
+    } else {
+        {
+            Scope sc(h, s, "warp3_kernel", 0.0, npix * 32.0);
+            HIPCHK(h, launch_warp3(h->lastden4, flow_prev, h->netin + 0, kNetInC, B, H, W, s));
+        }
+        if (h->cfg.future) {
+            HIPCHK(h, launch_demosaic(raw_next, h->green, h->next4, B, H / 2, W / 2, (int64_t)H * W * 4, 4, 1, s));
+            HIPCHK(h, launch_warp3(h->next4, flow_next, h->netin + 6, kNetInC, B, H, W, s));
+        }
     }
     if (h->has_feat() && !nw) {
         Scope sc(h, s, "warp48_kernel", 0.0, npix * (384.0 + 2.0));

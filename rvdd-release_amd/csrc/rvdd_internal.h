@@ -56,6 +56,7 @@ hipError_t launch_warp3(const float* src4, const float* flow_raw, float* dst, in
 hipError_t launch_warp48(const float* src, const float* flow_raw, float* dst, int B, int H, int W,
                          hipStream_t s);
 // generic NCHW warp with a full-resolution flow (util.flow_utils.warp).
+hipError_t launch_remosaick4(const float* rgb4, float* raw, int B, int H, int W, hipStream_t s);
 hipError_t launch_warp_nchw(const float* x, const float* flow, float* y, int n, int c, int H, int W,
                             hipStream_t s);
 hipError_t launch_upsample_flow(const float* t, float* out, int nc, int h, int w, float mul,

@@ -26,7 +26,7 @@ class recurrentModel(BaseModel):
 
     def __init__(self, opt):
         BaseModel.__init__(self, opt)
-        for flag in ('no_predemosaic', 'warp_raw', 'raw_gt'):
+        for flag in ('no_predemosaic', 'raw_gt'):
             if getattr(opt, flag, False):
                 raise NotImplementedError(f"rvdd: --{flag} is outside the built hot path "
                                           "(no BASELINE configuration uses it)")
@@ -77,6 +77,7 @@ class recurrentModel(BaseModel):
             self._rt = rt
             rt.set_option("no_warp", int(no_warp))
             rt.set_option("prev_noisy_frame", int(bool(self.opt.prev_noisy_frame)))
+            rt.set_option("warp_raw", int(bool(self.opt.warp_raw)))
             rt.reset()
         if self.training_unrollings == 1 or self.first_frame:
             rt.reset()

@@ -69,7 +69,7 @@ def test_model_registry_and_options():
     with pytest.raises(AttributeError):
         make_opt(no_such_flag=1)
     assert create_model(make_opt(no_warp=True)).opt.no_warp                  # --no_warp is built (tests/test_gpu_parity.py)
-    for flag in ("no_predemosaic", "warp_raw", "raw_gt"):
+    for flag in ("no_predemosaic", "raw_gt"):
         with pytest.raises(NotImplementedError):
             create_model(make_opt(**{flag: True}))
     with pytest.raises(ValueError):

@@ -89,3 +89,16 @@ def test_prev_noisy_frame_sequence_matches_reference():
     for k, t in enumerate(range(1, g["raw"].shape[0])):
         den = rec.step(g["raw"][t - 1][None], g["raw"][t][None], None, g["flow_prev"][t][None], None, first=(t == 1))
         assert (den[0] - g["denoised"][k]).abs().max() < 2e-5
+
+
+@pytest.mark.parametrize("name,stem,fut", [("warpraw-iso3200", "recurrent-convunet-iso3200", 0),
+                                           ("warpraw-future-iso3200", "recurrent-convunet-future-iso3200", 1)])
+def test_warp_raw_sequence_matches_reference(name, stem, fut):
+    """--warp_raw: frames are re-mosaicked, warped at raw resolution with the raw-resolution flow, demosaicked again."""
+    g = {k: torch.from_numpy(v) for k, v in np.load(os.path.join(GOLDEN, f"seq_{name}.npz")).items()}
+    rec = O.RecurrentOracle(load_weights(stem), future=fut, warp_raw=True)
+    T = g["raw"].shape[0]
+    for k, t in enumerate(range(1, T - fut)):
+        den = rec.step(g["raw"][t - 1][None], g["raw"][t][None], g["raw"][t + 1][None] if fut else None,
+                       g["flow_prev"][t][None], g["flow_next"][t][None] if fut else None, first=(t == 1))
+        assert (den[0] - g["denoised"][k]).abs().max() < 2e-5

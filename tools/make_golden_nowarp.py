@@ -20,6 +20,9 @@ import make_golden as MG  # noqa: E402
 CASES = {"nowarp-iso3200": ("convunet-mode=fixedfeatures", 0, "non_recurrent-convunet-no_warp-iso3200", ["--no_warp"], False),
          "nowarp-future-iso3200": ("convunet-mode=fixedfeatures", 1, "non_recurrent-convunet-no_warp-future-iso3200", ["--no_warp"], False),
          # --prev_noisy_frame (recurrent_model.py:33, :335-337): no checkpoint was trained with it; any one runs with it
+         # --warp_raw (:149-152): likewise, no checkpoint of its own
+         "warpraw-iso3200": ("convunet-mode=fixedfeatures", 0, "recurrent-convunet-iso3200", ["--warp_raw"], False),
+         "warpraw-future-iso3200": ("convunet-mode=fixedfeatures", 1, "recurrent-convunet-future-iso3200", ["--warp_raw"], False),
          "prevnoisy-feat-iso3200": ("convunet-mode=fixedfeatures+feat", 0, "recurrent-convunet+feat-iso3200", ["--prev_noisy_frame", "--feature_rec"], True)}
 
 
