@@ -178,6 +178,10 @@ int rvdd_srgb_metrics(rvdd_t* h, const uint8_t* a, const uint8_t* b, int32_t n, 
  * Unknown names are an error. */
 int rvdd_set_option(rvdd_t* h, const char* name, int32_t value);
 
+/* Host-only helper of the TIFF reader that replaces `iio.read` (library.py:75-77): LZW strip / tile decoder
+ * (TIFF 6.0 section 13).  in[n] -> out (capacity cap); returns the bytes produced or -1 (corrupt stream, output full). */
+int64_t rvdd_tiff_lzw_decode(const uint8_t* in, int64_t n, uint8_t* out, int64_t cap);
+
 /* ---- measurement ----------------------------------------------------------- */
 
 /* When enabled, every launch of the U-Net kernels is bracketed by HIP events

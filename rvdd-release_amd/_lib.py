@@ -40,6 +40,7 @@ _PROTOS = {
     "rvdd_upsample_factor_2": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float,
                                          _P, _P]),
     "rvdd_tvl1flow": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, C.POINTER(C.c_int32), _P]),
+    "rvdd_tiff_lzw_decode": (C.c_int64, [_P, C.c_int64, _P, C.c_int64]),
     "rvdd_set_option": (C.c_int, [_P, C.c_char_p, C.c_int32]),
     "rvdd_tvl1flow_batch": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32), _P]),
     "rvdd_ppipe": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.c_int64, C.c_int64,

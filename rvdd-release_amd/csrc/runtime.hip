@@ -677,6 +677,61 @@ int rvdd_finalize_weights(rvdd_t* h) {
     return RVDD_OK;
 }
 
+// Host-only helper of the TIFF reader (rvdd-release_amd/tiffio.py): TIFF 6.0 section 13 LZW (MSB-first codes of
+// 9..12 bits, ClearCode 256, EndOfInformation 257, "early change").  The pure-Python decoder does ~1 MB/s, a
+// 1280x720 four-channel float frame is 15 MB.  Returns the number of bytes produced, or -1 on a corrupt stream / a
+// full output buffer.
+int64_t rvdd_tiff_lzw_decode(const uint8_t* in, int64_t n, uint8_t* out, int64_t cap) {
+    if (!in || !out || n < 0 || cap < 0) return -1;
+    struct Entry { int32_t prev; uint16_t len; uint8_t first, last; };
+    static thread_local Entry tab[4096];
+    for (int i = 0; i < 256; ++i) tab[i] = Entry{-1, 1, (uint8_t)i, (uint8_t)i};
+    int next = 258, nbits = 9, prev = -1;
+    uint32_t buf = 0;
+    int have = 0;
+    int64_t pos = 0, o = 0;
+    for (;;) {
+        while (have < nbits) {
+            if (pos >= n) return o;                    // streams without an EOI code end with the data
+            buf = (buf << 8) | in[pos++];
+            have += 8;
+        }
+        const int code = (int)((buf >> (have - nbits)) & ((1u << nbits) - 1u));
+        have -= nbits;
+        if (code == 257) return o;
+        if (code == 256) {
+            next = 258;
+            nbits = 9;
+            prev = -1;
+            continue;
+        }
+        int cur;
+        if (prev < 0) {
+            if (code >= 256) return -1;
+            cur = code;
+        } else if (code < next) {
+            cur = code;
+            if (next < 4096) {
+                tab[next] = Entry{prev, (uint16_t)(tab[prev].len + 1), tab[prev].first, tab[code].first};
+                ++next;
+            }
+        } else if (code == next && next < 4096) {
+            tab[next] = Entry{prev, (uint16_t)(tab[prev].len + 1), tab[prev].first, tab[prev].first};
+            cur = next++;
+        } else {
+            return -1;
+        }
+        const int len = tab[cur].len;
+        if (o + len > cap) return -1;
+        for (int e = cur, k = len - 1; k >= 0; --k, e = tab[e].prev) out[o + k] = tab[e].last;
+        o += len;
+        prev = cur;
+        if (next >= 2047) nbits = 12;
+        else if (next >= 1023) nbits = 11;
+        else if (next >= 511) nbits = 10;
+    }
+}
+
 int rvdd_set_option(rvdd_t* h, const char* name, int32_t value) {
     if (!h || !name) return RVDD_ERR_ARG;
     if (std::strcmp(name, "no_warp") == 0) {

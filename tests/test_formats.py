@@ -83,6 +83,49 @@ def test_we_read_pillow_float(tmp_path, compression, predictor):
     assert np.array_equal(tiffio.read(p)[..., 0], f)
 
 
+def test_native_lzw_decoder_equals_python(tmp_path):
+    """LZW strips go through `rvdd_tiff_lzw_decode` (host code in librvdd_hip.so) when the library loads; the
+    pure-Python decoder is the independent restatement.  Same bytes out, including the error behaviour."""
+    import ctypes
+    from PIL import Image
+    from rvdd_release_amd import _lib
+    dec = _lib.load().rvdd_tiff_lzw_decode
+    smooth = (np.add.outer(np.arange(97), np.arange(131)) % 251).astype(np.uint8)
+    for img in (smooth, RNG.integers(0, 255, (97, 131)).astype(np.uint8), np.zeros((300, 400), np.uint8)):
+        p = str(tmp_path / "l.tif")
+        Image.fromarray(img).save(p, compression="tiff_lzw")
+        raw = open(p, "rb").read()
+        # single-strip or multi-strip: decode every strip both ways
+        import struct as S
+        (ifd,) = S.unpack("<I", raw[4:8])
+        (n,) = S.unpack("<H", raw[ifd:ifd + 2])
+        tags = {}
+        for i in range(n):
+            tag, typ, cnt, val = S.unpack("<HHII", raw[ifd + 2 + 12 * i: ifd + 14 + 12 * i])
+            tags[tag] = (typ, cnt, val)
+
+        def values(tag):
+            typ, cnt, val = tags[tag]
+            if cnt == 1:
+                return [val]
+            f = {3: "H", 4: "I"}[typ]
+            return list(S.unpack("<" + f * cnt, raw[val:val + cnt * S.calcsize(f)]))
+        total = b""
+        for off, cnt in zip(values(273), values(279)):
+            chunk = raw[off:off + cnt]
+            want = tiffio._lzw_decode(chunk)
+            out = ctypes.create_string_buffer(len(want) + 16)
+            got = dec(chunk, len(chunk), out, len(out))
+            assert got == len(want) and out.raw[:got] == want
+            assert dec(chunk, len(chunk), out, len(want) - 1) == -1 if len(want) > 1 else True       # output too small
+            total += want
+        assert np.array_equal(np.frombuffer(total, np.uint8)[:img.size].reshape(img.shape), img)
+    bad = bytes([0xFF, 0xFF, 0xFF, 0xFF])                                     # code 511 first: not in the table
+    assert dec(bad, len(bad), ctypes.create_string_buffer(64), 64) == -1
+    with pytest.raises(tiffio.TiffError):
+        tiffio._lzw_decode(bad)
+
+
 def _handmade(path, arr, bo="<", big=False, planar=1, tile=None, rows_per_strip=None, deflate=False):
     """A TIFF writer independent of tiffio.write: endianness, BigTIFF, planar/tiled/multi-strip layouts."""
     H, W, C = arr.shape
