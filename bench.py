@@ -212,7 +212,8 @@ def main():
         "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic" + (" (REHEARSAL: all ranks on one GPU, not a measurement)" if rehearsal else ""),
-        "config": {"workload": f"{args.config}: {DESCR[args.config]}", "arch": arch, "checkpoint": stem,
+        "config": {"workload": f"{args.config}: {DESCR[args.config]}" + (f" (run with --frames {T})" if args.frames else ""),
+                   "arch": arch, "checkpoint": stem,
                    "frame": f"{W}x{H}", "frames_per_sequence": T, "sequences_per_gpu": B,
                    "output_frames_per_step_per_gpu": n_out * B, "parallelism": f"sequences sharded over {world} GPU(s)"},
         "fps_per_gpu": round(fps / world, 3), "ms_per_frame": round(1e3 * elapsed / (frames_total / world), 3),
