@@ -265,18 +265,11 @@ int g_variant = 0;   // A/B switch for the measurement hook (rvdd_debug_conv_ben
 
 template <int CIN, int EPI, bool ACC_IN, int VARIANT>
 hipError_t launch_v(const ConvArgs& a, hipStream_t s) {
-    static bool attr_done = false;
+    static std::atomic<uint64_t> attr_done{0};
     auto kern = conv3x3_kernel<CIN, EPI, ACC_IN, VARIANT>;
     constexpr size_t lds = Geo<CIN>::LDS_BYTES;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_done = true;
-    }
-    int dev = 0, cus = 256;
-    (void)hipGetDevice(&dev);
-    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(kern), lds, attr_done); e != hipSuccess) return e;
+    const int cus = current_device_cus();
     const int grid = a.ntiles < cus ? a.ntiles : cus;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, a);
     return hipGetLastError();

@@ -352,12 +352,7 @@ __global__ void pad_copy_kernel(const float* __restrict__ src, float* __restrict
     reinterpret_cast<f32x4*>(dst)[gid] = v;
 }
 
-int num_cus() {
-    int dev = 0, cus = 256;
-    (void)hipGetDevice(&dev);
-    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    return cus;
-}
+int num_cus() { return current_device_cus(); }
 
 }  // namespace
 
@@ -378,13 +373,9 @@ hipError_t launch_proj1x1(const float* in1, int c1, const float* in2, int c2, co
 }
 
 hipError_t launch_next_dwln(const float* x, float* ln_out, const NextBlockW& w, int B, int H, int W, hipStream_t s) {
-    static bool attr = false;
-    if (!attr) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(dwln_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)D_LDS_BYTES);
-        if (e != hipSuccess) return e;
-        attr = true;
-    }
+    static std::atomic<uint64_t> attr{0};
+    if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(dwln_kernel), D_LDS_BYTES, attr); e != hipSuccess)
+        return e;
     if ((size_t)H * W * kF * 4 >= 0x80000000ull) return hipErrorInvalidValue;
     const int tx = (W + DT_W - 1) / DT_W, ty = (H + DT_H - 1) / DT_H;
     hipLaunchKernelGGL(dwln_kernel, dim3(B * tx * ty), dim3(512), D_LDS_BYTES, s, x, w.dw_w, w.dw_b, w.ln_w, w.ln_b,
@@ -394,13 +385,9 @@ hipError_t launch_next_dwln(const float* x, float* ln_out, const NextBlockW& w, 
 
 hipError_t launch_next_mlp(const float* ln, const float* x, float* out, const NextBlockW& w, int64_t npix,
                            hipStream_t s) {
-    static bool attr = false;
-    if (!attr) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)M_LDS_BYTES);
-        if (e != hipSuccess) return e;
-        attr = true;
-    }
+    static std::atomic<uint64_t> attr{0};
+    if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(mlp_kernel), M_LDS_BYTES, attr); e != hipSuccess)
+        return e;
     if (npix <= 0) return hipSuccess;
     const long nblk = (npix + 16 * M_NPB - 1) / (16 * M_NPB);
     // one workgroup of 12 waves per CU: three waves per SIMD share one LDS copy of the two weight matrices

@@ -42,6 +42,31 @@ struct ProfPending {
     hipEvent_t e0, e1;
 };
 
+struct NextBlk {          // one ConvBlock of the ConvNeXt net (networks/new_unet.py:74-103)
+    NextBlockW w{};
+    int c1 = 0, c2 = 0;   // projection sources (0,0 = identity)
+};
+
+// Every entry point acts on the handle's device, whatever the caller's current device is, and leaves
+// the caller's current device as it found it.
+struct DeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    hipError_t err = hipSuccess;
+    explicit DeviceGuard(int dev) {
+        err = hipGetDevice(&prev);
+        if (err == hipSuccess && prev != dev) {
+            err = hipSetDevice(dev);
+            switched = err == hipSuccess;
+        }
+    }
+    ~DeviceGuard() {
+        if (switched) (void)hipSetDevice(prev);
+    }
+    DeviceGuard(const DeviceGuard&) = delete;
+    DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+
 struct Level {
     int H = 0, W = 0;
     float* t[3] = {nullptr, nullptr, nullptr};
@@ -56,7 +81,7 @@ struct rvdd_handle {
     std::string err;
     bool finalized = false;
     bool need_init = true;
-    bool force_wino = false;      // measurement hook: Winograd at every size
+    bool force_wino = false;      // Winograd at every size (RVDD_CONV=winograd / rvdd_set_option "conv_kernel" 2): tests + measurement
     bool warp_raw = false;        // --warp_raw (rvdd_set_option): warp the re-mosaicked frames at raw resolution, demosaic afterwards
     bool prev_noisy = false;      // --prev_noisy_frame (rvdd_set_option): the next step's "previous frame" is the demosaiced noisy one
     bool no_warp = false;         // --no_warp (rvdd_set_option): previous output / features / next frame enter the net unwarped
@@ -68,8 +93,7 @@ struct rvdd_handle {
     std::map<std::string, Conv3> conv3;
     float* w_out = nullptr;   // [3][48]
     float* b_out = nullptr;   // [3]
-    std::map<std::string, float*> dev_w;    // ConvNeXt tensors by key
-    std::vector<NextBlockW> next_blocks;
+    std::map<std::string, NextBlk> next_blk;   // ConvNeXt blocks by name
 
     // workspace
     Level lv[4];
@@ -110,6 +134,11 @@ int fail(rvdd_t* h, int code, const char* fmt, ...) {
     if (h) h->err = buf; else g_create_error = buf;
     return code;
 }
+
+#define ENTER(h)                                                                            \
+    DeviceGuard guard__((h)->cfg.device);                                                   \
+    if (guard__.err != hipSuccess)                                                          \
+        return fail((h), RVDD_ERR_HIP, "cannot select device %d: %s", (h)->cfg.device, hipGetErrorString(guard__.err))
 
 #define HIPCHK(h, expr)                                                                     \
     do {                                                                                    \
@@ -153,7 +182,8 @@ std::vector<float> arrange_conv3x3(const HostTensor& t, int c0, int cn, int cin_
 }
 
 // OIHW [48][cin_total][3][3], channels [c0, c0+48) -> U = G g G^T per (cout, cin), stored
-// [pos 16][j 3][m 3][cout&15][g 4][i 4] with channel = c0 + 16j+4g+i: the A-fragment order of wino3x3.hip.
+// [pos 16][j 3][m 3][lane = 16g + (cout&15)][i 4] with channel = c0 + 16j+4g+i: the A-fragment order of wino3x3.hip,
+// lane-linear so that each lane group of a ds_read_b128 covers one whole 256-B bank row (no bank conflict).
 // nj = 3: input channels c0 .. c0+47 of the filter; nj = 1: the first layer, channels 0 .. cin_total-1 (6 or 9)
 // zero-padded to 16
 std::vector<float> arrange_wino3x3(const HostTensor& t, int c0, int nj = 3) {
@@ -171,7 +201,7 @@ std::vector<float> arrange_wino3x3(const HostTensor& t, int c0, int nj = 3) {
                 for (int k = 0; k < 4; ++k) u[i][k] = tmp[i][0] * G[k][0] + tmp[i][1] * G[k][1] + tmp[i][2] * G[k][2];
             const int j = c / 16, g = (c % 16) / 4, ii = c % 4, m = co / 16, lr = co % 16;
             for (int pos = 0; pos < 16; ++pos)
-                out[((((size_t)(pos * nj + j) * 3 + m) * 16 + lr) * 4 + g) * 4 + ii] = (float)u[pos / 4][pos % 4];
+                out[(((size_t)(pos * nj + j) * 3 + m) * 64 + g * 16 + lr) * 4 + ii] = (float)u[pos / 4][pos % 4];
         }
     return out;
 }
@@ -554,12 +584,15 @@ int rvdd_create(const rvdd_cfg* cfg, rvdd_t** out) {
                     hipGetErrorString(e));
     if (cfg->device < 0 || cfg->device >= ndev)
         return fail(nullptr, RVDD_ERR_ARG, "rvdd_create: device %d out of range (0..%d)", cfg->device, ndev - 1);
-    e = hipSetDevice(cfg->device);
-    if (e != hipSuccess) return fail(nullptr, RVDD_ERR_HIP, "hipSetDevice: %s", hipGetErrorString(e));
+    DeviceGuard guard(cfg->device);
+    if (guard.err != hipSuccess) return fail(nullptr, RVDD_ERR_HIP, "cannot select device %d: %s", cfg->device, hipGetErrorString(guard.err));
 
     rvdd_t* h = new rvdd_handle();
     h->cfg = *cfg;
-    if (const char* cv = std::getenv("RVDD_CONV")) h->use_wino = std::strcmp(cv, "direct") != 0;
+    if (const char* cv = std::getenv("RVDD_CONV")) {     // direct | winograd (forced at every size) | anything else = auto
+        h->use_wino = std::strcmp(cv, "direct") != 0;
+        h->force_wino = std::strcmp(cv, "winograd") == 0;
+    }
     const int B = cfg->batch, H = cfg->height, W = cfg->width;
     int rc = RVDD_OK;
     auto A = [&](float** p, size_t floats) {
@@ -600,6 +633,7 @@ int rvdd_create(const rvdd_cfg* cfg, rvdd_t** out) {
 
 void rvdd_destroy(rvdd_t* h) {
     if (!h) return;
+    DeviceGuard guard(h->cfg.device);
     (void)hipDeviceSynchronize();
     for (void* p : h->allocs) (void)hipFree(p);
     if (h->scratch) (void)hipFree(h->scratch);
@@ -643,7 +677,7 @@ int rvdd_finalize_weights(rvdd_t* h) {
     if (h->finalized) return RVDD_OK;
     for (const auto& k : expected_keys(h))
         if (!h->staged.count(k.key)) return fail(h, RVDD_ERR_WEIGHT, "missing state_dict key '%s'", k.key.c_str());
-    HIPCHK(h, hipSetDevice(h->cfg.device));
+    ENTER(h);
     if (!h->is_next()) {
         for (const auto& n : convunet_conv_names(h->has_feat())) {
             const HostTensor& wt = h->staged.at(n + ".weight");
@@ -748,7 +782,15 @@ int rvdd_set_option(rvdd_t* h, const char* name, int32_t value) {
         h->prev_noisy = value != 0;
         return RVDD_OK;
     }
-    return fail(h, RVDD_ERR_ARG, "rvdd_set_option: unknown option '%s' (known: no_warp, warp_raw, prev_noisy_frame)", name);
+    if (std::strcmp(name, "conv_kernel") == 0) {
+        // which kernel runs the 3x3 convs: 0 = by launch size (default), 1 = the direct kernel everywhere,
+        // 2 = the Winograd kernel everywhere (also where it is the slower choice: tests and A/B measurements)
+        if (value < 0 || value > 2) return fail(h, RVDD_ERR_ARG, "rvdd_set_option: conv_kernel must be 0 (auto), 1 (direct) or 2 (winograd)");
+        h->use_wino = value != 1;
+        h->force_wino = value == 2;
+        return RVDD_OK;
+    }
+    return fail(h, RVDD_ERR_ARG, "rvdd_set_option: unknown option '%s' (known: no_warp, warp_raw, prev_noisy_frame, conv_kernel)", name);
 }
 
 int rvdd_reset(rvdd_t* h) {
@@ -760,6 +802,7 @@ int rvdd_reset(rvdd_t* h) {
 int rvdd_step(rvdd_t* h, const float* raw_prev, const float* raw_cur, const float* raw_next,
               const float* flow_prev, const float* flow_next, float* out_rgb, void* stream) {
     if (!h) return RVDD_ERR_ARG;
+    ENTER(h);
     if (!h->finalized) return fail(h, RVDD_ERR_STATE, "rvdd_step: weights not finalized");
     const bool nw = h->no_warp;
     if (!raw_cur || (!flow_prev && !nw) || !out_rgb) return fail(h, RVDD_ERR_ARG, "rvdd_step: raw_cur, flow_prev and out_rgb are required");
@@ -817,6 +860,7 @@ int rvdd_step(rvdd_t* h, const float* raw_prev, const float* raw_cur, const floa
 
 int rvdd_get_state(rvdd_t* h, float* lastden, float* lastfeat, void* stream) {
     if (!h) return RVDD_ERR_ARG;
+    ENTER(h);
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int B = h->cfg.batch, H = h->cfg.height, W = h->cfg.width;
     if (lastden) HIPCHK(h, launch_nhwc_to_nchw(h->lastden4, lastden, B, 3, H, W, 4, s));
@@ -829,6 +873,7 @@ int rvdd_get_state(rvdd_t* h, float* lastden, float* lastfeat, void* stream) {
 
 int rvdd_set_state(rvdd_t* h, const float* lastden, const float* lastfeat, void* stream) {
     if (!h) return RVDD_ERR_ARG;
+    ENTER(h);
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int B = h->cfg.batch, H = h->cfg.height, W = h->cfg.width;
     if (lastden) {
@@ -844,6 +889,7 @@ int rvdd_set_state(rvdd_t* h, const float* lastden, const float* lastfeat, void*
 
 int rvdd_psnr_l1(rvdd_t* h, const float* den, const float* gt, int64_t count, float* out2, void* stream) {
     if (!h || !den || !gt || !out2 || count <= 0) return fail(h, RVDD_ERR_ARG, "rvdd_psnr_l1: bad argument");
+    ENTER(h);
     hipStream_t s = static_cast<hipStream_t>(stream);
     int nblk = (int)((count + 256 * 16 - 1) / (256 * 16));
     if (nblk > 1024) nblk = 1024;
@@ -858,6 +904,7 @@ int rvdd_psnr_l1(rvdd_t* h, const float* den, const float* gt, int64_t count, fl
 
 int rvdd_unet_forward(rvdd_t* h, const float* x, const float* feat_in, float* out, float* feat_out, void* stream) {
     if (!h) return RVDD_ERR_ARG;
+    ENTER(h);
     if (!h->finalized) return fail(h, RVDD_ERR_STATE, "rvdd_unet_forward: weights not finalized");
     if (!x || !out) return fail(h, RVDD_ERR_ARG, "rvdd_unet_forward: x and out are required");
     if (h->has_feat() && !feat_in)
@@ -874,6 +921,7 @@ int rvdd_unet_forward(rvdd_t* h, const float* x, const float* feat_in, float* ou
 int rvdd_demosaic_ha(rvdd_t* h, const float* raw, int32_t n, int32_t hh, int32_t ww, float* rgb, void* stream) {
     if (h && n == 0) return RVDD_OK;       // an empty batch is valid and launches nothing
     if (!h || !raw || !rgb || n < 0 || hh < 1 || ww < 1) return fail(h, RVDD_ERR_ARG, "rvdd_demosaic_ha: bad argument");
+    ENTER(h);
     hipStream_t s = static_cast<hipStream_t>(stream);
     RC(ensure_scratch(h, (size_t)n * 4 * hh * ww * sizeof(float)));
     const int64_t hw = (int64_t)4 * hh * ww;
@@ -885,6 +933,7 @@ int rvdd_warp_bicubic(rvdd_t* h, const float* x, const float* flow, int32_t n, i
                       float* y, void* stream) {
     if (h && n == 0) return RVDD_OK;
     if (!h || !x || !flow || !y || n < 0 || c < 1 || H < 2 || W < 2) return fail(h, RVDD_ERR_ARG, "rvdd_warp_bicubic: bad argument");
+    ENTER(h);
     HIPCHK(h, launch_warp_nchw(x, flow, y, n, c, H, W, static_cast<hipStream_t>(stream)));
     return RVDD_OK;
 }
@@ -893,6 +942,7 @@ int rvdd_upsample_factor_2(rvdd_t* h, const float* t, int32_t n, int32_t c, int3
                            float multiply_by, float* out, void* stream) {
     if (h && n == 0) return RVDD_OK;
     if (!h || !t || !out || n < 0 || c < 1 || hh < 1 || ww < 1) return fail(h, RVDD_ERR_ARG, "rvdd_upsample_factor_2: bad argument");
+    ENTER(h);
     HIPCHK(h, launch_upsample_flow(t, out, n * c, hh, ww, multiply_by, static_cast<hipStream_t>(stream)));
     return RVDD_OK;
 }
@@ -900,6 +950,7 @@ int rvdd_upsample_factor_2(rvdd_t* h, const float* t, int32_t n, int32_t c, int3
 int rvdd_tvl1flow(rvdd_t* h, const float* I0, const float* I1, float* u, int32_t nx, int32_t ny, int32_t* iterations,
                   void* stream) {
     if (!h || !I0 || !I1 || !u || nx < 16 || ny < 16) return fail(h, RVDD_ERR_ARG, "rvdd_tvl1flow: bad argument (images must be >= 16x16)");
+    ENTER(h);
     if (!tvl1_size_ok(nx, ny))
         return fail(h, RVDD_ERR_ARG, "rvdd_tvl1flow: image too skinny for its pyramid (the reference reads out of bounds at this size)");
     if (!h->tvl1 || tvl1_ws_nx(h->tvl1) != nx || tvl1_ws_ny(h->tvl1) != ny) {
@@ -919,6 +970,7 @@ int rvdd_ppipe(rvdd_t* h, const float* img, int32_t n, int32_t H, int32_t W, int
                float* out_f32, void* stream) {
     if (h && n == 0) return RVDD_OK;
     if (!h || !img || !out_u8 || n < 0 || H < 1 || W < 1) return fail(h, RVDD_ERR_ARG, "rvdd_ppipe: bad argument");
+    ENTER(h);
     if (!(rgb_gain != 0.0) || !(red_gain != 0.0) || !(blue_gain != 0.0)) return fail(h, RVDD_ERR_ARG, "rvdd_ppipe: zero gain");
     // fwd_ppipe.py:29: a float32 tensor of Python-double quotients
     const float gains[3] = {(float)(1.0 / (red_gain * rgb_gain)), (float)(1.0 / rgb_gain), (float)(1.0 / (blue_gain * rgb_gain))};
@@ -929,6 +981,7 @@ int rvdd_ppipe(rvdd_t* h, const float* img, int32_t n, int32_t H, int32_t W, int
 int rvdd_srgb_metrics(rvdd_t* h, const uint8_t* a, const uint8_t* b, int32_t n, int32_t H, int32_t W, double* psnr,
                       double* ssim, void* stream) {
     if (!h || !a || !b || n < 1) return fail(h, RVDD_ERR_ARG, "rvdd_srgb_metrics: bad argument");
+    ENTER(h);
     if (H < 7 || W < 7) return fail(h, RVDD_ERR_ARG, "rvdd_srgb_metrics: win_size exceeds image extent (images must be >= 7x7)");
     hipStream_t s = static_cast<hipStream_t>(stream);
     RC(ensure_scratch(h, srgb_metrics_workspace(n, H, W)));
@@ -951,6 +1004,7 @@ int rvdd_tvl1flow_batch(rvdd_t* h, const float* I0, const float* I1, float* u, i
     if (h && n == 0) return RVDD_OK;
     if (!h || !I0 || !I1 || !u || n < 0 || nx < 16 || ny < 16)
         return fail(h, RVDD_ERR_ARG, "rvdd_tvl1flow_batch: bad argument (images must be >= 16x16)");
+    ENTER(h);
     if (!tvl1_size_ok(nx, ny))
         return fail(h, RVDD_ERR_ARG, "rvdd_tvl1flow_batch: image too skinny for its pyramid (the reference reads out of bounds at this size)");
     if (!h->tvl1 || tvl1_ws_nx(h->tvl1) != nx || tvl1_ws_ny(h->tvl1) != ny) {
@@ -968,6 +1022,7 @@ int rvdd_tvl1flow_batch(rvdd_t* h, const float* I0, const float* I1, float* u, i
 
 int rvdd_profile_enable(rvdd_t* h, int32_t on) {
     if (!h) return RVDD_ERR_ARG;
+    ENTER(h);
     RC(prof_flush(h));
     if (on) for (auto& p : h->prof) { p.seen = p.launches = 0; p.ms = p.flops = p.bytes = 0; }
     h->prof_on = on != 0;
@@ -986,6 +1041,7 @@ int rvdd_profile_count(const rvdd_t* h) { return h ? (int)h->prof.size() : 0; }
 int rvdd_profile_read(rvdd_t* h, int32_t idx, char* name, int32_t name_cap, int64_t* launches,
                       double* total_ms, double* flops, double* bytes) {
     if (!h || idx < 0 || idx >= (int)h->prof.size()) return fail(h, RVDD_ERR_ARG, "rvdd_profile_read: bad index");
+    ENTER(h);
     RC(prof_flush(h));
     const ProfClass& p = h->prof[idx];
     if (name && name_cap > 0) {
@@ -1001,6 +1057,7 @@ int rvdd_profile_read(rvdd_t* h, int32_t idx, char* name, int32_t name_cap, int6
 
 int rvdd_debug_conv_bench(rvdd_t* h, int32_t variant, int32_t level, int32_t iters, float* ms, void* stream) {
     if (!h || !ms || level < 0 || level > 3 || iters < 1) return fail(h, RVDD_ERR_ARG, "rvdd_debug_conv_bench: bad argument");
+    ENTER(h);
     if (!h->finalized || h->is_next()) return fail(h, RVDD_ERR_STATE, "rvdd_debug_conv_bench: needs a finalized convunet handle");
     hipStream_t s = static_cast<hipStream_t>(stream);
     const bool was = h->prof_on, was_wino = h->use_wino;
@@ -1029,12 +1086,14 @@ int rvdd_debug_conv_bench(rvdd_t* h, int32_t variant, int32_t level, int32_t ite
 
 int rvdd_timer_start(rvdd_t* h, void* stream) {
     if (!h) return RVDD_ERR_ARG;
+    ENTER(h);
     HIPCHK(h, hipEventRecord(h->t0, static_cast<hipStream_t>(stream)));
     return RVDD_OK;
 }
 
 int rvdd_timer_stop_ms(rvdd_t* h, void* stream, float* ms) {
     if (!h || !ms) return RVDD_ERR_ARG;
+    ENTER(h);
     HIPCHK(h, hipEventRecord(h->t1, static_cast<hipStream_t>(stream)));
     HIPCHK(h, hipEventSynchronize(h->t1));
     HIPCHK(h, hipEventElapsedTime(ms, h->t0, h->t1));

@@ -6,10 +6,37 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kF = 48;        // feature channels everywhere (filters=48)
 constexpr int kNetInC = 16;   // padded channel count of the network input map
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a PER-DEVICE attribute of a kernel: `done` (one per kernel
+// instantiation) remembers the devices of this process that already have it, one bit per device ordinal.
+inline hipError_t allow_dynamic_lds(const void* kern, size_t bytes, std::atomic<uint64_t>& done) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const uint64_t bit = 1ull << (dev & 63);
+    if (done.load(std::memory_order_acquire) & bit) return hipSuccess;
+    e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e == hipSuccess) done.fetch_or(bit, std::memory_order_release);
+    return e;
+}
+// compute units of the current device (queried once per device ordinal)
+inline int current_device_cus() {
+    static std::atomic<int> cache[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    int v = cache[dev & 63].load(std::memory_order_relaxed);
+    if (v > 0) return v;
+    int cus = 256;
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    cache[dev & 63].store(cus, std::memory_order_relaxed);
+    return cus;
+}
 
 // ---------------------------------------------------------------- conv3x3 --
 // EPI_RELU_OUT3 (Winograd kernel only): ReLU, store the 48-channel map AND apply the final 1x1 conv 48->3

@@ -16,8 +16,8 @@
 //    workgroup run independently after the filter bank is resident.
 //  * The transformed filter bank U (16 positions x 48 x 48 floats = 144 KiB) is
 //    DMA'd to LDS once per (persistent) workgroup, pre-arranged on the host as
-//    [pos][j][m][cout&15][g][i] so that an A fragment is one conflict-free
-//    ds_read_b128 per four MFMAs.
+//    [pos][j][m][lane = 16g + (cout&15)][i]: an A fragment is one ds_read_b128 per
+//    four MFMAs whose four lane groups each cover one whole 256-B bank row.
 //  * Per wave and unit (16 tiles = 2x32 pixels): 3 chunks x 16 positions x 3 cout
 //    blocks x 4 k-steps = 576 MFMAs on 48 accumulators (192 VGPRs); the patch of the
 //    next chunk / next unit is in flight while the current one is multiplied.
@@ -98,7 +98,6 @@ __device__ __forceinline__ void wino_body(const ConvArgs& a) {
     __syncthreads();
 
     const int units_per_img = a.tiles_x * a.tiles_y;
-    const unsigned in_bytes = (unsigned)(a.H * a.W * CIN * 4);      // the conv input
     const unsigned map_bytes = (unsigned)(a.H * a.W * kF * 4);      // 48-channel maps of the input's size (partial sums, residuals)
     const unsigned out_bytes = (unsigned)(a.Hout * a.Wout * kF * 4);
     const int row_bytes = a.W * CIN * 4;
@@ -113,29 +112,30 @@ __device__ __forceinline__ void wino_body(const ConvArgs& a) {
         u.ty = uy * 4 + wave;
         u.tx = ux * 16 + lr;
     };
-    // the 16 patch pixels of a tile: 16 buffer loads of 16 B; pixels outside the image get an
-    // out-of-range offset (hardware zero fill = padding 1).  Offsets are recomputed per load
-    // (a few VALU ops) instead of being kept in 16 registers.
+    // The 16 patch pixels of a tile: 16 buffer loads of 16 B.  One buffer descriptor PER PATCH ROW (the row index
+    // is wave-uniform, so this is scalar work): base = the row's first pixel, num_records = the row's bytes, or 0
+    // for a row outside the image.  The hardware range check then zero-fills whole rows above / below the image and
+    // every pixel right of it (= padding 1) with no per-lane select, and no offset ever exceeds a row, whatever the
+    // size of the map.  Only the tile column left of the image (x = -1) needs a lane select.
     auto load_patch = [&](f32x4 (&p)[16], const UnitPos& u, int j) {
-        __amdgpu_buffer_rsrc_t r =
-            __builtin_amdgcn_make_buffer_rsrc((void*)(a.in + (size_t)u.b * a.H * a.W * CIN), 0, in_bytes, 0x00020000);
+        const float* img = a.in + (size_t)u.b * a.H * a.W * CIN;
         const int y0 = 2 * u.ty - 1, x0 = 2 * u.tx - 1;
-        const int base = (y0 * a.W + x0) * (CIN * 4) + (16 * j + 4 * g) * 4;
-        // branch-free validity: an invalid row / column adds 2^30 to the offset, which pushes it
-        // past num_records (< 2^31) whatever the (possibly negative) base is
-        int ro[4], co[4];
+        const unsigned v1 = (unsigned)((x0 + 1) * (CIN * 4) + (16 * j + 4 * g) * 4);      // pixel x0 + 1 >= 0
+        const unsigned v0 = x0 >= 0 ? v1 - CIN * 4 : 0xffffffffu;
 #pragma unroll
-        for (int d = 0; d < 4; ++d) {
-            ro[d] = (unsigned)(y0 + d) < (unsigned)a.H ? d * row_bytes : 0x40000000;
-            co[d] = (unsigned)(x0 + d) < (unsigned)a.W ? d * (CIN * 4) : 0x40000000;
+        for (int dy = 0; dy < 4; ++dy) {
+            const int y = y0 + dy;
+            const bool row_ok = (unsigned)y < (unsigned)a.H;
+            __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(
+                (void*)(img + (ptrdiff_t)y * a.W * CIN), 0, row_ok ? row_bytes : 0, 0x00020000);
+            p[dy * 4 + 0] = bload(r, v0);
+            p[dy * 4 + 1] = bload(r, v1);
+            p[dy * 4 + 2] = bload(r, v1 + CIN * 4);
+            p[dy * 4 + 3] = bload(r, v1 + 2 * CIN * 4);
         }
-#pragma unroll
-        for (int dy = 0; dy < 4; ++dy)
-#pragma unroll
-            for (int dx = 0; dx < 4; ++dx) p[dy * 4 + dx] = bload(r, (unsigned)(base + ro[dy] + co[dx]));
     };
 
-    const float* ub = U + lr * 16 + g * 4;
+    const float* ub = U + lane * 4;     // lane-linear fragments: each ds_read_b128 lane group covers one bank row
     f32x4 pb[2][16];      // ping-pong patch buffers (raw patch -> transformed in place)
     f32x4 acc[16][3];
     auto ldsA = [&](int j, int pos, int m) {
@@ -351,24 +351,18 @@ __global__ __launch_bounds__(256, 1) void wino3x3_c16_kernel(ConvArgs a) {
 
 template <int EPI, bool ACC_IN, int NJ>
 hipError_t launch_w(const ConvArgs& a0, hipStream_t s) {
-    static bool attr_done = false;
+    static std::atomic<uint64_t> attr_done{0};
     void (*kern)(ConvArgs);
     if constexpr (NJ == 3) kern = wino3x3_kernel<EPI, ACC_IN>;
     else kern = wino3x3_c16_kernel<EPI>;
     constexpr size_t U_LDS_BYTES = (size_t)u_floats(NJ) * 4;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)U_LDS_BYTES);
-        if (e != hipSuccess) return e;
-        attr_done = true;
-    }
+    if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(kern), U_LDS_BYTES, attr_done); e != hipSuccess)
+        return e;
     ConvArgs a = a0;
     a.tiles_x = (a.W + 31) / 32;     // unit = 4 tile rows x 16 tile columns = 8 x 32 output pixels
     a.tiles_y = (a.H + 7) / 8;
     a.ntiles = a.B * a.tiles_x * a.tiles_y;
-    int dev = 0, cus = 256;
-    (void)hipGetDevice(&dev);
-    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const int cus = current_device_cus();
     const int grid = a.ntiles < cus ? a.ntiles : cus;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), U_LDS_BYTES, s, a);
     return hipGetLastError();
@@ -381,12 +375,14 @@ size_t wino3x3_weight_floats() { return U_FLOATS; }
 hipError_t launch_wino3x3(const ConvArgs& a, int cin, int epi, hipStream_t s) {
     if (a.ntiles <= 0) return hipSuccess;
     if (cin == 16) {
-        if (a.acc_in || (size_t)a.H * a.W * kF * 4 >= 0x80000000ull) return hipErrorInvalidValue;
+        if (a.acc_in || (size_t)a.Hout * a.Wout * kF * 4 >= 0x80000000ull) return hipErrorInvalidValue;
         if (epi == EPI_NONE) return launch_w<EPI_NONE, false, 1>(a, s);
         if (epi == EPI_RELU) return launch_w<EPI_RELU, false, 1>(a, s);
         return hipErrorInvalidValue;
     }
     if (cin != 48) return hipErrorInvalidValue;
+    // stores and the side inputs (partial sums, residuals) address their map with one 32-bit byte offset whose
+    // out-of-image sentinel is 2^31; the conv input is addressed per row and has no such limit
     if ((size_t)a.H * a.W * kF * 4 >= 0x80000000ull || (size_t)a.Hout * a.Wout * kF * 4 >= 0x80000000ull)
         return hipErrorInvalidValue;
     const bool acc = a.acc_in != nullptr;

@@ -58,7 +58,7 @@ class HipDenoiser:
         self.device_index = device
         self.filters = 48
         self._sd: Optional[Dict[str, torch.Tensor]] = None
-        self._rt: Dict[tuple, RvddRuntime] = {}
+        self._rt: "OrderedDict[tuple, RvddRuntime]" = OrderedDict()     # least recently used first
         self.old_features: Optional[torch.Tensor] = None
         self.training = False
 
@@ -91,15 +91,24 @@ class HipDenoiser:
         return self
 
     # -- runtime handles -------------------------------------------------------
+    # A runtime owns its workspace (about 1.5 GB per 720p sequence): keep the handles of the last few frame
+    # sizes only.  A validation run sees one or two sizes; a loop over many sizes must not pile them up.
+    MAX_CACHED_RUNTIMES = 2
+
     def runtime_for(self, B: int, H: int, W: int) -> RvddRuntime:
         key = (B, H, W)
         rt = self._rt.get(key)
-        if rt is None:
-            if self._sd is None:
-                raise RuntimeError("rvdd: weights not loaded (call load_state_dict / model.setup first)")
-            rt = RvddRuntime(self._arch, self.future, B, H, W, self.device_index)
-            rt.load_state_dict(self._sd)
-            self._rt[key] = rt
+        if rt is not None:
+            self._rt.move_to_end(key)
+            return rt
+        if self._sd is None:
+            raise RuntimeError("rvdd: weights not loaded (call load_state_dict / model.setup first)")
+        while len(self._rt) >= self.MAX_CACHED_RUNTIMES:
+            _, old = self._rt.popitem(last=False)
+            old.close()
+        rt = RvddRuntime(self._arch, self.future, B, H, W, self.device_index)
+        rt.load_state_dict(self._sd)
+        self._rt[key] = rt
         return rt
 
     def __call__(self, x: torch.Tensor) -> torch.Tensor:

@@ -25,9 +25,11 @@ def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
     return None if t is None else t.data_ptr()
 
 
-def _chk_dev(t: torch.Tensor, shape: Tuple[int, ...], name: str) -> torch.Tensor:
+def _chk_dev(t: torch.Tensor, shape: Tuple[int, ...], name: str, device: Optional[int] = None) -> torch.Tensor:
     if not t.is_cuda:
         raise RuntimeError(f"{name} must be a GPU tensor (rvdd has no CPU path)")
+    if device is not None and t.device.index != device:
+        raise RuntimeError(f"{name} lives on cuda:{t.device.index} but this runtime drives cuda:{device}")
     if tuple(t.shape) != tuple(shape):
         raise RuntimeError(f"{name} has shape {tuple(t.shape)}, expected {tuple(shape)}")
     if t.dtype != torch.float32:
@@ -94,19 +96,19 @@ class RvddRuntime:
     def step(self, raw_prev, raw_cur, raw_next, flow_prev, flow_next, out=None) -> torch.Tensor:
         B, H, W = self.B, self.H, self.W
         rs, fs = (B, 4, H // 2, W // 2), (B, 2, H // 2, W // 2)
-        raw_cur = _chk_dev(raw_cur, rs, "raw_cur")
+        raw_cur = _chk_dev(raw_cur, rs, "raw_cur", self.device)
         if getattr(self, "no_warp", False):
             flow_prev = flow_next = None
         elif flow_prev is None:
             raise RuntimeError("rvdd_step: flow_prev is required (no --no_warp option set on this runtime)")
-        flow_prev = None if flow_prev is None else _chk_dev(flow_prev, fs, "flow_prev")
-        raw_prev = None if raw_prev is None else _chk_dev(raw_prev, rs, "raw_prev")
-        raw_next = None if raw_next is None else _chk_dev(raw_next, rs, "raw_next")
-        flow_next = None if flow_next is None else _chk_dev(flow_next, fs, "flow_next")
+        flow_prev = None if flow_prev is None else _chk_dev(flow_prev, fs, "flow_prev", self.device)
+        raw_prev = None if raw_prev is None else _chk_dev(raw_prev, rs, "raw_prev", self.device)
+        raw_next = None if raw_next is None else _chk_dev(raw_next, rs, "raw_next", self.device)
+        flow_next = None if flow_next is None else _chk_dev(flow_next, fs, "flow_next", self.device)
         if out is None:
             out = torch.empty(B, 3, H, W, dtype=torch.float32, device=self._tdev)
         else:
-            _chk_dev(out, (B, 3, H, W), "out")
+            _chk_dev(out, (B, 3, H, W), "out", self.device)
             assert out.is_contiguous()
         self._check(self.lib.rvdd_step(self.h, _ptr(raw_prev), _ptr(raw_cur), _ptr(raw_next),
                                        _ptr(flow_prev), _ptr(flow_next), _ptr(out), self._stream()),
@@ -123,16 +125,16 @@ class RvddRuntime:
     def set_state(self, lastden=None, lastfeat=None):
         B, H, W = self.B, self.H, self.W
         if lastden is not None:
-            lastden = _chk_dev(lastden, (B, 3, H, W), "lastden")
+            lastden = _chk_dev(lastden, (B, 3, H, W), "lastden", self.device)
         if lastfeat is not None:
-            lastfeat = _chk_dev(lastfeat, (B, 48, H, W), "lastfeat")
+            lastfeat = _chk_dev(lastfeat, (B, 48, H, W), "lastfeat", self.device)
         self._check(self.lib.rvdd_set_state(self.h, _ptr(lastden), _ptr(lastfeat), self._stream()),
                     "rvdd_set_state")
 
     def psnr_l1(self, den: torch.Tensor, gt: torch.Tensor) -> Tuple[float, float]:
         """-> (L1*100, PSNR) as compute_losses (models/recurrent_model.py:512-525)."""
-        den = _chk_dev(den, den.shape, "den")
-        gt = _chk_dev(gt, den.shape, "gt")
+        den = _chk_dev(den, den.shape, "den", self.device)
+        gt = _chk_dev(gt, den.shape, "gt", self.device)
         out = (C.c_float * 2)()
         self._check(self.lib.rvdd_psnr_l1(self.h, _ptr(den), _ptr(gt), den.numel(), out, self._stream()),
                     "rvdd_psnr_l1")
@@ -141,9 +143,9 @@ class RvddRuntime:
     # -- single ops -----------------------------------------------------------
     def unet_forward(self, x, feat_in=None):
         B, H, W = self.B, self.H, self.W
-        x = _chk_dev(x, (B, 3 * (2 + self.future), H, W), "x")
+        x = _chk_dev(x, (B, 3 * (2 + self.future), H, W), "x", self.device)
         if feat_in is not None:
-            feat_in = _chk_dev(feat_in, (B, 48, H, W), "feat_in")
+            feat_in = _chk_dev(feat_in, (B, 48, H, W), "feat_in", self.device)
         out = torch.empty(B, 3, H, W, dtype=torch.float32, device=self._tdev)
         fo = torch.empty(B, 48, H, W, dtype=torch.float32, device=self._tdev) if self.feat else None
         self._check(self.lib.rvdd_unet_forward(self.h, _ptr(x), _ptr(feat_in), _ptr(out), _ptr(fo),
@@ -152,7 +154,7 @@ class RvddRuntime:
 
     def demosaic(self, raw: torch.Tensor) -> torch.Tensor:
         n, c, h, w = raw.shape
-        raw = _chk_dev(raw, raw.shape, "raw")
+        raw = _chk_dev(raw, raw.shape, "raw", self.device)
         assert c % 4 == 0
         k = n * (c // 4)
         out = torch.empty(n, 3 * (c // 4), 2 * h, 2 * w, dtype=torch.float32, device=raw.device)
@@ -162,8 +164,8 @@ class RvddRuntime:
 
     def warp(self, x: torch.Tensor, flow: torch.Tensor) -> torch.Tensor:
         n, c, H, W = x.shape
-        x = _chk_dev(x, x.shape, "x")
-        flow = _chk_dev(flow, (n, 2, H, W), "flow")
+        x = _chk_dev(x, x.shape, "x", self.device)
+        flow = _chk_dev(flow, (n, 2, H, W), "flow", self.device)
         y = torch.empty_like(x)
         self._check(self.lib.rvdd_warp_bicubic(self.h, _ptr(x), _ptr(flow), n, c, H, W, _ptr(y),
                                                self._stream()), "rvdd_warp_bicubic")
@@ -171,7 +173,7 @@ class RvddRuntime:
 
     def upsample_factor_2(self, t: torch.Tensor, multiply_by: float = 1.0) -> torch.Tensor:
         *rem, c, h, w = t.shape
-        t = _chk_dev(t, t.shape, "t")
+        t = _chk_dev(t, t.shape, "t", self.device)
         n = 1
         for r in rem:
             n *= r
@@ -183,8 +185,8 @@ class RvddRuntime:
     def tvl1flow(self, I0: torch.Tensor, I1: torch.Tensor, want_iterations: bool = False):
         """[ny,nx] x2 -> flow [2,ny,nx] (libBridge tvl1flow, libBridge.cpp:44)."""
         ny, nx = I0.shape
-        I0 = _chk_dev(I0, (ny, nx), "I0")
-        I1 = _chk_dev(I1, (ny, nx), "I1")
+        I0 = _chk_dev(I0, (ny, nx), "I0", self.device)
+        I1 = _chk_dev(I1, (ny, nx), "I1", self.device)
         u = torch.empty(2, ny, nx, dtype=torch.float32, device=I0.device)
         it = C.c_int32(0)
         self._check(self.lib.rvdd_tvl1flow(self.h, _ptr(I0), _ptr(I1), _ptr(u), nx, ny,
@@ -194,8 +196,8 @@ class RvddRuntime:
     def tvl1flow_batch(self, I0: torch.Tensor, I1: torch.Tensor, want_iterations: bool = False):
         """[n,ny,nx] x2 -> flows [n,2,ny,nx]: n independent pairs, two per cooperative launch."""
         n, ny, nx = I0.shape
-        I0 = _chk_dev(I0, (n, ny, nx), "I0")
-        I1 = _chk_dev(I1, (n, ny, nx), "I1")
+        I0 = _chk_dev(I0, (n, ny, nx), "I0", self.device)
+        I1 = _chk_dev(I1, (n, ny, nx), "I1", self.device)
         u = torch.empty(n, 2, ny, nx, dtype=torch.float32, device=I0.device)
         it = (C.c_int32 * max(n, 1))()
         self._check(self.lib.rvdd_tvl1flow_batch(self.h, _ptr(I0), _ptr(I1), _ptr(u), n, nx, ny,
@@ -208,6 +210,8 @@ class RvddRuntime:
         -> uint8 [n,H,W,3] (and the float32 sRGB x 255 image before rounding)."""
         if not img.is_cuda or img.dtype != torch.float32 or img.dim() != 4:
             raise RuntimeError("ppipe: img must be a 4-D float32 GPU tensor (rvdd has no CPU path)")
+        if img.device.index != self.device:
+            raise RuntimeError(f"ppipe: img lives on cuda:{img.device.index} but this runtime drives cuda:{self.device}")
         if layout == "nchw":
             n, c, H, W = img.shape
             sn, sc, sy, sx = img.stride()
@@ -232,6 +236,8 @@ class RvddRuntime:
         if not (a.is_cuda and b.is_cuda) or a.dtype != torch.uint8 or b.dtype != torch.uint8 or a.dim() != 4 \
                 or a.shape[3] != 3:
             raise RuntimeError("srgb_metrics: a, b must be uint8 GPU tensors [n,H,W,3]")
+        if a.device.index != self.device or b.device.index != self.device:
+            raise RuntimeError(f"srgb_metrics: a, b must live on cuda:{self.device}, the device this runtime drives")
         a, b = a.contiguous(), b.contiguous()
         n, H, W, _ = a.shape
         ps, ss = (C.c_double * n)(), (C.c_double * n)()

@@ -36,6 +36,19 @@ def parity_psnr(a, b):
     return 200.0 if mse == 0 else 10 * math.log10(4.0 / mse)
 
 
+@pytest.fixture(params=["auto", "winograd"])
+def conv_kernel(request, monkeypatch):
+    """Which kernel runs the 3x3 convs.  "auto" picks by launch size, so small frames run the direct kernel;
+    "winograd" forces the production (720p) Winograd kernel at every size: ragged tiles in x and y, the
+    zero_pad_features output placement, the 16-channel first layer and the fused 1x1 epilogue all run at the
+    fixture sizes the reference pinned.  Read by rvdd_create (RVDD_CONV)."""
+    if request.param == "winograd":
+        monkeypatch.setenv("RVDD_CONV", "winograd")
+    else:
+        monkeypatch.delenv("RVDD_CONV", raising=False)
+    return request.param
+
+
 @pytest.fixture(scope="module")
 def ops():
     from rvdd_release_amd.util._ops import ops_runtime
@@ -89,7 +102,7 @@ def test_psnr(ops):
 
 
 @pytest.mark.parametrize("name", BUILT)
-def test_net_forward_golden(name):
+def test_net_forward_golden(name, conv_kernel):
     from rvdd_release_amd.networks import define_net_arch
     stem, fut, _ = VARIANTS[name]
     g = _npz(f"net_{name}.npz")
@@ -115,7 +128,7 @@ def test_feat_net_requires_features():
 
 
 @pytest.mark.parametrize("name", BUILT)
-def test_sequence_golden_model_surface(name):
+def test_sequence_golden_model_surface(name, conv_kernel):
     """Drives the model exactly like validate.py:64-88 drives the reference's."""
     from rvdd_release_amd.models import create_model
     from rvdd_release_amd.options import make_opt
@@ -158,8 +171,11 @@ def test_sequence_golden_model_surface(name):
     ("convunet+feat", "recurrent-convunet+feat-iso3200", 0, 2, 72, 104),      # ragged tiles, batch 2
     ("convunet+feat", "recurrent-convunet+feat-future-iso12800", 1, 1, 36, 52),  # zero_pad_features path
     ("convunet", "recurrent-convunet-iso3200", 0, 1, 256, 256),               # BASELINE config C1 size
+    ("convunet+feat", "recurrent-convunet+feat-iso3200", 0, 2, 136, 248),     # shaped like the 1/8 level of 1080p: Winograd
+                                                                              # by size, ragged in x at every level
+    ("convunet", "recurrent-convunet-future-iso3200", 1, 3, 20, 28),          # smallest golden size, batch 3
 ])
-def test_sequence_vs_oracle(arch, stem, fut, B, H, W):
+def test_sequence_vs_oracle(arch, stem, fut, B, H, W, conv_kernel):
     from rvdd_release_amd import synth
     from rvdd_release_amd.runtime import RvddRuntime
     if arch.startswith("next") and "next-iso3200" not in BUILT:
@@ -278,6 +294,108 @@ def test_full_size_720p_vs_oracle_and_invariants():
     finally:
         del os.environ["RVDD_CONV"]
     assert (direct[0] - alone[0]).abs().max() < 1e-4 and parity_psnr(direct[0].cpu(), alone[0].cpu()) > 120.0
+
+
+@pytest.mark.parametrize("arch,stem,fut,iso", [
+    ("convunet+feat", "recurrent-convunet+feat-future-iso12800", 1, 12800),       # BASELINE config C3
+    ("next+feat", "recurrent-ConvNeXtUnet+feat-future-iso3200", 1, 3200),        # BASELINE config C4
+])
+def test_full_size_720p_future_configs_vs_oracle(arch, stem, fut, iso):
+    """BASELINE configs C3 and C4 at their real size (1280x720, future frame): two output frames against the
+    oracle (max-abs < 1e-4, parity PSNR > 120 dB, task PSNR within 0.01 dB) and run-to-run determinism."""
+    from rvdd_release_amd import synth
+    from rvdd_release_amd.runtime import RvddRuntime
+    if arch.startswith("next") and "next-iso3200" not in BUILT:
+        pytest.skip("ConvNeXt path not built")
+    sd = load_weights(stem)
+    H, W, T = 720, 1280, 4
+    s0 = synth.make_sequence(T, H, W, iso=iso, seed=3000 + fut, device="cuda")
+
+    def run():
+        rt = RvddRuntime(arch, fut, 1, H, W, 0)
+        rt.load_state_dict(sd)
+        outs = [rt.step(s0.raw[t - 1][None] if t == 1 else None, s0.raw[t][None], s0.raw[t + 1][None],
+                        s0.flow_prev[t][None], s0.flow_next[t][None]).clone() for t in (1, 2)]
+        _, feat = rt.get_state()
+        rt.close()
+        return outs, feat
+
+    got, feat = run()
+    again, feat2 = run()
+    for a, b in zip(got, again):
+        assert torch.equal(a, b)
+    assert torch.equal(feat, feat2)
+    orc = O.RecurrentOracle(sd, future=fut)
+    c = lambda x: x[None].cpu()
+    for t in (1, 2):
+        want = orc.step(c(s0.raw[t - 1]), c(s0.raw[t]), c(s0.raw[t + 1]), c(s0.flow_prev[t]), c(s0.flow_next[t]),
+                        first=(t == 1))[0]
+        g = got[t - 1][0].cpu()
+        assert (g - want).abs().max() < 1e-4 and parity_psnr(g, want) > 120.0, (t, float((g - want).abs().max()))
+        gt = c(s0.gt[t])
+        assert abs(O.psnr(g[None], gt) - O.psnr(want[None], gt)) < 0.01
+
+
+def test_batch_of_four_720p_invariants():
+    """B = 4 (the bench batch).  At 720p the 1/8-resolution level switches from the direct kernel (B <= 2) to the
+    Winograd kernel (B >= 4: enough 8x32-pixel units to fill the chip), so a sequence of a B = 4 run equals the
+    same sequence run alone TO FP32 TOLERANCE (max-abs < 1e-4, parity > 120 dB), not bit for bit; what does hold
+    bit for bit is position independence inside the batch (the same sequence in slots 0 and 2) and, with the
+    kernel choice pinned (conv_kernel = winograd at every size), equality with the run alone."""
+    from rvdd_release_amd import synth
+    from rvdd_release_amd.runtime import RvddRuntime
+    sd = load_weights("recurrent-convunet+feat-iso3200")
+    H, W = 720, 1280
+    seqs = [synth.make_sequence(3, H, W, iso=3200, seed=2100 + b, device="cuda") for b in range(2)]
+
+    def run(which, conv=0):
+        rt = RvddRuntime("convunet+feat", 0, len(which), H, W, 0)
+        rt.set_option("conv_kernel", conv)
+        rt.load_state_dict(sd)
+        outs = []
+        for t in (1, 2):
+            st = lambda f: torch.stack([f(seqs[b]) for b in which], 0)
+            outs.append(rt.step(st(lambda s: s.raw[t - 1]) if t == 1 else None, st(lambda s: s.raw[t]), None,
+                                st(lambda s: s.flow_prev[t]), None).clone())
+        rt.close()
+        return outs
+
+    four = run([0, 1, 0, 1])
+    alone = run([1])
+    for t in range(2):
+        assert torch.equal(four[t][0], four[t][2]) and torch.equal(four[t][1], four[t][3])
+        d = (four[t][1] - alone[t][0]).abs().max()
+        assert d < 1e-4 and parity_psnr(four[t][1].cpu(), alone[t][0].cpu()) > 120.0, float(d)
+    four_w = run([0, 1, 0, 1], conv=2)
+    alone_w = run([1], conv=2)
+    for t in range(2):
+        assert torch.equal(four_w[t][1], alone_w[t][0])
+
+
+def test_4k_frame_borders():
+    """A frame above 5.59 Mpx (one 48-channel map > 2^30 bytes): the padding-1 border of the 3x3 convs comes from
+    the buffer range check, which must hold whatever the size of the map.  One step of config C2's net on a
+    3840x2176 frame against the oracle, whole frame (borders included), Winograd and direct kernel."""
+    from rvdd_release_amd import synth
+    from rvdd_release_amd.runtime import RvddRuntime
+    sd = load_weights("recurrent-convunet+feat-iso3200")
+    H, W = 2176, 3840
+    s0 = synth.make_sequence(2, H, W, iso=3200, seed=4000, device="cuda")
+    outs = {}
+    for conv in (0, 1):
+        rt = RvddRuntime("convunet+feat", 0, 1, H, W, 0)
+        rt.set_option("conv_kernel", conv)
+        rt.load_state_dict(sd)
+        outs[conv] = rt.step(s0.raw[0][None], s0.raw[1][None], None, s0.flow_prev[1][None], None)[0].cpu()
+        rt.close()
+    c = lambda x: x[None].cpu()
+    want = O.RecurrentOracle(sd, future=0).step(c(s0.raw[0]), c(s0.raw[1]), None, c(s0.flow_prev[1]), None, first=True)[0]
+    for conv, got in outs.items():
+        d = (got - want).abs()
+        assert d.max() < 1e-4, (conv, float(d.max()))
+        # the outermost ring of pixels is where a wrong (non-zero) halo read would show
+        ring = torch.cat((d[:, :2].flatten(), d[:, -2:].flatten(), d[:, :, :2].flatten(), d[:, :, -2:].flatten()))
+        assert ring.max() < 1e-4 and parity_psnr(got, want) > 120.0
 
 
 def test_empty_and_odd_inputs(ops):

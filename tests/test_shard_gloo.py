@@ -37,6 +37,13 @@ WORKER = textwrap.dedent("""
 """)
 
 
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
 def _run(nproc, tmp_path):
     script = tmp_path / "worker.py"
     script.write_text(WORKER.format(repo=REPO))
@@ -45,7 +52,7 @@ def _run(nproc, tmp_path):
         cmd = [sys.executable, str(script)]
     else:
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}",
-               "--master-addr", "127.0.0.1", "--master-port", "29653", str(script)]
+               "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), str(script)]
     out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     import json
