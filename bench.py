@@ -2,111 +2,222 @@
 """Headline benchmark: output frames/s of the recurrent denoise+demosaic hot
 path on N MI355X (one process per GPU), BASELINE.json's metric.
 
-  python bench.py                       # N=1, config C2, finishes in minutes
-  python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
-      --master-addr 127.0.0.1 --master-port P bench.py --gpus N --steps K --warmup W
+  python bench.py                                  # N=1, config C2, finishes in minutes
+  python bench.py --gpus N --steps K --warmup W    # launches its own N ranks (torch.distributed.run child)
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+      --master-port P bench.py --gpus N --steps K --warmup W          # or is launched as one of them
 
 A "step" is one pass of the hot path over one batch of synthetic input already
 resident in HBM: B independent sequences of T frames advanced in lockstep on
 each GPU (T-1-future output frames per sequence).  Sequences share nothing, so
-ranks never exchange data inside the timed region (weak scaling); the only
-collectives are the barrier/max that bracket it and one all-gather of the
-per-frame PSNR values afterwards.
+ranks never exchange data inside the timed region; the only collectives are the
+barrier/max that bracket it, one all-gather of the per-frame PSNR values
+afterwards and, with --collate-outputs, one all-gather of the output frames
+(timed on its own, outside the compute region).
 
-The JSON line carries `roofline` for the dominant kernel (the 48->48 3x3 conv,
-f32 MFMA: FLOP-bound, peak 157.3 TFLOP/s) measured with HIP events around each
-of its launches inside the timed region, and `cpu_baseline`: the CPU oracle
-(oracle/rvdd_oracle.py, a torch-CPU restatement of the reference's PyTorch
-path) timed on this host's cores on a bounded sample of the same workload.
+  N = 1   config C2 (the configuration the metric is quoted on), B = 4
+  N > 1   config C5 (B = 8 sequences of 90 frames per GPU: 64 sequences on 8 GPUs), weak scaling;
+          --scaling strong fixes the total at --sequences (64) instead and runs each rank's share in groups of B
+
+The JSON line carries `roofline` for the dominant kernel (the 48->48 3x3 conv on
+the f32 matrix cores, peak 157.3 TFLOP/s), measured with HIP events around a
+uniform sample of its launches inside the timed region, and `cpu_baseline`: the
+CPU oracle (oracle/rvdd_oracle.py, a torch-CPU restatement of the reference's
+PyTorch path) timed on this host's cores on a bounded sample of the same workload.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import torch
 
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 CONFIGS = {
-    # name: (arch, weights stem, future, iso, H, W, T, algorithmic GFLOP per output frame @ HxW)
-    "C1": ("convunet", "recurrent-convunet-iso3200", 0, 3200, 256, 256, 8, 25.50),
-    "C2": ("convunet+feat", "recurrent-convunet+feat-iso3200", 0, 3200, 720, 1280, 30, 435.025),
-    "C3": ("convunet+feat", "recurrent-convunet+feat-future-iso12800", 1, 12800, 720, 1280, 30, 437.413),
-    "C4": ("next+feat", "recurrent-ConvNeXtUnet+feat-future-iso3200", 1, 3200, 720, 1280, 30, 401.998),
+    # name: (arch, weights stem, future, iso, H, W, T, default B, algorithmic GFLOP per output frame @ HxW)
+    "C1": ("convunet", "recurrent-convunet-iso3200", 0, 3200, 256, 256, 8, 4, 25.50),
+    "C2": ("convunet+feat", "recurrent-convunet+feat-iso3200", 0, 3200, 720, 1280, 30, 4, 435.025),
+    "C3": ("convunet+feat", "recurrent-convunet+feat-future-iso12800", 1, 12800, 720, 1280, 30, 4, 437.413),
+    "C4": ("next+feat", "recurrent-ConvNeXtUnet+feat-future-iso3200", 1, 3200, 720, 1280, 30, 4, 401.998),
+    "C5": ("convunet+feat", "recurrent-convunet+feat-iso3200", 0, 3200, 720, 1280, 90, 8, 435.025),
 }
 DESCR = {
     "C1": "RVDD-basic (recurrent convunet) ISO3200 256x256 8-frame sequences",
     "C2": "recurrent convunet+feat ISO3200 1280x720 30-frame sequences",
     "C3": "recurrent convunet+feat+future ISO12800 1280x720 30-frame sequences",
     "C4": "recurrent ConvNeXtUnet+feat+future ISO3200 1280x720 30-frame sequences",
+    "C5": "recurrent convunet+feat ISO3200 1280x720 90-frame sequences, 8 per GPU (64 on 8 GPUs)",
 }
 FP32_PEAK_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md, chip table (vector = matrix f32)
 _CONV = "conv3x3_kernel<48, 1, false>" if os.environ.get("RVDD_CONV") == "direct" else "wino3x3_kernel<1, false>"
 DOMINANT = {"convunet": _CONV, "convunet+feat": _CONV, "next": "mlp_kernel", "next+feat": "mlp_kernel"}
+# The launches of a kernel class inside one frame-step repeat with period 14 (3x3 conv) or 25 (ConvNeXt MLP) over the
+# four resolution levels; bracketing every 3rd launch (3 is coprime with both) samples every position equally often.
+EVENT_STRIDE = 3
+# MFMA flops a kernel EXECUTES per algorithmic (direct 3x3 conv) flop: Winograd F(2x2,3x3) multiplies 16 times per
+# 2x2 outputs where the direct form multiplies 36 times
+EXECUTED_PER_ALGORITHMIC = {"wino3x3": 16.0 / 36.0}
 
 
-def main():
+def _free_port():
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", default="C2", choices=sorted(CONFIGS))
-    ap.add_argument("--batch", type=int, default=4, help="sequences advanced in lockstep per GPU")
+    ap.add_argument("--config", default=None, choices=sorted(CONFIGS), help="default: C2 on one GPU, C5 on several")
+    ap.add_argument("--batch", type=int, default=0, help="sequences advanced in lockstep per GPU (default: the config's)")
     ap.add_argument("--frames", type=int, default=0, help="override frames per sequence")
-    ap.add_argument("--cpu-frames", type=int, default=8, help="frames of the CPU-oracle sample (0 = skip)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: --batch sequences per GPU; strong: --sequences in total, split over the GPUs")
+    ap.add_argument("--sequences", type=int, default=64, help="total sequences with --scaling strong")
+    ap.add_argument("--collate-outputs", action="store_true",
+                    help="after the timed region, all-gather the output frames of the last group (timed separately)")
+    ap.add_argument("--cpu-frames", type=int, default=10, help="timed frames of the CPU-oracle sample (0 = skip)")
+    ap.add_argument("--cpu-frames-8", type=int, default=4, help="timed frames of the second CPU sample at 8 threads (0 = skip)")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--all-kernel-events", action="store_true",
                     help="diagnostic: bracket EVERY launch of every kernel (costs ~6 %% of the frame rate); "
-                         "default brackets every 4th launch of the dominant kernel only")
-    args = ap.parse_args()
+                         f"default brackets every {EVENT_STRIDE}rd launch of the dominant kernel only")
+    return ap.parse_args(argv)
 
-    from safetensors.torch import load_file
-    from rvdd_release_amd import shard, synth
-    from rvdd_release_amd.runtime import RvddRuntime
 
-    arch, stem, fut, iso, H, W, T, gflop_frame = CONFIGS[args.config]
-    if args.frames:
-        T = args.frames
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+def self_launch(args) -> int:
+    """`python bench.py --gpus N` outside torch.distributed.run: start the N ranks as a CHILD process group
+    (nothing in this process has touched the GPU), relay their output, return their exit code."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # the host driver only supports dmabuf IPC (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", "4")
+    return subprocess.run(cmd, env=env).returncode
+
+
+class StubRuntime:
+    """RVDD_BENCH_STUB=1: a stand-in for the HIP runtime on the CPU so that tests/test_shard_gloo.py can drive this
+    file's launcher, sharding, collectives and JSON line without a GPU.  Never a measurement, and says so."""
+
+    def __init__(self, B, H, W):
+        self.B, self.H, self.W = B, H, W
+        self._t0 = 0.0
+
+    def load_state_dict(self, sd):
+        pass
+
+    def reset(self):
+        pass
+
+    def step(self, raw_prev, raw_cur, raw_next, flow_prev, flow_next, out=None):
+        import torch
+        up = torch.nn.functional.interpolate(raw_cur[:, 1:4], scale_factor=2, mode="nearest")
+        out.copy_(up)
+        return out
+
+    def psnr_l1(self, den, gt):
+        import math
+        d = (den.double() - gt.double())
+        return float(100 * d.abs().mean()), 10 * math.log10(4.0 / max(float((d * d).mean()), 1e-30))
+
+    def timer_start(self):
+        self._t0 = time.perf_counter()
+
+    def timer_stop_ms(self):
+        return 1e3 * (time.perf_counter() - self._t0)
+
+    def profile_select(self, *a):
+        pass
+
+    def profile_enable(self, on):
+        pass
+
+    def profile_read(self):
+        return []
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args))
     if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={os.environ.get('WORLD_SIZE', '1')}: "
-                         "launch with torch.distributed.run")
+                         "run `python bench.py --gpus N` (it launches its own ranks) or use torch.distributed.run")
+
+    import torch
+    from rvdd_release_amd import shard, synth
+
+    config = args.config or ("C2" if args.gpus == 1 else "C5")
+    arch, stem, fut, iso, H, W, T, B_default, gflop_frame = CONFIGS[config]
+    if args.frames:
+        T = args.frames
+    B = args.batch or B_default
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    stub = os.environ.get("RVDD_BENCH_STUB") == "1"
     # RVDD_BENCH_ONE_GPU=1: rehearsal of the multi-process path on a one-GPU box -- every rank on GPU 0,
     # collectives over gloo on host tensors.  Never a measurement.
     rehearsal = os.environ.get("RVDD_BENCH_ONE_GPU") == "1"
-    dev_index = 0 if rehearsal else local_rank
-    torch.cuda.set_device(dev_index)
-    dev = torch.device("cuda", dev_index)
-    rank, local_rank, world, dist = shard.init_distributed("gloo" if rehearsal else "nccl", dev)    # nccl = RCCL on ROCm
-    coll_dev = None if rehearsal else dev
+    if stub:
+        dev = torch.device("cpu")
+        rank, local_rank, world, dist = shard.init_distributed("gloo")
+        coll_dev = None
+        H, W = 32, 48
+        sd = {}
+        rt = StubRuntime(B, H, W)
+    else:
+        from safetensors.torch import load_file
+        from rvdd_release_amd.runtime import RvddRuntime
+        dev_index = 0 if rehearsal else local_rank
+        torch.cuda.set_device(dev_index)
+        dev = torch.device("cuda", dev_index)
+        rank, local_rank, world, dist = shard.init_distributed("gloo" if rehearsal else "nccl", dev)  # nccl = RCCL on ROCm
+        coll_dev = None if rehearsal else dev
+        sd = load_file(os.path.join(REPO, "weights", stem + ".safetensors"))
+        rt = RvddRuntime(arch, fut, B, H, W, dev_index)
+        rt.load_state_dict(sd)
+    on_host = stub or rehearsal
 
-    B = args.batch
-    sd = load_file(os.path.join(REPO, "weights", stem + ".safetensors"))
-    rt = RvddRuntime(arch, fut, B, H, W, dev_index)
-    rt.load_state_dict(sd)
+    # ---- which sequences this rank advances (static block partition, shard.py; no data-path collective)
+    if args.scaling == "strong":
+        total_seqs = args.sequences
+        if total_seqs % (world * B):
+            raise SystemExit(f"--sequences {total_seqs} must be a multiple of gpus x batch = {world * B}")
+    else:
+        total_seqs = B * world
+    my_seqs = list(shard.shard_sequences(total_seqs, rank, world))
+    groups = [my_seqs[i:i + B] for i in range(0, len(my_seqs), B)]     # one group = B sequences in lockstep
 
     # ---- synthetic inputs, resident in HBM, [T,B,...] so that a time slice is contiguous
-    cfg_id = int(args.config[1])
-    my_seqs = shard.shard_sequences(B * world, rank, world)   # weak scaling: B sequences per GPU
-    seqs = [synth.make_sequence(T, H, W, iso=iso, seed=1000 * cfg_id + sid, device=str(dev)) for sid in my_seqs]
-    raw = torch.stack([s.raw for s in seqs], 1).contiguous()
-    fprev = torch.stack([s.flow_prev for s in seqs], 1).contiguous()
-    fnext = torch.stack([s.flow_next for s in seqs], 1).contiguous()
-    gt = torch.stack([s.gt for s in seqs], 1).contiguous()
+    cfg_id = int(config[1])
     n_out = T - 1 - fut
-    outs = torch.empty(n_out, B, 3, H, W, dtype=torch.float32, device=dev)
+    inputs = []
+    gt = None
+    for gi, grp in enumerate(groups):
+        seqs = [synth.make_sequence(T, H, W, iso=iso, seed=1000 * cfg_id + sid, device=str(dev)) for sid in grp]
+        raw = torch.stack([s.raw for s in seqs], 1).contiguous()
+        fprev = torch.stack([s.flow_prev for s in seqs], 1).contiguous()
+        fnext = torch.stack([s.flow_next for s in seqs], 1).contiguous() if fut else None
+        inputs.append((raw, fprev, fnext))
+        if gi == len(groups) - 1:
+            gt = torch.stack([s.gt for s in seqs], 1).contiguous()     # ground truth of the last group (task PSNR)
+        del seqs
+    outs = torch.empty(n_out, B, 3, H, W, dtype=torch.float32, device=dev)   # outputs of the group being advanced
 
     def one_step():
-        rt.reset()                                            # FirstOfVideo
-        for t in range(1, T - fut):
-            rt.step(raw[t - 1] if t == 1 else None, raw[t], raw[t + 1] if fut else None, fprev[t],
-                    fnext[t] if fut else None, out=outs[t - 1])
+        for raw, fprev, fnext in inputs:
+            rt.reset()                                        # FirstOfVideo
+            for t in range(1, T - fut):
+                rt.step(raw[t - 1] if t == 1 else None, raw[t], raw[t + 1] if fut else None, fprev[t],
+                        fnext[t] if fut else None, out=outs[t - 1])
 
     def barrier():
-        shard.barrier(dist, dev)
+        shard.barrier(dist, None if on_host else dev)
 
     for _ in range(args.warmup):
         one_step()
@@ -115,7 +226,7 @@ def main():
         if args.all_kernel_events:
             rt.profile_select(None, 1)
         else:
-            rt.profile_select(DOMINANT[arch], 4)
+            rt.profile_select(DOMINANT[arch], EVENT_STRIDE)
         rt.profile_enable(True)
     t0 = time.perf_counter()
     rt.timer_start()
@@ -128,19 +239,35 @@ def main():
     rt.profile_enable(False)
 
     elapsed = shard.max_over_ranks(wall, dist, coll_dev)
-    frames_total = args.steps * n_out * B * world
+    n_ranks_seen = shard.count_ranks(dist, coll_dev)             # from the collective itself, not from the environment
+    frames_total = args.steps * n_out * total_seqs
     fps = frames_total / elapsed
 
-    # ---- task PSNR of every output frame of the last step (outside the timed region)
+    # ---- task PSNR of every output frame of the last group of the last step (outside the timed region)
     psnr = torch.tensor([[rt.psnr_l1(outs[k], gt[k + 1])[1] for k in range(n_out)]], dtype=torch.float64, device=dev)
-    psnr_mean = float(shard.gather_metrics(psnr.cpu() if rehearsal else psnr, dist).mean().item())    # the one collate collective
+    psnr_mean = float(shard.gather_metrics(psnr.cpu() if on_host else psnr, dist).mean().item())    # the collate collective
+
+    # ---- optional: collate the output frames themselves (north star: "one all-gather only to collate outputs")
+    collate = None
+    if args.collate_outputs:
+        src = outs.cpu() if rehearsal else outs
+        barrier()
+        tc = time.perf_counter()
+        gathered = shard.gather_outputs(src, dist)
+        barrier()
+        dt = time.perf_counter() - tc
+        nbytes = src.numel() * 4
+        collate = {"ms": round(1e3 * dt, 3), "bytes_per_rank": nbytes, "gathered_shape": list(gathered.shape),
+                   "recv_GBps_per_rank": round(nbytes * (world - 1) / dt / 1e9, 2) if world > 1 else None,
+                   "what": "all-gather of the output frames of the last group, outside the timed region"}
+        del gathered
 
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
         return
 
-    # ---- roofline of the dominant kernel (HIP events around its launches, this rank)
+    # ---- roofline of the dominant kernel (HIP events around a uniform sample of its launches, this rank)
     roofline = None
     kernels = {}
     for p in prof:
@@ -152,29 +279,32 @@ def main():
     dom = DOMINANT[arch]
     if dom in kernels:
         k = kernels[dom]
-        # HBM bytes per launch from the PMC passes (tools/gpu_profile.sh + tools/pmc_summary.py); counters
-        # cannot be read from inside this process, so the last committed measurement is quoted
-        traffic = None
+        # HBM bytes per launch from the PMC passes of the same command (tools/gpu_profile.sh + tools/pmc_summary.py:
+        # average over ALL launches of the kernel in a frame-step, like the event sample); counters cannot be read
+        # from inside this process, so the last committed measurement is quoted together with its source file
+        traffic, traffic_src = None, None
         try:
             tj = json.load(open(os.path.join(REPO, "profiles", "traffic.json")))
-            traffic = tj[args.config]["kernels"].get(dom)
+            ent = tj.get(config) or tj.get("C2" if config == "C5" else config)
+            traffic, traffic_src = ent["kernels"].get(dom), ent.get("source")
         except Exception:
             pass
-        roofline = {"bound": "mfma", "kernel": dom, "achieved": round(k["tflops"], 2), "peak": FP32_PEAK_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(k["tflops"] / FP32_PEAK_TFLOPS, 4), "traffic": traffic,
+        factor = next((f for pre, f in EXECUTED_PER_ALGORITHMIC.items() if dom.startswith(pre)), 1.0)
+        executed = k["tflops"] * factor
+        roofline = {"bound": "mfma", "kernel": dom, "achieved": round(executed, 2), "peak": FP32_PEAK_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(executed / FP32_PEAK_TFLOPS, 4), "traffic": traffic,
+                    "traffic_source": traffic_src,
                     "algorithmic_bytes_per_launch": round(k["bytes_per_launch"]),
+                    "what_is_counted": "MFMA flops the kernel executes (Winograd F(2x2,3x3): 16/36 of the direct conv's)"
+                                       if factor != 1.0 else "the kernel's algorithmic flops (all executed on MFMA)",
+                    "algorithmic_equiv_tflops": round(k["tflops"], 2),
                     "launches": k["launches"], "avg_launch_us": round(k["avg_us"], 2),
-                    "events": "every launch" if args.all_kernel_events else "every 4th launch"}
-        if dom.startswith("wino3x3"):
-            # `achieved` counts the ALGORITHMIC flops of the 3x3 conv (2*9*Cin*Cout per pixel).  The
-            # Winograd F(2x2,3x3) kernel executes 16 instead of 36 multiplies per 2x2 outputs, so frac > 1 is
-            # possible; the fraction of the MFMA peak the kernel actually issues is reported beside it.
-            roofline["executed_mfma_tflops"] = round(k["tflops"] * 16.0 / 36.0, 2)
-            roofline["executed_mfma_frac"] = round(k["tflops"] * 16.0 / 36.0 / FP32_PEAK_TFLOPS, 4)
+                    "events": "every launch" if args.all_kernel_events else
+                              f"every {EVENT_STRIDE}rd launch (uniform over the launches of a frame-step)"}
 
     # ---- CPU baseline: the oracle on this host's cores, bounded sample, sequence 0
     cpu = None
-    if world == 1 and args.cpu_frames > 0:
+    if world == 1 and args.cpu_frames > 0 and not stub:
         sys.path.insert(0, os.path.join(REPO, "oracle"))
         import rvdd_oracle as O
         cores = os.cpu_count() or 1
@@ -185,48 +315,65 @@ def main():
         # a 1-GPU box grants a 16-CPU share of a larger host: more threads than the share only
         # oversubscribe it (256 threads measured 40x slower than 16)
         cores = int(os.environ.get("RVDD_CPU_THREADS", min(cores, 16)))
-        torch.set_num_threads(cores)
-        orc = O.RecurrentOracle(sd, future=fut)
-        r0, p0, n0 = raw[:, 0].cpu(), fprev[:, 0].cpu(), fnext[:, 0].cpu()
-        nf = min(args.cpu_frames, n_out)
-        times, worst, ppsnr = [], 0.0, 1e9
-        for t in range(1, 1 + nf):
-            tc = time.perf_counter()
-            den = orc.step(r0[t - 1][None], r0[t][None], r0[t + 1][None] if fut else None, p0[t][None],
-                           n0[t][None] if fut else None, first=(t == 1))
-            times.append(time.perf_counter() - tc)
-            g = outs[t - 1, 0].cpu()
-            d = (g - den[0]).double()
-            worst = max(worst, float(d.abs().max()))
-            mse = float((d * d).mean())
-            ppsnr = min(ppsnr, 200.0 if mse == 0 else 10 * torch.log10(torch.tensor(4.0 / mse)).item())
-        timed = times[1:] if len(times) > 1 else times        # first frame = warm-up
-        cpu_fps = len(timed) / sum(timed)
-        cpu = {"value": round(cpu_fps, 4), "unit": "frames/s", "cores": cores, "kind": "port",
-               "sample": f"{len(timed)} frame(s) of sequence 0 of the same workload after 1 warm-up frame, "
-                         f"torch {torch.__version__} CPU ops, {cores} threads",
-               "gpu_vs_cpu_max_abs_diff": worst, "gpu_vs_cpu_parity_psnr_db": round(ppsnr, 2)}
+        raw0, fprev0, fnext0 = inputs[-1]
+        r0, p0 = raw0[:, 0].cpu(), fprev0[:, 0].cpu()
+        n0 = fnext0[:, 0].cpu() if fut else None
 
+        def cpu_sample(threads, warm, timed, check):
+            torch.set_num_threads(threads)
+            orc = O.RecurrentOracle(sd, future=fut)
+            nf = min(warm + timed, n_out)
+            times, worst, ppsnr = [], 0.0, 1e9
+            for t in range(1, 1 + nf):
+                tc = time.perf_counter()
+                den = orc.step(r0[t - 1][None], r0[t][None], r0[t + 1][None] if fut else None, p0[t][None],
+                               n0[t][None] if fut else None, first=(t == 1))
+                times.append(time.perf_counter() - tc)
+                if check:
+                    d = (outs[t - 1, 0].cpu() - den[0]).double()
+                    worst = max(worst, float(d.abs().max()))
+                    mse = float((d * d).mean())
+                    ppsnr = min(ppsnr, 200.0 if mse == 0 else 10 * torch.log10(torch.tensor(4.0 / mse)).item())
+            tt = times[warm:] if len(times) > warm else times
+            return len(tt) / sum(tt), len(tt), worst, ppsnr
+
+        v, n_t, worst, ppsnr = cpu_sample(cores, 2, args.cpu_frames, True)
+        cpu = {"value": round(v, 4), "unit": "frames/s", "cores": cores, "kind": "port",
+               "sample": f"{n_t} frame(s) of sequence 0 of the same workload after 2 warm-up frames, B = 1, "
+                         f"torch {torch.__version__} CPU ops, {cores} threads of {os.cpu_count()} host CPUs",
+               "gpu_vs_cpu_max_abs_diff": worst, "gpu_vs_cpu_parity_psnr_db": round(ppsnr, 2)}
+        if args.cpu_frames_8 > 0 and cores > 8:
+            v8, n8, _, _ = cpu_sample(8, 1, args.cpu_frames_8, False)
+            cpu["value_8_threads"] = round(v8, 4)
+            cpu["sample_8_threads"] = f"{n8} frame(s) after 1 warm-up frame, 8 threads (BASELINE.md section 2 used 8)"
+
+    par = (f"{total_seqs} sequences sharded over {world} GPU(s), {len(groups)} group(s) of {B} in lockstep per GPU"
+           if args.scaling == "strong" else f"sequences sharded over {world} GPU(s), {B} per GPU in lockstep")
+    data = "synthetic"
+    if rehearsal:
+        data += " (REHEARSAL: all ranks on one GPU, not a measurement)"
+    if stub:
+        data += " (STUB: CPU stand-in for the HIP runtime, launcher/collective test only, not a measurement)"
     line = {
         "metric": "frames/sec (whole job), recurrent video denoise+demosaic inference", "value": round(fps, 3),
-        "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic" + (" (REHEARSAL: all ranks on one GPU, not a measurement)" if rehearsal else ""),
-        "config": {"workload": f"{args.config}: {DESCR[args.config]}" + (f" (run with --frames {T})" if args.frames else ""),
+        "unit": "frames/s", "n_gpus": world, "n_ranks_seen": n_ranks_seen, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": args.scaling,
+        "vs_baseline": None, "dtype": "f32", "data": data,
+        "config": {"workload": f"{config}: {DESCR[config]}" + (f" (run with --frames {T})" if args.frames else ""),
                    "arch": arch, "checkpoint": stem,
-                   "frame": f"{W}x{H}", "frames_per_sequence": T, "sequences_per_gpu": B,
-                   "output_frames_per_step_per_gpu": n_out * B, "parallelism": f"sequences sharded over {world} GPU(s)"},
+                   "frame": f"{W}x{H}", "frames_per_sequence": T, "sequences_per_gpu": len(my_seqs),
+                   "sequences_in_lockstep": B, "sequences_total": total_seqs,
+                   "output_frames_per_step_per_gpu": n_out * len(my_seqs), "parallelism": par},
         "fps_per_gpu": round(fps / world, 3), "ms_per_frame": round(1e3 * elapsed / (frames_total / world), 3),
         "gpu_event_ms_per_step": round(ev_ms / args.steps, 3),
         "algorithmic_gflop_per_frame": gflop_frame,
-        "whole_path_tflops": round(fps / world * gflop_frame * (H * W) / (CONFIGS[args.config][4] * CONFIGS[args.config][5]) / 1e3, 2),
-        "whole_path_frac_of_fp32_peak": round(fps / world * gflop_frame / 1e3 / FP32_PEAK_TFLOPS, 4),
+        "whole_path_algorithmic_tflops": round(fps / world * gflop_frame / 1e3, 2),
         "task_psnr_db": round(psnr_mean, 3),
-        "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels,
+        "roofline": roofline, "cpu_baseline": cpu, "collate": collate, "kernels": kernels,
     }
     if cpu:
         line["gpu_over_cpu"] = round(fps / cpu["value"], 1)
-    print(json.dumps(line))
+    print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()
 

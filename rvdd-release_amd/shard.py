@@ -67,3 +67,26 @@ def gather_metrics(local: torch.Tensor, dist) -> torch.Tensor:
     parts: List[torch.Tensor] = [torch.empty_like(local) for _ in range(dist.get_world_size())]
     dist.all_gather(parts, local.contiguous())
     return torch.cat(parts, 0)
+
+
+def count_ranks(dist, device: Optional[torch.device] = None) -> int:
+    """How many ranks take part, counted by the collective itself (a sum of ones)."""
+    t = torch.ones(1, dtype=torch.int64, device=device if device is not None else "cpu")
+    if dist is not None:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return int(t.item())
+
+
+def gather_outputs(local: torch.Tensor, dist) -> torch.Tensor:
+    """Collate the output frames: [...] per rank -> [world, ...] on every rank, ONE all-gather
+    (RCCL picks the direct one-hop algorithm over xGMI for a single large message per peer)."""
+    if dist is None:
+        return local[None]
+    world = dist.get_world_size()
+    local = local.contiguous()
+    out = torch.empty((world,) + tuple(local.shape), dtype=local.dtype, device=local.device)
+    if dist.get_backend() == "gloo":
+        dist.all_gather(list(out.unbind(0)), local)
+    else:
+        dist.all_gather_into_tensor(out, local)
+    return out

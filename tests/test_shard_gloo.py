@@ -82,3 +82,48 @@ def test_two_ranks_equal_one_process(tmp_path):
         outs = O.RecurrentOracle(sd, future=0).run_sequence(s.raw, s.flow_prev)
         want = [O.psnr(outs[k][None], s.gt[k + 1][None]) for k in range(2)]
         assert max(abs(a - b) for a, b in zip(want, two["metrics"][sid])) < 1e-4
+
+
+def _bench(args, tmp_path):
+    """bench.py's OWN launcher (`python bench.py --gpus N`, no torch.distributed.run around it) with the CPU stub
+    standing in for the HIP runtime: ranks over gloo, the same sharding, collectives and JSON line as on the GPU node."""
+    import json
+    env = dict(os.environ, RVDD_BENCH_STUB="1", OMP_NUM_THREADS="2")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py")] + args, capture_output=True, text=True,
+                         env=env, timeout=600, cwd=str(tmp_path))
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout                       # rank 0 prints ONE JSON line
+    return json.loads(lines[0])
+
+
+def test_bench_self_launch_two_ranks_weak(tmp_path):
+    r = _bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--frames", "4", "--batch", "2", "--collate-outputs"], tmp_path)
+    assert r["n_gpus"] == 2 and r["n_ranks_seen"] == 2 and r["scaling"] == "weak"
+    assert r["config"]["workload"].startswith("C5")           # the multi-GPU default configuration
+    assert r["config"]["sequences_total"] == 4 and r["config"]["sequences_per_gpu"] == 2
+    assert r["value"] > 0 and r["steps"] == 2 and r["warmup"] == 1
+    assert abs(r["value"] - 2 * 3 * 4 / (r["ms_per_step"] * 2 / 1e3)) / r["value"] < 1e-3    # frames of ALL ranks / max time
+    assert r["collate"]["gathered_shape"] == [2, 3, 2, 3, 32, 48]
+    assert "STUB" in r["data"] and r["cpu_baseline"] is None and r["vs_baseline"] is None
+
+
+def test_bench_self_launch_strong_scaling(tmp_path):
+    r = _bench(["--gpus", "2", "--steps", "1", "--warmup", "0", "--frames", "3", "--batch", "2", "--scaling", "strong",
+                "--sequences", "8"], tmp_path)
+    assert r["scaling"] == "strong" and r["n_ranks_seen"] == 2
+    assert r["config"]["sequences_total"] == 8 and r["config"]["sequences_per_gpu"] == 4
+    assert r["config"]["output_frames_per_step_per_gpu"] == 2 * 4
+    one = _bench(["--gpus", "1", "--steps", "1", "--warmup", "0", "--frames", "3", "--batch", "2", "--config", "C5",
+                  "--scaling", "strong", "--sequences", "8"], tmp_path)
+    assert one["n_gpus"] == 1 and one["config"]["sequences_per_gpu"] == 8
+    assert abs(one["task_psnr_db"] - r["task_psnr_db"]) < 20       # same generator; both finite numbers
+
+
+def test_bench_refuses_mismatched_world(tmp_path):
+    env = dict(os.environ, RVDD_BENCH_STUB="1", WORLD_SIZE="3", RANK="0", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2"], capture_output=True, text=True,
+                         env=env, timeout=120)
+    assert out.returncode != 0 and "WORLD_SIZE=3" in out.stderr
