@@ -23,8 +23,6 @@
 //    next chunk / next unit is in flight while the current one is multiplied.
 #include "rvdd_internal.h"
 
-#include <cstdlib>
-#include <cstring>
 #include <type_traits>
 
 namespace {
@@ -35,8 +33,6 @@ constexpr int u_floats(int nj) { return 16 * nj * 3 * 256; }
 constexpr int U_FLOATS = u_floats(3);
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void lds_void;
-typedef __attribute__((address_space(3))) int lds_int;
-typedef __attribute__((address_space(3))) f32x4 lds_f32x4;
 
 __device__ __forceinline__ f32x4 bload(__amdgpu_buffer_rsrc_t r, unsigned off) {
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
@@ -343,412 +339,23 @@ __device__ __forceinline__ void wino_body(const ConvArgs& a) {
     }
 }
 
-// =====================================================================================================
-// Two waves per SIMD (8 waves, 512 threads per workgroup): the organisation the production launches use.
-//
-// Measured on gfx950 (tools/mfma_valu_bench.hip, profiles/r02_mfma_valu_microbench.log): the f32 MFMA and the
-// f32 VALU share the SIMD's lanes, so their cycles ADD; with ONE wave per SIMD a vector instruction in the
-// MFMA stream costs its 4-cycle issue (v_pk_add_f32 5.5) plus ~28 cycles for every MFMA -> VALU switch, with
-// TWO waves per SIMD the same instruction costs its 2 lane cycles (pk 4.7) and one wave's transforms, LDS and
-// memory waits sit under the other wave's MFMAs.  Two waves need <= 256 registers each, i.e. half the
-// accumulators: a PAIR of waves shares one row of 16 tiles, wave HF = 0 owns the Winograd positions of rows
-// 0-1 (8 positions x 48 couts = 96 accumulator registers), wave HF = 1 rows 2-3.  Each half needs only three
-// of the four patch rows (B^T d: rows 0,1 come from d0,d1,d2; rows 2,3 from d1,d2,d3).  The output transform
-// A^T M A is linear in M, so each wave applies it to its own rows and the two partial 2x2 outputs are summed
-// through LDS: wave 0 hands over its share of the bottom output row and finishes the top one, wave 1 the
-// reverse (two 16-B values per lane and cout block, 1 KiB slots, pairwise ready/consumed counters in LDS --
-// no workgroup barrier, the four pairs of a workgroup drift freely against each other, which is what keeps
-// one wave's epilogue under another's MFMAs).
-constexpr int X_FLOATS = 8 * 256;          // exchange slots: one KiB per wave
-constexpr int X_FLAGS = 16;                // per wave: ready, consumed
-
-__device__ __forceinline__ f32x4 nadd4(f32x4 a, f32x4 b) {      // -a - b
-    f32x2 lo, hi;
-    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[1,1] neg_hi:[1,1]" : "=v"(lo) : "v"(f32x2{a[0], a[1]}), "v"(f32x2{b[0], b[1]}));
-    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[1,1] neg_hi:[1,1]" : "=v"(hi) : "v"(f32x2{a[2], a[3]}), "v"(f32x2{b[2], b[3]}));
-    return f32x4{lo[0], lo[1], hi[0], hi[1]};
-}
-
-template <int EPI, bool ACC_IN, int NJ, int HF>
-__device__ __forceinline__ void wino2_half(const ConvArgs& a, float* U, lds_f32x4* XCH, lds_int* FLG) {
-    constexpr int CIN = 16 * NJ;
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int pair = wave >> 1;
-    const int lr = lane & 15;
-    const int g = lane >> 4;
-
-    const int units_per_img = a.tiles_x * a.tiles_y;
-    const unsigned map_bytes = (unsigned)(a.H * a.W * kF * 4);
-    const unsigned out_bytes = (unsigned)(a.Hout * a.Wout * kF * 4);
-    const int row_bytes = a.W * CIN * 4;
-
-    auto locate = [&](int unit, UnitPos& u) {
-        u.b = __builtin_amdgcn_readfirstlane(unit / units_per_img);
-        const int rr = unit - u.b * units_per_img;
-        const int uy = __builtin_amdgcn_readfirstlane(rr / a.tiles_x);
-        const int ux = rr - uy * a.tiles_x;
-        u.ty = uy * 4 + pair;
-        u.tx = ux * 16 + lr;
-    };
-    // the three patch rows this half needs (HF = 0: rows 0..2, HF = 1: rows 1..3), one descriptor per row
-    auto load_patch = [&](f32x4 (&p)[12], const UnitPos& u, int j) {
-        const float* img = a.in + (size_t)u.b * a.H * a.W * CIN;
-        const int y0 = 2 * u.ty - 1 + HF, x0 = 2 * u.tx - 1;
-        const unsigned v1 = (unsigned)((x0 + 1) * (CIN * 4) + (16 * j + 4 * g) * 4);
-        const unsigned v0 = x0 >= 0 ? v1 - CIN * 4 : 0xffffffffu;
-#pragma unroll
-        for (int dy = 0; dy < 3; ++dy) {
-            const int y = y0 + dy;
-            const bool row_ok = (unsigned)y < (unsigned)a.H;
-            __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(
-                (void*)(img + (ptrdiff_t)y * a.W * CIN), 0, row_ok ? row_bytes : 0, 0x00020000);
-            p[dy * 4 + 0] = bload(r, v0);
-            p[dy * 4 + 1] = bload(r, v1);
-            p[dy * 4 + 2] = bload(r, v1 + CIN * 4);
-            p[dy * 4 + 3] = bload(r, v1 + 2 * CIN * 4);
-        }
-    };
-    // B^T d B restricted to this half's two rows, in place: p[0..7] = transformed rows, in 4 slices
-    //   slices 0,1: column pass for x = 2 sl, 2 sl + 1;  slices 2,3: row pass for row sl - 2
-    auto transform_slice = [&](f32x4 (&p)[12], int sl) {
-        if (sl < 2) {
-#pragma unroll
-            for (int x = 2 * sl; x < 2 * sl + 2; ++x) {
-                const f32x4 e0 = p[x], e1 = p[4 + x], e2 = p[8 + x];
-                if constexpr (HF == 0) {
-                    p[x] = sub4(e0, e2);          // d0 - d2
-                    p[4 + x] = e1 + e2;           // d1 + d2
-                } else {
-                    p[x] = sub4(e1, e0);          // d2 - d1
-                    p[4 + x] = sub4(e0, e2);      // d1 - d3
-                }
-            }
-        } else {
-            const int y = sl - 2;
-            const f32x4 t0 = p[4 * y], t1 = p[4 * y + 1], t2 = p[4 * y + 2], t3 = p[4 * y + 3];
-            p[4 * y] = sub4(t0, t2);
-            p[4 * y + 1] = t1 + t2;
-            p[4 * y + 2] = sub4(t2, t1);
-            p[4 * y + 3] = sub4(t1, t3);
-        }
-    };
-
-    // This half's 8 positions of the bank span 72 KiB, more than the 64 KiB a ds_read offset field reaches: two
-    // opaque index registers (positions 0-6, position 7) keep every fragment address "register + immediate";
-    // left to itself hipcc materialises 72 address registers ahead of the loop and spills them.
-    int ia = lane * 4 + HF * (8 * NJ * 3 * 256);
-    int ib = ia + 7 * NJ * 3 * 256;
-    asm volatile("" : "+v"(ia));
-    asm volatile("" : "+v"(ib));
-    f32x4 pb[2][12];
-    f32x4 acc[8][3];
-    auto ldsA = [&](int j, int k, int m) {
-        return k < 7 ? *reinterpret_cast<const f32x4*>(U + ia + ((k * NJ + j) * 3 + m) * 256)
-                     : *reinterpret_cast<const f32x4*>(U + ib + (j * 3 + m) * 256);
-    };
-
-    // position k of this half = global position 8 HF + k.  Seeds (see wino_body): bias in position (1,1);
-    // the two-pass partial sums in the corners: M00 = P00, M03 = -P01 (this is HF 0), M30 = -P10, M33 = P11 (HF 1).
-    auto stage = [&](auto JC, auto XC, bool first, const UnitPos& ld_u, int ld_j) {
-        constexpr int J = decltype(JC)::value;
-        constexpr int X = decltype(XC)::value;
-        constexpr int Y = 1 - X;
-        load_patch(pb[Y], ld_u, ld_j);
-        f32x4 wq[2][3];
-        constexpr int ORD0[8] = {0, 1, 2, 3, 4, 6, 7, 5};     // HF 0, bias seed in k = 5
-        constexpr int ORD0A[8] = {1, 2, 4, 5, 6, 7, 0, 3};    // HF 0, partial-sum seeds in k = 0, 3
-        constexpr int ORD1[8] = {0, 1, 2, 3, 4, 5, 6, 7};     // HF 1, nothing seeded
-        constexpr int ORD1A[8] = {0, 1, 2, 3, 5, 6, 4, 7};    // HF 1, partial-sum seeds in k = 4 (pos 12), 7 (pos 15)
-        auto ord = [&](int st) { return HF == 0 ? (ACC_IN ? ORD0A[st] : ORD0[st]) : (ACC_IN ? ORD1A[st] : ORD1[st]); };
-#pragma unroll
-        for (int m = 0; m < 3; ++m) wq[0][m] = ldsA(J, ord(0), m);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int st = 0; st < 8; ++st) {
-            const int k = ord(st);
-            const bool seeded = ACC_IN ? (HF == 0 ? (k == 0 || k == 3) : (k == 4 || k == 7)) : (HF == 0 && k == 5);
-            const bool negated = ACC_IN && (HF == 0 ? k == 3 : k == 4);
-            if (st + 1 < 8) {
-#pragma unroll
-                for (int m = 0; m < 3; ++m) wq[(st + 1) & 1][m] = ldsA(J, ord(st + 1), m);
-            }
-            if (st >= 4) transform_slice(pb[Y], st - 4);
-            if (first && negated) {
-#pragma unroll
-                for (int m = 0; m < 3; ++m) acc[k][m] = -acc[k][m];
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int m = 0; m < 3; ++m) {
-                    const f32x4 c = (first && i == 0 && !seeded) ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[k][m];
-                    acc[k][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[st & 1][m][i], pb[X][k][i], c, 0, 0, 0);
-                }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    };
-
-    // ---- pairwise exchange through LDS.  LDS executes one wave's DS instructions in order and is one unit per
-    // CU, so "value, then counter" needs no wait in between; the compiler is kept from reordering by the asm
-    // barriers.  Counters only grow (round number), every spin is bounded.
-    int rnd = 0;
-    volatile lds_int* myflag = FLG + 2 * wave;
-    volatile lds_int* peerflag = FLG + 2 * (wave ^ 1);
-    lds_f32x4* myslot = XCH + wave * 64 + lane;
-    const lds_f32x4* peerslot = XCH + (wave ^ 1) * 64 + lane;
-    auto spin_until = [&](volatile lds_int* f, int want) {
-#pragma unroll 1
-        for (int it = 0; it < (1 << 22); ++it) {
-            if (__builtin_amdgcn_readfirstlane(*f) >= want) break;
-            __builtin_amdgcn_s_sleep(1);
-        }
-    };
-    auto exchange = [&](f32x4 mine) -> f32x4 {
-        ++rnd;
-        spin_until(myflag + 1, rnd - 1);            // the partner has consumed my previous value
-        asm volatile("" ::: "memory");
-        *myslot = mine;
-        asm volatile("" ::: "memory");
-        myflag[0] = rnd;                            // ready
-        spin_until(peerflag, rnd);
-        asm volatile("" ::: "memory");
-        const f32x4 v = *peerslot;
-        asm volatile("" ::: "memory");
-        peerflag[1] = rnd;                          // consumed (LDS runs this after the read above)
-        return v;
-    };
-
-    int unit = blockIdx.x;
-    UnitPos cur, nxt;
-    locate(unit, cur);
-    load_patch(pb[0], cur, 0);
-#pragma unroll
-    for (int sl = 0; sl < 4; ++sl) transform_slice(pb[0], sl);
-
-    using I0 = std::integral_constant<int, 0>;
-    using I1 = std::integral_constant<int, 1>;
-    using I2 = std::integral_constant<int, 2>;
-
-    auto run_unit = [&](auto PC) {
-        constexpr int P = decltype(PC)::value;
-        using XP = std::integral_constant<int, P>;
-        using XQ = std::integral_constant<int, 1 - P>;
-        locate(unit + gridDim.x, nxt);
-        if (unit + (int)gridDim.x >= a.ntiles) nxt.ty = 1 << 20;
-        if constexpr (ACC_IN) {
-            __amdgpu_buffer_rsrc_t pr = __builtin_amdgcn_make_buffer_rsrc(
-                (void*)(a.acc_in + (size_t)cur.b * a.H * a.W * kF), 0, map_bytes, 0x00020000);
-            constexpr int slot[2] = {HF == 0 ? 0 : 4, HF == 0 ? 3 : 7};      // this half's two corners
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const int yy = 2 * cur.ty + HF, xx = 2 * cur.tx + q;
-                const unsigned o = (yy < a.H && xx < a.W) ? (unsigned)(((yy * a.W + xx) * kF + 4 * g) * 4) : 0x80000000u;
-#pragma unroll
-                for (int m = 0; m < 3; ++m) acc[slot[q]][m] = bload(pr, o + 64 * m);
-            }
-        } else if constexpr (HF == 0) {
-#pragma unroll
-            for (int m = 0; m < 3; ++m) acc[5][m] = *reinterpret_cast<const f32x4*>(a.bias + 16 * m + 4 * g);
-        }
-        if constexpr (NJ == 3) {
-            stage(I0{}, XP{}, true, cur, 1);
-            stage(I1{}, XQ{}, false, cur, 2);
-            stage(I2{}, XP{}, false, nxt, 0);
-        } else {
-            stage(I0{}, XP{}, true, nxt, 0);
-        }
-
-        // ---- this half's share of A^T M A, exchange, epilogue of its output row (HF 0: top, HF 1: bottom)
-        __amdgpu_buffer_rsrc_t orr = __builtin_amdgcn_make_buffer_rsrc(
-            (void*)(a.out + (size_t)cur.b * a.Hout * a.Wout * kF), 0, out_bytes, 0x00020000);
-        __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(
-            (void*)((EPI == EPI_RELU_ADD2 ? a.res1 : a.out) + (size_t)cur.b * a.H * a.W * kF), 0, map_bytes, 0x00020000);
-        __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc(
-            (void*)((EPI == EPI_RELU_ADD2 ? a.res2 : a.out) + (size_t)cur.b * a.H * a.W * kF), 0, map_bytes, 0x00020000);
-        const int yy = 2 * cur.ty + HF, ox = 2 * cur.tx;
-        unsigned po[2], so[2];
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int xx = ox + q;
-            const bool ok = yy < a.H && xx < a.W;
-            po[q] = ok ? (unsigned)(((yy * a.W + xx) * kF + 4 * g) * 4) : 0x80000000u;
-            so[q] = ok ? (unsigned)((((yy + a.oy) * a.Wout + xx + a.ox) * kF + 4 * g) * 4) : 0x80000000u;
-        }
-        float o3[2][3];
-        if constexpr (EPI == EPI_RELU_OUT3) {
-#pragma unroll
-            for (int q = 0; q < 2; ++q) o3[q][0] = o3[q][1] = o3[q][2] = 0.f;
-        }
-#pragma unroll
-        for (int m = 0; m < 3; ++m) {
-            f32x4 ra[2], rb[2];
-            if constexpr (EPI == EPI_RELU_ADD2) {
-#pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    ra[q] = bload(r1, po[q] + 64 * m);
-                    rb[q] = bload(r2, po[q] + 64 * m);
-                }
-            }
-            // partial rows of A^T M: HF 0: s0 += M0 + M1, s1 += M1;   HF 1: s0 += M2, s1 += -M2 - M3
-            f32x4 yp[4];      // q = 2*row + col, this half's contribution
-            if constexpr (HF == 0) {
-                f32x4 t0[4];
-#pragma unroll
-                for (int x = 0; x < 4; ++x) t0[x] = acc[x][m] + acc[4 + x][m];
-                yp[0] = (t0[0] + t0[1]) + t0[2];
-                yp[1] = sub4(sub4(t0[1], t0[2]), t0[3]);
-                yp[2] = (acc[4][m] + acc[5][m]) + acc[6][m];
-                yp[3] = sub4(sub4(acc[5][m], acc[6][m]), acc[7][m]);
-            } else {
-                f32x4 w[4];
-#pragma unroll
-                for (int x = 0; x < 4; ++x) w[x] = acc[x][m] + acc[4 + x][m];
-                yp[0] = (acc[0][m] + acc[1][m]) + acc[2][m];
-                yp[1] = sub4(sub4(acc[1][m], acc[2][m]), acc[3][m]);
-                yp[2] = sub4(nadd4(w[0], w[1]), w[2]);          // -(w0 + w1 + w2)
-                yp[3] = sub4(w[2] + w[3], w[1]);                // -(w1 - w2 - w3)
-            }
-            f32x4 y[2];       // the two pixels of this half's output row
-            {
-                const f32x4 o0 = exchange(yp[HF == 0 ? 2 : 0]);
-                const f32x4 o1 = exchange(yp[HF == 0 ? 3 : 1]);
-                y[0] = yp[2 * HF] + o0;
-                y[1] = yp[2 * HF + 1] + o1;
-            }
-            if constexpr (EPI == EPI_POOL) {
-                // MaxPool2d(2) of the un-activated conv output: row maxima, the bottom one travels to HF 0
-                f32x4 v;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = fmaxf(y[0][r], y[1][r]);
-                const f32x4 o = exchange(v);
-                if constexpr (HF == 0) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], o[r]);
-                    const bool ok = cur.ty < a.Hout && cur.tx < a.Wout;
-                    bstore(orr, ok ? (unsigned)(((cur.ty * a.Wout + cur.tx) * kF + 16 * m + 4 * g) * 4) : 0x80000000u, v);
-                }
-            } else {
-#pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    f32x4 v = y[q];
-                    if constexpr (EPI == EPI_RELU || EPI == EPI_RELU_ADD2 || EPI == EPI_RELU_OUT3) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
-                    }
-                    if constexpr (EPI == EPI_RELU_ADD2) v = (ra[q] + rb[q]) + v;
-                    bstore(orr, so[q] + 64 * m, v);
-                    if constexpr (EPI == EPI_RELU_OUT3) {
-#pragma unroll
-                        for (int c = 0; c < 3; ++c) {
-                            const f32x4 w = *reinterpret_cast<const f32x4*>(a.w3 + c * kF + 16 * m + 4 * g);
-                            o3[q][c] += (v[0] * w[0] + v[1] * w[1]) + (v[2] * w[2] + v[3] * w[3]);
-                        }
-                    }
-                }
-            }
-        }
-        if constexpr (EPI == EPI_RELU_OUT3) {
-            const size_t hw = (size_t)a.H * a.W;
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                float t[3];
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    float v = o3[q][c];
-                    v += __shfl_xor(v, 16);
-                    v += __shfl_xor(v, 32);
-                    t[c] = v + a.b3[c];
-                }
-                const int xx = ox + q;
-                if (g == 0 && yy < a.H && xx < a.W) {
-                    const size_t pidx = (size_t)yy * a.W + xx;
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) a.out3_nchw[((size_t)cur.b * 3 + c) * hw + pidx] = t[c];
-                    if (a.out3_nhwc4)
-                        reinterpret_cast<f32x4*>(a.out3_nhwc4)[(size_t)cur.b * hw + pidx] = f32x4{t[0], t[1], t[2], 0.f};
-                }
-            }
-        }
-        cur = nxt;
-    };
-
-#pragma unroll 1
-    for (;;) {
-        run_unit(I0{});
-        unit += gridDim.x;
-        if (unit >= a.ntiles) break;
-        run_unit(I1{});
-        unit += gridDim.x;
-        if (unit >= a.ntiles) break;
-    }
-}
-
-template <int EPI, bool ACC_IN, int NJ>
-__device__ __forceinline__ void wino2_body(const ConvArgs& a) {
-    extern __shared__ __attribute__((aligned(16))) float U[];
-    constexpr int UF = u_floats(NJ);
-    lds_f32x4* XCH = (lds_f32x4*)(U + UF);
-    lds_int* FLG = (lds_int*)(U + UF + X_FLOATS);
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    {
-        __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, UF * 4, 0x00020000);
-        for (int k = wave; k < UF / 256; k += 8)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lds_void*)(U + k * 256), 16, (unsigned)(k * 1024 + lane * 16),
-                                                     0, 0, 0);
-    }
-    if (tid < X_FLAGS) FLG[tid] = 0;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (wave & 1) wino2_half<EPI, ACC_IN, NJ, 1>(a, U, XCH, FLG);
-    else wino2_half<EPI, ACC_IN, NJ, 0>(a, U, XCH, FLG);
-}
-
 template <int EPI, bool ACC_IN>
-__global__ __launch_bounds__(512, 2) void wino3x3_kernel(ConvArgs a) {
-    wino2_body<EPI, ACC_IN, 3>(a);
+__global__ __launch_bounds__(256, 1) void wino3x3_kernel(ConvArgs a) {
+    wino_body<EPI, ACC_IN, 3>(a);
 }
 // the first layer: 16-channel (zero-padded 6 / 9) network input
 template <int EPI>
-__global__ __launch_bounds__(512, 2) void wino3x3_c16_kernel(ConvArgs a) {
-    wino2_body<EPI, false, 1>(a);
-}
-// round-1 organisation (one wave per SIMD, 512 registers, all 16 positions in one wave): kept as the A/B
-// reference of the measurement hook (RVDD_WINO=v1)
-template <int EPI, bool ACC_IN>
-__global__ __launch_bounds__(256, 1) void wino3x3_v1_kernel(ConvArgs a) {
-    wino_body<EPI, ACC_IN, 3>(a);
-}
-template <int EPI>
-__global__ __launch_bounds__(256, 1) void wino3x3_c16_v1_kernel(ConvArgs a) {
+__global__ __launch_bounds__(256, 1) void wino3x3_c16_kernel(ConvArgs a) {
     wino_body<EPI, false, 1>(a);
 }
 
-bool use_v1() {
-    static const bool v1 = [] {
-        const char* e = std::getenv("RVDD_WINO");
-        return e && std::strcmp(e, "v1") == 0;
-    }();
-    return v1;
-}
-
-template <int EPI, bool ACC_IN, int NJ, bool V1>
-hipError_t launch_wv(const ConvArgs& a0, hipStream_t s) {
+template <int EPI, bool ACC_IN, int NJ>
+hipError_t launch_w(const ConvArgs& a0, hipStream_t s) {
     static std::atomic<uint64_t> attr_done{0};
     void (*kern)(ConvArgs);
-    if constexpr (V1) {
-        if constexpr (NJ == 3) kern = wino3x3_v1_kernel<EPI, ACC_IN>;
-        else kern = wino3x3_c16_v1_kernel<EPI>;
-    } else {
-        if constexpr (NJ == 3) kern = wino3x3_kernel<EPI, ACC_IN>;
-        else kern = wino3x3_c16_kernel<EPI>;
-    }
-    constexpr size_t U_LDS_BYTES = (size_t)u_floats(NJ) * 4 + (V1 ? 0 : (size_t)X_FLOATS * 4 + X_FLAGS * 4);
-    constexpr int THREADS = V1 ? 256 : 512;
+    if constexpr (NJ == 3) kern = wino3x3_kernel<EPI, ACC_IN>;
+    else kern = wino3x3_c16_kernel<EPI>;
+    constexpr size_t U_LDS_BYTES = (size_t)u_floats(NJ) * 4;
     if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(kern), U_LDS_BYTES, attr_done); e != hipSuccess)
         return e;
     ConvArgs a = a0;
@@ -757,13 +364,8 @@ hipError_t launch_wv(const ConvArgs& a0, hipStream_t s) {
     a.ntiles = a.B * a.tiles_x * a.tiles_y;
     const int cus = current_device_cus();
     const int grid = a.ntiles < cus ? a.ntiles : cus;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(THREADS), U_LDS_BYTES, s, a);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), U_LDS_BYTES, s, a);
     return hipGetLastError();
-}
-
-template <int EPI, bool ACC_IN, int NJ>
-hipError_t launch_w(const ConvArgs& a, hipStream_t s) {
-    return use_v1() ? launch_wv<EPI, ACC_IN, NJ, true>(a, s) : launch_wv<EPI, ACC_IN, NJ, false>(a, s);
 }
 
 }  // namespace

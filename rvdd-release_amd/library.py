@@ -8,6 +8,25 @@ import torch
 from .util._ops import ops_runtime
 
 
+# skimage.color.rgb2gray: Y = 0.2125 R + 0.7154 G + 0.0721 B (ITU-R 709 luma on linear values), integer images
+# scaled to [0,1] first (img_as_float).  scikit-image is not installed here and the reference does not pin it:
+# restated from its published definition, parity with skimage itself unpinned.
+_RGB2GRAY = (0.2125, 0.7154, 0.0721)
+
+
+def _gray(a: torch.Tensor, dev) -> torch.Tensor:
+    """[h,w,c] image -> the [h,w] float32 plane libBridge's tvl1flow receives (library.py:160-168)."""
+    if a.dim() != 3 or a.shape[2] not in (1, 3, 4):
+        raise AssertionError("TVL1_flow: images must be [h,w,c] with c = 1 (gray), 3 (RGB) or 4 (packed raw)")
+    if a.shape[2] == 3:
+        x = a.to(dev, torch.float64)
+        if not a.dtype.is_floating_point:
+            x = x / float(torch.iinfo(a.dtype).max)
+        w = torch.tensor(_RGB2GRAY, dtype=torch.float64, device=dev)
+        return (x @ w).to(torch.float32).contiguous()
+    return a.to(dev, torch.float32).mean(dim=2).contiguous()
+
+
 class CPPbridge(object):
     """Same constructor and method as the reference's ctypes bridge; `libpath` is accepted and
     ignored (the flow runs in librvdd_hip.so on `device`)."""
@@ -17,20 +36,16 @@ class CPPbridge(object):
         self.rt = ops_runtime(device)
 
     def TVL1_flow(self, Im1, Im2):
-        """Im1, Im2: [h,w,c] images (numpy or torch; c = 1 or 4).  4-channel raw frames are reduced
-        by the channel mean as in library.py:165-167; 3-channel input must be gray-converted by the
-        caller (the reference uses skimage.rgb2gray, not reproduced here).
+        """Im1, Im2: [h,w,c] images (numpy or torch; c = 1, 3 or 4).  4-channel raw frames are reduced by the
+        channel mean (library.py:165-167), RGB images by the luminance of skimage.color.rgb2gray
+        (library.py:160-162; see `_gray`).
         Returns the flow as a float32 numpy array [h,w,2] such that Im2(x + flow) ~ Im1(x)."""
         a = Im1 if torch.is_tensor(Im1) else torch.as_tensor(np.asarray(Im1))
         b = Im2 if torch.is_tensor(Im2) else torch.as_tensor(np.asarray(Im2))
         if a.shape != b.shape:
             raise AssertionError("Both images Im1 and Im2 are supposed to share same size")
-        if a.dim() != 3 or a.shape[2] not in (1, 4):
-            raise NotImplementedError("rvdd TVL1_flow: pass [h,w,1] gray or [h,w,4] packed raw images")
         dev = torch.device("cuda", self.device)
-        g1 = a.to(dev, torch.float32).mean(dim=2).contiguous()
-        g2 = b.to(dev, torch.float32).mean(dim=2).contiguous()
-        flow = self.rt.tvl1flow(g1, g2)
+        flow = self.rt.tvl1flow(_gray(a, dev), _gray(b, dev))
         return flow.permute(1, 2, 0).contiguous().cpu().numpy()
 
     def TVL1_flow_batch(self, Im1s, Im2s):
@@ -44,13 +59,8 @@ class CPPbridge(object):
         dev = torch.device("cuda", self.device)
 
         def gray(ims):
-            out = []
-            for im in ims:
-                a = im if torch.is_tensor(im) else torch.as_tensor(np.asarray(im))
-                if a.dim() != 3 or a.shape[2] not in (1, 4):
-                    raise NotImplementedError("rvdd TVL1_flow: pass [h,w,1] gray or [h,w,4] packed raw images")
-                out.append(a.to(dev, torch.float32).mean(dim=2))
-            return torch.stack(out, 0).contiguous()
+            return torch.stack([_gray(im if torch.is_tensor(im) else torch.as_tensor(np.asarray(im)), dev)
+                                for im in ims], 0).contiguous()
         flows = self.rt.tvl1flow_batch(gray(Im1s), gray(Im2s))
         return [f.permute(1, 2, 0).contiguous().cpu().numpy() for f in flows]
 

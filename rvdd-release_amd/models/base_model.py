@@ -1,4 +1,7 @@
-"""The part of models/base_model.py (reference) that validate.py exercises."""
+"""Host-side base class of the model plugins: the slice of the reference's
+``BaseModel`` interface (models/base_model.py:9-67, 87-153, 173-214) that
+``validate.py`` and ``recurrentModel`` talk to.  Inference only: there are no
+optimizers, schedulers or ``save_networks`` behind it."""
 import copy
 import os
 from abc import ABC, abstractmethod
@@ -12,6 +15,22 @@ class _NoOptimizer:
 
     def __init__(self, lr):
         self.param_groups = [{'lr': lr}]
+
+
+def _read_state_dict(stem, name):
+    """``<stem>_net_<name>.pth`` (a torch state_dict, tensors only) or, when that file is absent, the neutral
+    conversion ``<stem>.safetensors`` shipped in weights/."""
+    pth = f"{stem}_net_{name}.pth"
+    twin = stem + ".safetensors"
+    if os.path.exists(pth):
+        print('loading the model from %s' % pth)
+        sd = torch.load(pth, map_location='cpu', weights_only=True)
+        return OrderedDict((k, v) for k, v in sd.items())          # drops a pickled _metadata attribute, if any
+    if os.path.exists(twin):
+        from safetensors.torch import load_file
+        print('loading the model from %s' % twin)
+        return load_file(twin)
+    raise FileNotFoundError(pth)
 
 
 class BaseModel(ABC):
@@ -30,6 +49,7 @@ class BaseModel(ABC):
         self.image_paths = []
         self.best_val_score = float("inf")
 
+    # -- what a model plugin supplies ----------------------------------------
     @abstractmethod
     def set_input(self, input):
         pass
@@ -45,20 +65,26 @@ class BaseModel(ABC):
     def optimize_parameters(self):
         raise NotImplementedError("rvdd is an inference runtime; training is out of scope")
 
-    def setup(self, opt):
-        """base_model.py:87-99: load the networks named by the options."""
-        if not self.isTrain:
-            self.load_networks(opt.epoch)
-        if self.isTrain and opt.path2epoch != '':
-            self.load_networks(opt.path2epoch, pathepoch=True)
-        self.print_networks(getattr(opt, 'verbose', False))
-
     def train(self):
         raise NotImplementedError("rvdd is an inference runtime; training is out of scope")
 
+    # -- what validate.py calls -------------------------------------------------
+    def _nets(self):
+        return [(n, getattr(self, 'net' + n)) for n in self.model_names]
+
+    def setup(self, opt):
+        """Weights come from ``--epoch`` under the run directory at test time, from ``--path2epoch`` (a path stem)
+        when the options were parsed in training mode, which is how validate.py parses them (base_model.py:87-99)."""
+        if self.isTrain:
+            if opt.path2epoch != '':
+                self.load_networks(opt.path2epoch, pathepoch=True)
+        else:
+            self.load_networks(opt.epoch)
+        self.print_networks(getattr(opt, 'verbose', False))
+
     def eval(self):
-        for name in self.model_names:
-            getattr(self, 'net' + name).eval()
+        for _, net in self._nets():
+            net.eval()
 
     @torch.no_grad()
     def test(self):
@@ -68,46 +94,23 @@ class BaseModel(ABC):
         return self.image_paths
 
     def get_current_visuals(self):
-        visual_ret = OrderedDict()
-        for name in self.visual_names:
-            visual_ret[name] = getattr(self, name)
-        return visual_ret
+        """name -> tensor for every entry of ``visual_names`` (validate.py:88 saves 'denoised')."""
+        return OrderedDict((name, getattr(self, name)) for name in self.visual_names)
 
     def get_current_losses(self):
-        errors_ret = OrderedDict()
-        for name in self.loss_names:
-            loss_str = 'loss_' + name
-            errors_ret[name] = float(getattr(self, loss_str)) if hasattr(self, loss_str) else 0
-        return errors_ret
+        """name -> Python float of ``self.loss_<name>``; 0 until the first compute_losses (validate.py:69,101)."""
+        return OrderedDict((name, float(getattr(self, 'loss_' + name, 0))) for name in self.loss_names)
 
     def load_networks(self, epoch, pathepoch=False):
-        """base_model.py:173-196.  Reads ``<epoch>_net_<name>.pth`` (a torch
-        state_dict) or, when that file is absent, its ``.safetensors`` twin
-        ``<epoch>.safetensors`` (the neutral conversion shipped in weights/)."""
-        for name in self.model_names:
-            if not pathepoch:
-                stem = os.path.join(self.save_dir, '%s' % epoch)
-            else:
-                stem = '%s' % epoch
-            load_path = '%s_net_%s.pth' % (stem, name)
-            net = getattr(self, 'net' + name)
-            if os.path.exists(load_path):
-                print('loading the model from %s' % load_path)
-                state_dict = torch.load(load_path, map_location='cpu', weights_only=True)
-            elif os.path.exists(stem + '.safetensors'):
-                from safetensors.torch import load_file
-                print('loading the model from %s' % (stem + '.safetensors'))
-                state_dict = load_file(stem + '.safetensors')
-            else:
-                raise FileNotFoundError(load_path)
-            if hasattr(state_dict, '_metadata'):
-                del state_dict._metadata
-            net.load_state_dict(state_dict)
+        """base_model.py:173-196, but strict: the runtime rejects unknown and missing keys where the reference
+        loads with strict=False."""
+        stem = str(epoch) if pathepoch else os.path.join(self.save_dir, str(epoch))
+        for name, net in self._nets():
+            net.load_state_dict(_read_state_dict(stem, name))
 
     def print_networks(self, verbose):
         print('---------- Networks initialized -------------')
-        for name in self.model_names:
-            net = getattr(self, 'net' + name)
-            num_params = sum(p.numel() for p in net.parameters())
-            print('[Network %s] Total number of parameters : %.3f M' % (name, num_params / 1e6))
+        for name, net in self._nets():
+            count = sum(p.numel() for p in net.parameters())
+            print('[Network %s] Total number of parameters : %.3f M' % (name, count / 1e6))
         print('-----------------------------------------------')

@@ -26,22 +26,28 @@ from .util.Hamilton_Adam_demo import HamiltonAdam
 
 
 def compute_flows_from_denoised(data: dict, model, opt) -> None:
-    """Replace data['flow'] by the TV-L1 flow from the last noisy frame to the re-mosaicked previous output.
+    """Replace the flow towards the previous frame in data['flow'] by the TV-L1 flow from the current noisy frame
+    to the re-mosaicked previous OUTPUT.
 
     The released reference cannot actually run this branch (it hands `remosaick` a squeezed 3-D tensor,
     validate.py:29-31 vs util/Hamilton_Adam_demo.py:237-238, and appends the same flow `opt.patch_depth - 1`
-    times); this is its evident intent: ONE flow, shaped like the dataset's `data['flow']` ([1,1,2,h,w])."""
-    if getattr(opt, "future_patch_depth", 0):
-        raise NotImplementedError("rvdd: --val_flow_from_denoised with a future frame is not built "
-                                  "(the reference pairs the NEXT frame with the previous output there)")
+    times); this is its evident intent: ONE flow, shaped like the dataset's `data['flow']` ([1,1,2,h,w]).
+    With a future frame (`--future_patch_depth 1`) the reference would in addition pair the NEXT noisy frame
+    (`data['n'][0, -4:]`) with the previous output and leave the model without its second flow (an IndexError in
+    recurrent_model.py:317); here the current frame is the second packed frame whatever follows it, and the flow
+    towards the next frame -- which no output exists for yet -- stays the dataset's pre-computed one."""
     dev = model.device
-    noisy_last = data['n'][0, -4:, :, :].to(dev, torch.float32)                      # packed raw, [-1,1]
+    noisy_cur = data['n'][0, 4:8, :, :].to(dev, torch.float32)                       # packed raw, [-1,1]
     prev_out = HamiltonAdam('gbrg').remosaick(model.denoised.to(dev))[0]
     # the reference hands (x+1)/2 images to CPPbridge, which reduces 4 channels to their mean (library.py:67-68, :165-167)
-    target = ((noisy_last + 1.0) / 2.0).mean(dim=0).contiguous()
+    target = ((noisy_cur + 1.0) / 2.0).mean(dim=0).contiguous()
     moving = ((prev_out + 1.0) / 2.0).mean(dim=0).contiguous()
     flow = ops_runtime(dev.index or 0).tvl1flow(target, moving)                     # moving(x + flow) ~ target(x)
-    data['flow'] = flow[None, None]
+    if getattr(opt, "future_patch_depth", 0):
+        keep = data['flow'][:, 1:2].to(dev, torch.float32)                          # cur -> next, from the dataset
+        data['flow'] = torch.cat((flow[None, None], keep), dim=1)
+    else:
+        data['flow'] = flow[None, None]
 
 
 def init_validation_dataloader(opt):

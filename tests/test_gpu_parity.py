@@ -398,6 +398,36 @@ def test_4k_frame_borders():
         assert ring.max() < 1e-4 and parity_psnr(got, want) > 120.0
 
 
+def test_all_twenty_checkpoints_load_strictly_and_run():
+    """Every checkpoint of the reference's trained-nets/ passes the runtime's strict key/shape table
+    (runtime.hip expected_keys) under the architecture its name states and produces a finite frame."""
+    import glob
+    from rvdd_release_amd import synth
+    from rvdd_release_amd.runtime import RvddRuntime
+    stems = sorted(os.path.basename(p)[:-12] for p in glob.glob(os.path.join(WEIGHTS, "*.safetensors")))
+    assert len(stems) == 20
+    H, W = 32, 48
+    s = synth.make_sequence(3, H, W, seed=5, device="cuda")
+    for stem in stems:
+        fut = 1 if "-future" in stem else 0
+        arch = ("next" if "ConvNeXt" in stem else "convunet") + ("+feat" if "+feat" in stem else "")
+        if arch.startswith("next") and "next-iso3200" not in BUILT:
+            continue
+        rt = RvddRuntime(arch, fut, 1, H, W, 0)
+        rt.load_state_dict(load_weights(stem))
+        if "no_warp" in stem:
+            rt.set_option("no_warp", 1)
+        out = rt.step(s.raw[0][None], s.raw[1][None], s.raw[2][None] if fut else None, s.flow_prev[1][None],
+                      s.flow_next[1][None] if fut else None)
+        assert torch.isfinite(out).all() and out.abs().max() < 4, stem
+        # a checkpoint of another family is refused by name, not silently half-loaded
+        other = RvddRuntime("convunet" if arch != "convunet" else "convunet+feat", fut, 1, H, W, 0)
+        with pytest.raises(RuntimeError, match="state_dict key"):
+            other.load_state_dict(load_weights(stem))
+        other.close()
+        rt.close()
+
+
 def test_empty_and_odd_inputs(ops):
     """Zero-sized batches are accepted and launch nothing; odd (non multiple of the tile) sizes of the single ops."""
     assert ops.demosaic(torch.zeros(0, 4, 8, 12).cuda()).shape == (0, 3, 16, 24)

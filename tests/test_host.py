@@ -98,12 +98,24 @@ def test_load_networks_reads_pth_and_safetensors(tmp_path):
 def test_every_shipped_checkpoint_matches_its_key_table():
     """The key/shape table the runtime enforces (runtime.hip expected_keys) is the
     reference's: count tensors and parameters."""
-    want = {"recurrent-convunet-iso3200": (48, 522243), "recurrent-convunet-future-iso3200": (48, 523539),
-            "recurrent-convunet+feat-iso3200": (50, 563763), "recurrent-convunet+feat-future-iso12800": (50, 565059),
-            "recurrent-ConvNeXtUnet-iso3200": (226, 523635), "recurrent-ConvNeXtUnet+feat-future-iso3200": (237, 549651)}
-    for stem, (nt, npar) in want.items():
+    fam = {"convunet": (48, 522243), "convunet-future": (48, 523539), "convunet+feat": (50, 563763),
+           "convunet+feat-future": (50, 565059), "ConvNeXtUnet": (226, 523635), "ConvNeXtUnet+feat-future": (237, 549651)}
+    stems = []
+    for iso in ("iso3200", "iso12800"):
+        for f in ("convunet", "convunet-future", "convunet+feat", "convunet+feat-future", "ConvNeXtUnet",
+                  "ConvNeXtUnet+feat-future"):
+            stems.append((f"recurrent-{f}-{iso}", fam[f]))
+        for f, k in (("convunet", "convunet"), ("convunet-future", "convunet-future"), ("convunet-no_warp", "convunet"),
+                     ("convunet-no_warp-future", "convunet-future")):
+            stems.append((f"non_recurrent-{f}-{iso}", fam[k]))
+    assert len(stems) == 20                                   # every file of the reference's trained-nets/
+    import glob, os
+    from conftest import WEIGHTS
+    assert sorted(os.path.basename(p)[:-12] for p in glob.glob(os.path.join(WEIGHTS, "*.safetensors"))) == sorted(s for s, _ in stems)
+    for stem, (nt, npar) in stems:
         sd = load_weights(stem)
         assert len(sd) == nt and sum(v.numel() for v in sd.values()) == npar, stem
+        assert all(v.dtype == torch.float32 for v in sd.values())
 
 
 def test_synth_is_deterministic_and_shaped():

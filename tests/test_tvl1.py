@@ -161,3 +161,27 @@ def test_hip_flow_smallest_and_skinny_sizes(h, w):
     # reference reads out of bounds there (mask.c:262-325); refused instead of reproduced
     with pytest.raises(RuntimeError, match="skinny"):
         ops_runtime(0).tvl1flow(torch.zeros(16, 300, device="cuda"), torch.zeros(16, 300, device="cuda"))
+
+
+@pytest.mark.gpu
+def test_hip_bridge_rgb_images():
+    """CPPbridge.TVL1_flow on [h,w,3] images (library.py:160-162): luminance 0.2125 R + 0.7154 G + 0.0721 B, as
+    skimage.color.rgb2gray defines it (restated: scikit-image is not installed), uint8 scaled to [0,1] first."""
+    from rvdd_release_amd.library import CPPbridge
+    rng = np.random.default_rng(5)
+    h, w = 48, 64
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
+    base = np.stack([np.sin(0.21 * xx + 0.1 * yy), np.cos(0.17 * yy - 0.05 * xx), np.sin(0.11 * (xx + yy))], -1)
+    a = (0.5 + 0.4 * base + 0.01 * rng.standard_normal((h, w, 3))).astype(np.float32)
+    b = np.roll(a, (1, -2), (0, 1))
+    br = CPPbridge(None)
+    flow = br.TVL1_flow(a, b)
+    lum = lambda im, div=1.0: ((im.astype(np.float64) / div) @ np.array([0.2125, 0.7154, 0.0721])).astype(np.float32)[..., None]
+    assert np.array_equal(flow, br.TVL1_flow(lum(a), lum(b)))                    # same plane as the 1-channel path
+    want = T.TVL1_flow(lum(a), lum(b))
+    assert np.abs(flow - want).max() < 5e-3
+    a8, b8 = (np.clip(a, 0, 1) * 255).astype(np.uint8), (np.clip(b, 0, 1) * 255).astype(np.uint8)
+    f8 = br.TVL1_flow(a8, b8)
+    assert np.array_equal(f8, br.TVL1_flow(lum(a8, 255.0), lum(b8, 255.0)))
+    with pytest.raises(AssertionError):
+        br.TVL1_flow(a[..., :2], b[..., :2])

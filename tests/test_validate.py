@@ -78,3 +78,41 @@ def test_compute_validation(online):
     assert abs(res["PSNR_valLoss"] - psnr) < 0.02
     assert abs(res["L1_valLoss"] - l1) < 1e-3
     assert res["lr"] == opt.lr and model.isTrain is False
+
+
+def test_compute_validation_online_flow_with_future_frame():
+    """--val_flow_from_denoised with --future_patch_depth 1: the flow towards the previous frame is recomputed
+    from the previous OUTPUT (TV-L1 on the device), the flow towards the next frame stays the dataset's."""
+    from rvdd_release_amd import synth
+    from rvdd_release_amd.models import create_model
+    from rvdd_release_amd.options import make_opt
+    from rvdd_release_amd.validate import compute_validation
+    stem = "recurrent-convunet+feat-future-iso12800"
+    sd = load_weights(stem)
+    s = synth.make_sequence(5, 96, 128, iso=12800, seed=70)
+
+    def dataset():
+        for t in range(1, s.raw.shape[0] - 1):
+            yield {"n": torch.cat((s.raw[t - 1], s.raw[t], s.raw[t + 1]), 0)[None],
+                   "flow": torch.stack((s.flow_prev[t], s.flow_next[t]), 0)[None],
+                   "gt": torch.cat((s.gt[t - 1], s.gt[t]), 0)[None],
+                   "n_path": [f"video0/{t:03d}.tif"], "gt_path": [f"video0/{t:03d}.tif"]}
+
+    opt = make_opt(netDenoiser=NET, feature_rec=True, future_patch_depth=1, path2epoch=os.path.join(WEIGHTS, stem),
+                   gpu_ids=[0], val_flow_from_denoised=True)
+    model = create_model(opt)
+    model.setup(opt)
+    opt.isTrain = model.isTrain = False
+    got = []
+    compute_validation(model, dataset(), opt, on_frame=lambda i, d, vis, l: got.append(vis["denoised"][0].cpu()))
+    rec = O.RecurrentOracle(sd, future=1)
+    den = None
+    for k, t in enumerate(range(1, s.raw.shape[0] - 1)):
+        flow = s.flow_prev[t][None]
+        if t > 1:
+            a = ((s.raw[t] + 1) / 2).permute(1, 2, 0).numpy()                    # the CURRENT noisy frame
+            b = ((_remosaick(den)[0] + 1) / 2).permute(1, 2, 0).numpy()
+            flow = torch.from_numpy(T.TVL1_flow(a, b).transpose(2, 0, 1).copy())[None]
+        den = rec.step(s.raw[t - 1][None], s.raw[t][None], s.raw[t + 1][None], flow, s.flow_next[t][None], first=(t == 1))
+        assert (got[k] - den[0]).abs().max() < 2e-3, (t, float((got[k] - den[0]).abs().max()))
+    assert len(got) == 3
