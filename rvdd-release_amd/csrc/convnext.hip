@@ -21,6 +21,10 @@
 // with g = l>>4.
 #include "rvdd_internal.h"
 
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+
 namespace {
 
 typedef __attribute__((address_space(3))) void lds_void;
@@ -78,104 +82,196 @@ __global__ __launch_bounds__(256) void proj1x1_kernel(const float* __restrict__ 
 }
 
 // ------------------------------------------------------------ dw 7x7 + LN --
-constexpr int DT_H = 8, DT_W = 16, DI_H = DT_H + 6, DI_W = DT_W + 6;
-constexpr int D_TILE_FLOATS = DI_H * DI_W * kF;          // 14784
-constexpr int D_W_FLOATS = 49 * kF;                       // 2352
-constexpr int D_NCHUNK = DI_H * DI_W * 12;                // 3696 16-B pieces
-constexpr size_t D_LDS_BYTES = (size_t)(D_TILE_FLOATS + D_W_FLOATS) * 4;
+constexpr int D_W_FLOATS = 49 * kF;                       // 2352: the 7x7 taps of the 48 channels, tap-major
 
-// 512 threads: thread t -> pixel t>>2 of the 8x16 tile, g = t&3 (channels 16j+4g..+3, j=0..2)
-__global__ __launch_bounds__(512) void dwln_kernel(const float* __restrict__ x, const float* __restrict__ dw_w,
-                                                   const float* __restrict__ dw_b,
-                                                   const float* __restrict__ ln_w,
-                                                   const float* __restrict__ ln_b, float* __restrict__ out,
-                                                   int B, int H, int W, int tiles_x, int tiles_y) {
+// ------------------------------------------- dw 7x7 + LN, sliding windows --
+// A pixel-per-thread kernel (round 1) reads one LDS value and one LDS weight per four FMAs and sits on the LDS
+// bandwidth (294 ds_read_b128 per thread).  Here a thread owns FOUR adjacent pixels of a row and four channels:
+// per filter row it reads the 10 input values its four 7-tap windows cover and the 7 weights once (17 reads for
+// 28 float4 FMAs, 3.3x fewer).  To keep two workgroups per CU with a 16x16-pixel tile (halo 22x22: 1.9x the
+// tile instead of 2.4x) the halo tile goes through LDS ONE 16-CHANNEL CHUNK AT A TIME (33 KiB), double-buffered:
+// the DMA of chunk j+1 runs under the FMAs of chunk j; the 12 channels x 4 pixels a thread accumulates stay in
+// registers until the LayerNorm (two __shfl_xor over the four channel-group lanes of a pixel).
+//
+// LDS image of a chunk: pixel pitch 64 B, row pitch 24 pixels, the four pixels of every aligned group of four
+// XOR-swizzled by the group index (slot = ((p & 3) ^ (R & 3)) * 4 + g, R = p >> 2) -- applied on the SOURCE
+// address of the LDS-DMA, whose destination is lane-linear.  With the lane map below (the 16 lanes that one
+// ds_read_b128 lane group serves = 4 quads x 4 channel groups of ONE row) every read is conflict-free.
+constexpr int E_TH = 16, E_TW = 16, E_IH = E_TH + 6, E_PITCH = 24;
+constexpr int E_BUF_FLOATS = E_IH * E_PITCH * 16;          // 8448 floats = 33 KiB: one 16-channel chunk of the halo tile
+constexpr int E_PIECES = E_BUF_FLOATS / 256;                // 33 LDS-DMA pieces of 1 KiB
+constexpr size_t E_LDS_BYTES = (size_t)(D_W_FLOATS + 2 * E_BUF_FLOATS) * 4;
+
+__global__ __launch_bounds__(256, 2) void dwln_kernel(const float* __restrict__ x, const float* __restrict__ dw_w,
+                                                      const float* __restrict__ dw_b, const float* __restrict__ ln_w,
+                                                      const float* __restrict__ ln_b, float* __restrict__ out,
+                                                      int B, int H, int W, int tiles_x, int tiles_y, int ntiles) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* Tl = smem;
-    float* Wl = smem + D_TILE_FLOATS;
+    float* Wl = smem;                        // [49][48]
+    float* Tl = smem + D_W_FLOATS;           // two chunk buffers
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int tile = blockIdx.x;
+
+    // Persistent workgroups (two per CU).  Blocks that share an XCD (blockIdx & 7 under round-robin placement:
+    // speed only) walk one contiguous band of tiles side by side, so the halo a tile shares with its neighbours
+    // is served by that XCD's L2.
+    const int per_xcd = (ntiles + 7) >> 3;
+    const int band_end = min(((int)(blockIdx.x & 7) + 1) * per_xcd, ntiles);
+    const int stride = (int)(gridDim.x >> 3);
+    int tile = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+    if (tile >= band_end) return;
     const int tiles_per_img = tiles_x * tiles_y;
-    const int b = tile / tiles_per_img;
-    const int rr = tile - b * tiles_per_img;
-    const int ty = rr / tiles_x, tx = rr - ty * tiles_x;
-    const int y0 = ty * DT_H, x0 = tx * DT_W;
+    struct TilePos { int b, y0, x0; };
+    auto locate = [&](int t) {
+        TilePos p;
+        p.b = t / tiles_per_img;
+        const int rr = t - p.b * tiles_per_img;
+        const int ty = rr / tiles_x;
+        p.y0 = ty * E_TH;
+        p.x0 = (rr - ty * tiles_x) * E_TW;
+        return p;
+    };
 
-    // halo tile (pad 3, zeros outside the image) by LDS-DMA
-    {
-        __amdgpu_buffer_rsrc_t ir = __builtin_amdgcn_make_buffer_rsrc((void*)(x + (size_t)b * H * W * kF), 0,
-                                                                      H * W * kF * 4, 0x00020000);
-        for (int k = wave; k * 64 < D_NCHUNK; k += 8) {
-            const int q = k * 64 + lane;
-            if (q < D_NCHUNK) {
-                const int px = q / 12, c4 = q - px * 12;
-                const int iy = px / DI_W, ix = px - iy * DI_W;
-                const int gy = y0 - 3 + iy, gx = x0 - 3 + ix;
-                const bool ok = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
-                dma16(ir, Tl + k * 256, ok ? (unsigned)(((gy * W + gx) * kF + c4 * 4) * 4) : 0x80000000u);
-            }
-        }
+    // lane -> (row of the wave's four rows, quad of four pixels, channel group); popcount parity puts the 16
+    // lanes of each ds_read_b128 lane group {0-3,12-15,20-27}, {4-11,16-19,28-31}, ... in one row
+    const int g = lane & 3;
+    const int idx = lane >> 2;
+    const int quad = idx & 3;
+    const int row = wave * 4 + ((idx >> 3) << 1) + (__builtin_popcount(idx & 7) & 1);
+
+    // which halo pixel / channel group each lane fetches for its (at most 9) DMA pieces: fixed for the kernel
+    int piece_yx[9];
+#pragma unroll
+    for (int n = 0; n < 9; ++n) {
+        const int k = wave + 4 * n;
+        const int R = k * 4 + (lane >> 4), sl = lane & 15;
+        const int p = 4 * R + ((sl >> 2) ^ (R & 3));
+        const int iy = p / E_PITCH, ix = p - iy * E_PITCH;
+        piece_yx[n] = (k < E_PIECES && ix < E_TW + 6) ? (iy << 8) | ix : -1;
     }
-    for (int q = tid; q < D_W_FLOATS / 4; q += 512)
-        reinterpret_cast<f32x4*>(Wl)[q] = reinterpret_cast<const f32x4*>(dw_w)[q];
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-
-    const int p = tid >> 2, g = tid & 3;
-    const int py = p / DT_W, pxl = p - py * DT_W;
-    f32x4 acc[3];
+    auto dma_chunk = [&](const TilePos& tp, int j, int buf) {
+        __amdgpu_buffer_rsrc_t ir =
+            __builtin_amdgcn_make_buffer_rsrc((void*)(x + (size_t)tp.b * H * W * kF), 0, H * W * kF * 4, 0x00020000);
+        float* dst = Tl + buf * E_BUF_FLOATS;
 #pragma unroll
-    for (int j = 0; j < 3; ++j) acc[j] = *reinterpret_cast<const f32x4*>(dw_b + 16 * j + 4 * g);
-    const float* tb = Tl + (py * DI_W + pxl) * kF + 4 * g;
-    const float* wb = Wl + 4 * g;
-#pragma unroll
-    for (int ky = 0; ky < 7; ++ky)
-#pragma unroll
-        for (int kx = 0; kx < 7; ++kx)
-#pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                const f32x4 v = *reinterpret_cast<const f32x4*>(tb + (ky * DI_W + kx) * kF + 16 * j);
-                const f32x4 wv = *reinterpret_cast<const f32x4*>(wb + (ky * 7 + kx) * kF + 16 * j);
-                acc[j] = acc[j] + v * wv;
+        for (int n = 0; n < 9; ++n) {
+            const int k = wave + 4 * n;
+            if (k < E_PIECES) {
+                const int gy = tp.y0 - 3 + (piece_yx[n] >> 8), gx = tp.x0 - 3 + (piece_yx[n] & 255);
+                const bool ok = piece_yx[n] >= 0 && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+                dma16(ir, dst + k * 256, ok ? (unsigned)(((gy * W + gx) * kF + 16 * j + 4 * (lane & 3)) * 4) : 0x80000000u);
             }
-    // LayerNorm over the 48 channels of the pixel: 12 here, the rest in lanes t^1, t^2, t^3
-    float s = 0.f;
-#pragma unroll
-    for (int j = 0; j < 3; ++j) s += (acc[j][0] + acc[j][1]) + (acc[j][2] + acc[j][3]);
-    s += __shfl_xor(s, 1);
-    s += __shfl_xor(s, 2);
-    const float u = s / 48.f;
-    float v2 = 0.f;
-#pragma unroll
-    for (int j = 0; j < 3; ++j)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float d = acc[j][r] - u;
-            v2 += d * d;
         }
-    v2 += __shfl_xor(v2, 1);
-    v2 += __shfl_xor(v2, 2);
-    const float den = sqrtf(v2 / 48.f + 1e-6f);
-    const int y = y0 + py, xx = x0 + pxl;
-    if (y < H && xx < W) {
-        float* o = out + (((size_t)b * H + y) * W + xx) * kF + 4 * g;
+    };
+    TilePos cur = locate(tile);
+    dma_chunk(cur, 0, 0);
+    for (int q = tid; q < D_W_FLOATS / 4; q += 256)
+        reinterpret_cast<f32x4*>(Wl)[q] = reinterpret_cast<const f32x4*>(dw_w)[q];
+
+    // read addresses: pixel (row + ky, 4 quad + dx) -> R = (row + ky) * 6 + quad + (dx >> 2); float offset =
+    // R * 64 + (((dx & 3) ^ (R & 3)) * 4 + g) * 4.  (R & 3) = (2 row + quad + 2 ky + (dx >> 2)) & 3: sixteen
+    // registers base + swizzle[c][d] for c = (2 ky + (dx >> 2)) & 3, d = dx & 3; the rest is an immediate.
+    const int t0 = (2 * row + quad) & 3;
+    int rd0[4][4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int d = 0; d < 4; ++d) rd0[c][d] = (row * 6 + quad) * 64 + ((d ^ ((t0 + c) & 3)) * 4 + g) * 4;
+
+    int par = 0;                 // buffer that holds (or receives) the chunk about to be used
+#pragma unroll 1
+    for (;;) {
+        const int next_tile = tile + stride;
+        const bool more = next_tile < band_end;
+        const TilePos nxt = locate(more ? next_tile : tile);
+        f32x4 acc[4][3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i][j] = *reinterpret_cast<const f32x4*>(dw_b + 16 * j + 4 * g);
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
-            const f32x4 lw = *reinterpret_cast<const f32x4*>(ln_w + 16 * j + 4 * g);
-            const f32x4 lb = *reinterpret_cast<const f32x4*>(ln_b + 16 * j + 4 * g);
-            f32x4 r;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();                              // this chunk landed; every wave is done with the other buffer
+            if (j + 1 < 3) dma_chunk(cur, j + 1, par ^ 1);
+            else if (more) dma_chunk(nxt, 0, par ^ 1);    // the next tile's first chunk rides under this tile's last
+            const float* tb = Tl + par * E_BUF_FLOATS;
+            const float* wb = Wl + 16 * j + 4 * g;
+            // rows are software-pipelined: the 17 reads of row ky + 1 are in flight under the 28 float4 FMAs of row ky
+            f32x4 win[2][10], wv[2][7];
+            auto read_row = [&](int ky, f32x4 (&wn)[10], f32x4 (&ww)[7]) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) r[k] = lw[k] * ((acc[j][k] - u) / den) + lb[k];
-            *reinterpret_cast<f32x4*>(o + 16 * j) = r;
+                for (int dx = 0; dx < 10; ++dx)
+                    wn[dx] = *reinterpret_cast<const f32x4*>(tb + rd0[(2 * ky + (dx >> 2)) & 3][dx & 3] + ky * 6 * 64 + (dx >> 2) * 64);
+#pragma unroll
+                for (int kx = 0; kx < 7; ++kx) ww[kx] = *reinterpret_cast<const f32x4*>(wb + (ky * 7 + kx) * kF);
+            };
+            read_row(0, win[0], wv[0]);
+#pragma unroll
+            for (int ky = 0; ky < 7; ++ky) {
+                if (ky + 1 < 7) read_row(ky + 1, win[(ky + 1) & 1], wv[(ky + 1) & 1]);
+#pragma unroll
+                for (int kx = 0; kx < 7; ++kx)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc[i][j] = acc[i][j] + win[ky & 1][i + kx] * wv[ky & 1][kx];
+                // one filter row at a time: left alone, instruction selection emits the (unchained) FMAs of a chunk
+                // behind ALL of its 119 LDS reads and spills a thousand registers.  The empty asm makes this row's
+                // sums a side effect that is ordered with the reads that follow.
+                asm volatile("" : "+v"(acc[0][j]), "+v"(acc[1][j]), "+v"(acc[2][j]), "+v"(acc[3][j])::"memory");
+            }
+            par ^= 1;
         }
+        // LayerNorm over the 48 channels of each pixel: 12 here, the rest in lanes l^1, l^2, l^3
+        const int y = cur.y0 + row;
+        f32x4 lw[3], lb[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            lw[j] = *reinterpret_cast<const f32x4*>(ln_w + 16 * j + 4 * g);
+            lb[j] = *reinterpret_cast<const f32x4*>(ln_b + 16 * j + 4 * g);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float sm = 0.f;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) sm += (acc[i][j][0] + acc[i][j][1]) + (acc[i][j][2] + acc[i][j][3]);
+            sm += __shfl_xor(sm, 1);
+            sm += __shfl_xor(sm, 2);
+            const float u = sm / 48.f;
+            float v2 = 0.f;
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float d = acc[i][j][r] - u;
+                    v2 += d * d;
+                }
+            v2 += __shfl_xor(v2, 1);
+            v2 += __shfl_xor(v2, 2);
+            // (x - u) / sqrt(var + eps) as (x - u) * (1 / sqrt(...)): one correctly rounded division per pixel instead
+            // of twelve per lane (each ~10 instructions); the quotient moves by at most one ulp
+            const float rden = 1.0f / sqrtf(v2 / 48.f + 1e-6f);
+            const int xx = cur.x0 + 4 * quad + i;
+            if (y < H && xx < W) {
+                float* o = out + (((size_t)cur.b * H + y) * W + xx) * kF + 4 * g;
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    f32x4 r;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) r[k] = lw[j][k] * ((acc[i][j][k] - u) * rden) + lb[j][k];
+                    *reinterpret_cast<f32x4*>(o + 16 * j) = r;
+                }
+            }
+        }
+        if (!more) break;
+        tile = next_tile;
+        cur = nxt;
     }
 }
 
 // ---------------------------------------------------------------------- MLP --
-// LDS: fc1 arranged [j(3)][m(12)][lr][g][i] = W1[16m+lr][16j+4g+i]            (9216 floats)
-//      fc2 arranged [m(12)][mo(3)][lr][g][r] = W2[16mo+lr][16m+4g+r]          (9216 floats)
+// LDS: fc1 arranged [j(3)][m(12)][lane = 16g+lr][i] = W1[16m+lr][16j+4g+i]     (9216 floats)
+//      fc2 arranged [m(12)][mo(3)][lane = 16g+lr][r] = W2[16mo+lr][16m+4g+r]   (9216 floats)
 constexpr int M_W_FLOATS = 192 * 48;
 constexpr size_t M_LDS_BYTES = (size_t)2 * M_W_FLOATS * 4;
 constexpr int M_NPB = 1;                       // 16-pixel groups per wave iteration
@@ -248,8 +344,8 @@ __global__ __launch_bounds__(768) void mlp_kernel(const float* __restrict__ ln, 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    const float* w1b = W1 + lr * 16 + g * 4;
-    const float* w2b = W2 + lr * 16 + g * 4;
+    const float* w1b = W1 + lane * 4;      // lane-linear fragments: each ds_read_b128 lane group covers one bank row
+    const float* w2b = W2 + lane * 4;
     const long nblk = (npix + 16 * M_NPB - 1) / (16 * M_NPB);
     const long wave_global = (long)blockIdx.x * (blockDim.x >> 6) + wave;
     const long nwaves = (long)gridDim.x * (blockDim.x >> 6);
@@ -373,13 +469,16 @@ hipError_t launch_proj1x1(const float* in1, int c1, const float* in2, int c2, co
 }
 
 hipError_t launch_next_dwln(const float* x, float* ln_out, const NextBlockW& w, int B, int H, int W, hipStream_t s) {
-    static std::atomic<uint64_t> attr{0};
-    if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(dwln_kernel), D_LDS_BYTES, attr); e != hipSuccess)
-        return e;
     if ((size_t)H * W * kF * 4 >= 0x80000000ull) return hipErrorInvalidValue;
-    const int tx = (W + DT_W - 1) / DT_W, ty = (H + DT_H - 1) / DT_H;
-    hipLaunchKernelGGL(dwln_kernel, dim3(B * tx * ty), dim3(512), D_LDS_BYTES, s, x, w.dw_w, w.dw_b, w.ln_w, w.ln_b,
-                       ln_out, B, H, W, tx, ty);
+    static std::atomic<uint64_t> attr{0};
+    if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(dwln_kernel), E_LDS_BYTES, attr); e != hipSuccess)
+        return e;
+    const int tx = (W + E_TW - 1) / E_TW, ty = (H + E_TH - 1) / E_TH;
+    const int ntiles = B * tx * ty;
+    // persistent: two workgroups per CU (LDS), never more blocks than tiles; the XCD band map needs a multiple of 8
+    const int grid = ((std::min(ntiles, 2 * num_cus()) + 7) / 8) * 8;
+    hipLaunchKernelGGL(dwln_kernel, dim3(grid), dim3(256), E_LDS_BYTES, s, x, w.dw_w, w.dw_b, w.ln_w, w.ln_b, ln_out, B, H, W,
+                       tx, ty, ntiles);
     return hipGetLastError();
 }
 

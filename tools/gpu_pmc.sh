@@ -1,0 +1,19 @@
+#!/bin/bash
+# One rocprofv3 --pmc pass per GROUP of counters (groups separated by ':', counters inside a group by ',';
+# a group must fit the block's slots: 8 SQ counters, FETCH_SIZE alone, WRITE_SIZE alone).
+# usage (GPU box, repo root): bash tools/gpu_pmc.sh <tag> "<group>:<group>..." <bench args...>
+set -o pipefail
+TAG=$1; GROUPS_=$2; shift 2
+ROOT=${GRAFT_REPO_ROOT:-$PWD}
+OUT=$ROOT/gpurun_out/pmc_$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+BENCH="python3 $ROOT/bench.py --steps 1 --warmup 1 --cpu-frames 0 --frames 4 --no-kernel-events $*"
+rc=0; i=0
+IFS=':' read -ra GS <<< "$GROUPS_"
+for G in "${GS[@]}"; do
+  i=$((i+1))
+  timeout -k 10 400 rocprofv3 --pmc ${G//,/ } --output-format csv -d $OUT/g$i -- $BENCH > $OUT/g$i.log 2>&1 || { rc=$?; tail -5 $OUT/g$i.log; break; }
+done
+ls $OUT | head -20
+exit $rc
