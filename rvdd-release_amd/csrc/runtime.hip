@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <map>
 #include <string>
 #include <vector>
@@ -86,6 +87,8 @@ struct rvdd_handle {
     bool prev_noisy = false;      // --prev_noisy_frame (rvdd_set_option): the next step's "previous frame" is the demosaiced noisy one
     bool no_warp = false;         // --no_warp (rvdd_set_option): previous output / features / next frame enter the net unwarped
     bool use_wino = true;         // 48->48 3x3 convs: Winograd F(2x2,3x3) (RVDD_CONV=direct selects the direct kernel)
+    int seq_major = 0;            // 1 = full-resolution stages one sequence at a time (see seq_major_on)
+    bool serpentine = false;      // sequence order of the current frame-step (flips every step when seq_major is on)
     std::map<std::string, HostTensor> staged;
     std::vector<void*> allocs;
 
@@ -393,16 +396,34 @@ bool wino_applies(const rvdd_t* h, int H, int W) {
     return h->use_wino && (h->force_wino || h->cfg.batch * ((W + 31) / 32) * ((H + 7) / 8) >= 200);
 }
 
-int run_conv(rvdd_t* h, const Conv3& L, const ConvCall& c, hipStream_t s) {
+// Sequences [b0, b0 + nb) of the batch: the maps of a ConvCall are those of the WHOLE batch, a launch may cover a part.
+struct Sub {
+    int b0, nb;
+};
+
+// Full-resolution stages one sequence at a time (depth first) instead of all B sequences per layer -- an option
+// (rvdd_set_option "seq_major"), off by default.  The idea: a 48-channel map of ONE 720p sequence (177 MB) stays in
+// the 256 MiB Infinity Cache between the layer that writes it and the layer that reads it, the maps of four (708 MB)
+// do not.  Measured (profiles/r02_c_seq_major.json): 424 frames/s against 456 batched -- per-sequence launches lose
+// more to their tails (3600 units on 256 CUs = 14.06 rounds) and to four filter-bank loads per layer than the cache
+// gives back.  Kept because it is free and pins an invariant the tests use: a launch's batch size does not enter a
+// tile's sums, so both schedules give bit-identical frames.
+bool seq_major_on(const rvdd_t* h) { return h->cfg.batch > 1 && h->seq_major == 1; }
+
+int run_conv(rvdd_t* h, const Conv3& L, const ConvCall& c, hipStream_t s, Sub sub = Sub{0, -1}) {
+    if (sub.nb < 0) sub.nb = h->cfg.batch;
+    const int cin_in = L.cin_pad[c.src];
+    const int Ho = c.epi == EPI_POOL ? c.H / 2 : (c.Hout ? c.Hout : c.H), Wo = c.epi == EPI_POOL ? c.W / 2 : (c.Wout ? c.Wout : c.W);
+    const size_t px_in = (size_t)sub.b0 * c.H * c.W, px_out = (size_t)sub.b0 * Ho * Wo;
     ConvArgs a{};
-    a.in = c.in;
+    a.in = c.in + px_in * cin_in;
     a.w = L.w[c.src];
     a.bias = L.bias;
-    a.acc_in = c.acc_in;
-    a.res1 = c.res1;
-    a.res2 = c.res2;
-    a.out = c.out;
-    a.B = h->cfg.batch;
+    a.acc_in = c.acc_in ? c.acc_in + px_in * kF : nullptr;
+    a.res1 = c.res1 ? c.res1 + px_in * kF : nullptr;
+    a.res2 = c.res2 ? c.res2 + px_in * kF : nullptr;
+    a.out = c.out + px_out * kF;
+    a.B = sub.nb;
     a.H = c.H;
     a.W = c.W;
     if (c.epi == EPI_POOL) {
@@ -427,8 +448,8 @@ int run_conv(rvdd_t* h, const Conv3& L, const ConvCall& c, hipStream_t s) {
     // per workgroup); the 1/8-resolution level of a single 720p sequence (60 units) runs faster direct
     a.w3 = h->w_out;
     a.b3 = h->b_out;
-    a.out3_nchw = c.out3_nchw;
-    a.out3_nhwc4 = c.out3_nhwc4;
+    a.out3_nchw = c.out3_nchw ? c.out3_nchw + px_in * 3 : nullptr;
+    a.out3_nhwc4 = c.out3_nhwc4 ? c.out3_nhwc4 + px_in * 4 : nullptr;
     const bool c16_ok = cin != 48 && !c.acc_in && (c.epi == EPI_NONE || c.epi == EPI_RELU);
     if ((cin == 48 || c16_ok) && L.wu[c.src] && wino_applies(h, c.H, c.W)) {
         a.w = L.wu[c.src];
@@ -448,44 +469,61 @@ int run_conv(rvdd_t* h, const Conv3& L, const ConvCall& c, hipStream_t s) {
         if (rc__) return rc__; \
     } while (0)
 
+// What rvdd_step does in front of the net for sequences [b0, b0 + nb) (demosaic, warps); empty for rvdd_unet_forward.
+using Prologue = std::function<int(Sub)>;
+
 // networks/unet.py:544-588 as specialised by UNet_FixedFeatures[_feat] (:595-825).
 int run_convunet(rvdd_t* h, const float* netin, const float* featw, float* feat_dst, float* out_nchw,
-                 float* out_nhwc4, hipStream_t s) {
+                 float* out_nhwc4, hipStream_t s, const Prologue& prologue) {
     const bool feat = h->has_feat();
     const int B = h->cfg.batch;
     Level* lv = h->lv;
     auto L = [&](const std::string& n) -> const Conv3& { return h->conv3.at(n); };
-    auto conv = [&](const std::string& name, const float* in, float* out, int lvl, int epi) {
+    auto conv = [&](const std::string& name, const float* in, float* out, int lvl, int epi, Sub sub) {
         ConvCall c;
         c.in = in; c.out = out; c.H = lv[lvl].H; c.W = lv[lvl].W; c.epi = epi;
-        return run_conv(h, L(name), c, s);
+        return run_conv(h, L(name), c, s, sub);
     };
     // two-source (virtual concat) conv: pass 1 leaves bias + sum over source A in `part`
-    auto conv2 = [&](const std::string& name, const float* inA, const float* inB, float* out, int lvl) {
+    auto conv2 = [&](const std::string& name, const float* inA, const float* inB, float* out, int lvl, Sub sub) {
         ConvCall c;
         c.in = inA; c.src = 0; c.out = lv[lvl].part; c.H = lv[lvl].H; c.W = lv[lvl].W; c.epi = EPI_NONE;
-        RC(run_conv(h, L(name), c, s));
+        RC(run_conv(h, L(name), c, s, sub));
         c.in = inB; c.src = 1; c.acc_in = lv[lvl].part; c.out = out; c.epi = EPI_RELU;
-        return run_conv(h, L(name), c, s);
+        return run_conv(h, L(name), c, s, sub);
     };
+    const Sub all{0, B};
+    // the full-resolution stages run per sequence when that keeps their maps in the Infinity Cache (seq_major_on),
+    // in an order that alternates from frame to frame so that a step begins with the sequence the last one ended on
+    const bool per_seq = seq_major_on(h);
+    std::vector<Sub> subs;
+    if (per_seq)
+        for (int k = 0; k < B; ++k) subs.push_back(Sub{h->serpentine ? B - 1 - k : k, 1});
+    else
+        subs.push_back(all);
 
-    // ---- encoder
-    if (feat) {
-        RC(conv("preprocessing_layer", netin, lv[0].t[0], 0, EPI_NONE));            // :742 (no activation)
-        RC(conv2("EncoderConvs.0.blocks.0.0", lv[0].t[0], featw, lv[0].t[1], 0));  // cat[y, old_features] :743
-    } else {
-        RC(conv("EncoderConvs.0.blocks.0.0", netin, lv[0].t[1], 0, EPI_RELU));
+    // ---- pre-stages + encoder level 0
+    for (const Sub sb : subs) {
+        if (prologue) RC(prologue(sb));
+        if (feat) {
+            RC(conv("preprocessing_layer", netin, lv[0].t[0], 0, EPI_NONE, sb));            // :742 (no activation)
+            RC(conv2("EncoderConvs.0.blocks.0.0", lv[0].t[0], featw, lv[0].t[1], 0, sb));  // cat[y, old_features] :743
+        } else {
+            RC(conv("EncoderConvs.0.blocks.0.0", netin, lv[0].t[1], 0, EPI_RELU, sb));
+        }
+        RC(conv("EncoderConvs.0.blocks.1.0", lv[0].t[1], lv[0].skip, 0, EPI_RELU, sb));
+        RC(conv("EncoderDown.0.conv", lv[0].skip, lv[1].t[0], 0, EPI_POOL, sb));            // :207-208
     }
-    RC(conv("EncoderConvs.0.blocks.1.0", lv[0].t[1], lv[0].skip, 0, EPI_RELU));
-    for (int i = 0; i < 3; ++i) {
-        const std::string e = "EncoderConvs." + std::to_string(i + 1);
-        RC(conv("EncoderDown." + std::to_string(i) + ".conv", lv[i].skip, lv[i + 1].t[0], i, EPI_POOL));  // :207-208
-        RC(conv(e + ".blocks.0.0", lv[i + 1].t[0], lv[i + 1].t[1], i + 1, EPI_RELU));
-        RC(conv(e + ".blocks.1.0", lv[i + 1].t[1], i + 1 < 3 ? lv[i + 1].skip : lv[3].t[2], i + 1, EPI_RELU));
+    // ---- encoder levels 1..3 (all sequences per launch: these levels need the batch to fill the chip)
+    for (int i = 1; i <= 3; ++i) {
+        const std::string e = "EncoderConvs." + std::to_string(i);
+        if (i > 1) RC(conv("EncoderDown." + std::to_string(i - 1) + ".conv", lv[i - 1].skip, lv[i].t[0], i - 1, EPI_POOL, all));
+        RC(conv(e + ".blocks.0.0", lv[i].t[0], lv[i].t[1], i, EPI_RELU, all));
+        RC(conv(e + ".blocks.1.0", lv[i].t[1], i < 3 ? lv[i].skip : lv[3].t[2], i, EPI_RELU, all));
     }
     // ---- bottleneck: d = e3 + d1 + d2 (:561-567)
     float* e3 = lv[3].t[2];
-    RC(conv("bottleneck.0.0", e3, lv[3].t[0], 3, EPI_RELU));
+    RC(conv("bottleneck.0.0", e3, lv[3].t[0], 3, EPI_RELU, all));
     {
         ConvCall c;
         c.in = lv[3].t[0]; c.out = lv[3].t[1]; c.H = lv[3].H; c.W = lv[3].W;
@@ -493,49 +531,56 @@ int run_convunet(rvdd_t* h, const float* netin, const float* featw, float* feat_
         RC(run_conv(h, L("bottleneck.1.0"), c, s));
     }
     const float* d = lv[3].t[1];
-    // ---- decoder (:570-579)
+    // ---- decoder (:570-579); its last level again per sequence, together with the post convs
+    float* fdst = feat_dst ? feat_dst : lv[0].t[2];
     for (int i = 0; i < 3; ++i) {
         const int lo = 3 - i, hi = 2 - i;
         const int uh = 2 * lv[lo].H, uw = 2 * lv[lo].W;      // size after nn.Upsample(x2)
-        {
-            Scope sc(h, s, "upsample2x_kernel", 0.0, (double)B * uh * uw * 192.0 * 1.25);
-            HIPCHK(h, launch_upsample2x(d, lv[hi].t[0], B, lv[lo].H, lv[lo].W, uh, uw, 0, 0, false, s));
+        const std::vector<Sub> one{all};
+        for (const Sub sb : (hi == 0 ? subs : one)) {
+            const size_t lo_px = (size_t)sb.b0 * lv[lo].H * lv[lo].W, hi_px = (size_t)sb.b0 * lv[hi].H * lv[hi].W;
+            {
+                Scope sc(h, s, "upsample2x_kernel", 0.0, (double)sb.nb * uh * uw * 192.0 * 1.25);
+                HIPCHK(h, launch_upsample2x(d + lo_px * kF, lv[hi].t[0] + (size_t)sb.b0 * uh * uw * kF, sb.nb, lv[lo].H, lv[lo].W, uh,
+                                            uw, 0, 0, false, s));
+            }
+            // conv + ReLU at the upsampled size, written into a map of the skip's size
+            // (zero_pad_features, :151-170; identity when sizes agree)
+            ConvCall c;
+            c.in = lv[hi].t[0]; c.out = lv[hi].t[1]; c.H = uh; c.W = uw; c.epi = EPI_RELU;
+            c.Hout = lv[hi].H; c.Wout = lv[hi].W;
+            c.oy = (lv[hi].H - uh) / 2; c.ox = (lv[hi].W - uw) / 2;
+            if (uh != lv[hi].H || uw != lv[hi].W)
+                HIPCHK(h, hipMemsetAsync(lv[hi].t[1] + hi_px * kF, 0, (size_t)sb.nb * lv[hi].H * lv[hi].W * kF * sizeof(float), s));
+            RC(run_conv(h, L("DecoderUp." + std::to_string(i) + ".up.1"), c, s, sb));
+            const std::string dc = "DecoderConvs." + std::to_string(i);
+            RC(conv2(dc + ".blocks.0.0", lv[hi].skip, lv[hi].t[1], lv[hi].t[0], hi, sb));   // cat(skip, dec) :541
+            RC(conv(dc + ".blocks.1.0", lv[hi].t[0], lv[hi].t[1], hi, EPI_RELU, sb));
+            if (hi > 0) continue;
+            // ---- post: hooked 48-ch map = next frame's features (:808-812), then 1x1 -> 3
+            if (wino_applies(h, lv[0].H, lv[0].W)) {
+                // PostConvs[1] (1x1, 48 -> 3) rides in the epilogue of PostConvs[0]'s Winograd kernel
+                ConvCall pc;
+                pc.in = lv[0].t[1]; pc.out = fdst; pc.H = lv[0].H; pc.W = lv[0].W; pc.epi = EPI_RELU_OUT3;
+                pc.out3_nchw = out_nchw; pc.out3_nhwc4 = out_nhwc4;
+                RC(run_conv(h, L("PostConvs.0.0"), pc, s, sb));
+            } else {
+                RC(conv("PostConvs.0.0", lv[0].t[1], fdst, 0, EPI_RELU, sb));
+                const size_t px0 = (size_t)sb.b0 * h->cfg.height * h->cfg.width;
+                const double px = (double)sb.nb * h->cfg.height * h->cfg.width;
+                Scope sc(h, s, "conv1x1_out_kernel", 2.0 * 48 * 3 * px, px * (192.0 + 12.0 + 16.0));
+                HIPCHK(h, launch_conv1x1_out(fdst + px0 * kF, h->w_out, h->b_out, out_nchw + px0 * 3,
+                                             out_nhwc4 ? out_nhwc4 + px0 * 4 : nullptr, sb.nb, h->cfg.height, h->cfg.width, s));
+            }
         }
-        // conv + ReLU at the upsampled size, written into a map of the skip's size
-        // (zero_pad_features, :151-170; identity when sizes agree)
-        ConvCall c;
-        c.in = lv[hi].t[0]; c.out = lv[hi].t[1]; c.H = uh; c.W = uw; c.epi = EPI_RELU;
-        c.Hout = lv[hi].H; c.Wout = lv[hi].W;
-        c.oy = (lv[hi].H - uh) / 2; c.ox = (lv[hi].W - uw) / 2;
-        if (uh != lv[hi].H || uw != lv[hi].W)
-            HIPCHK(h, hipMemsetAsync(lv[hi].t[1], 0, (size_t)B * lv[hi].H * lv[hi].W * kF * sizeof(float), s));
-        RC(run_conv(h, L("DecoderUp." + std::to_string(i) + ".up.1"), c, s));
-        const std::string dc = "DecoderConvs." + std::to_string(i);
-        RC(conv2(dc + ".blocks.0.0", lv[hi].skip, lv[hi].t[1], lv[hi].t[0], hi));   // cat(skip, dec) :541
-        RC(conv(dc + ".blocks.1.0", lv[hi].t[0], lv[hi].t[1], hi, EPI_RELU));
         d = lv[hi].t[1];
     }
-    // ---- post: hooked 48-ch map = next frame's features (:808-812), then 1x1 -> 3
-    float* fdst = feat_dst ? feat_dst : lv[0].t[2];
-    if (wino_applies(h, lv[0].H, lv[0].W)) {
-        // PostConvs[1] (1x1, 48 -> 3) rides in the epilogue of PostConvs[0]'s Winograd kernel
-        ConvCall c;
-        c.in = d; c.out = fdst; c.H = lv[0].H; c.W = lv[0].W; c.epi = EPI_RELU_OUT3;
-        c.out3_nchw = out_nchw; c.out3_nhwc4 = out_nhwc4;
-        return run_conv(h, L("PostConvs.0.0"), c, s);
-    }
-    RC(conv("PostConvs.0.0", d, fdst, 0, EPI_RELU));
-    {
-        const double px = (double)B * h->cfg.height * h->cfg.width;
-        Scope sc(h, s, "conv1x1_out_kernel", 2.0 * 48 * 3 * px, px * (192.0 + 12.0 + 16.0));
-        HIPCHK(h, launch_conv1x1_out(fdst, h->w_out, h->b_out, out_nchw, out_nhwc4, B, h->cfg.height,
-                                     h->cfg.width, s));
-    }
+    if (per_seq) h->serpentine = !h->serpentine;
     return RVDD_OK;
 }
 
 int run_net(rvdd_t* h, const float* netin, const float* featw, float* feat_dst, float* out_nchw,
-            float* out_nhwc4, hipStream_t s);
+            float* out_nhwc4, hipStream_t s, const Prologue& prologue);
 
 int ensure_scratch(rvdd_t* h, size_t bytes) {
     if (h->scratch_bytes >= bytes) return RVDD_OK;
@@ -556,9 +601,10 @@ int ensure_scratch(rvdd_t* h, size_t bytes) {
 
 namespace {
 int run_net(rvdd_t* h, const float* netin, const float* featw, float* feat_dst, float* out_nchw,
-            float* out_nhwc4, hipStream_t s) {
-    return h->is_next() ? run_convnext(h, netin, featw, feat_dst, out_nchw, out_nhwc4, s)
-                        : run_convunet(h, netin, featw, feat_dst, out_nchw, out_nhwc4, s);
+            float* out_nhwc4, hipStream_t s, const Prologue& prologue) {
+    if (!h->is_next()) return run_convunet(h, netin, featw, feat_dst, out_nchw, out_nhwc4, s, prologue);
+    if (prologue) RC(prologue(Sub{0, h->cfg.batch}));
+    return run_convnext(h, netin, featw, feat_dst, out_nchw, out_nhwc4, s);
 }
 }  // namespace
 
@@ -589,6 +635,7 @@ int rvdd_create(const rvdd_cfg* cfg, rvdd_t** out) {
 
     rvdd_t* h = new rvdd_handle();
     h->cfg = *cfg;
+    if (const char* sm = std::getenv("RVDD_SEQ_MAJOR")) h->seq_major = std::atoi(sm) != 0;     // measurement switch
     if (const char* cv = std::getenv("RVDD_CONV")) {     // direct | winograd (forced at every size) | anything else = auto
         h->use_wino = std::strcmp(cv, "direct") != 0;
         h->force_wino = std::strcmp(cv, "winograd") == 0;
@@ -782,6 +829,12 @@ int rvdd_set_option(rvdd_t* h, const char* name, int32_t value) {
         h->prev_noisy = value != 0;
         return RVDD_OK;
     }
+    if (std::strcmp(name, "seq_major") == 0) {
+        // 1 = the full-resolution stages of the convunet run one sequence at a time (measured slower: see seq_major_on)
+        if (value < 0 || value > 1) return fail(h, RVDD_ERR_ARG, "rvdd_set_option: seq_major must be 0 or 1");
+        h->seq_major = value;
+        return RVDD_OK;
+    }
     if (std::strcmp(name, "conv_kernel") == 0) {
         // which kernel runs the 3x3 convs: 0 = by launch size (default), 1 = the direct kernel everywhere,
         // 2 = the Winograd kernel everywhere (also where it is the slower choice: tests and A/B measurements)
@@ -790,7 +843,7 @@ int rvdd_set_option(rvdd_t* h, const char* name, int32_t value) {
         h->force_wino = value == 2;
         return RVDD_OK;
     }
-    return fail(h, RVDD_ERR_ARG, "rvdd_set_option: unknown option '%s' (known: no_warp, warp_raw, prev_noisy_frame, conv_kernel)", name);
+    return fail(h, RVDD_ERR_ARG, "rvdd_set_option: unknown option '%s' (known: no_warp, warp_raw, prev_noisy_frame, conv_kernel, seq_major)", name);
 }
 
 int rvdd_reset(rvdd_t* h) {
@@ -819,40 +872,55 @@ int rvdd_step(rvdd_t* h, const float* raw_prev, const float* raw_cur, const floa
         if (h->has_feat()) HIPCHK(h, hipMemsetAsync(h->lastfeat, 0, npix * kF * sizeof(float), s));
         h->need_init = false;
     }
-    {
-        Scope sc(h, s, "demosaic(ha_green+ha_rb)", 0.0, npix * 16.0);
-        HIPCHK(h, launch_demosaic(raw_cur, h->green, h->netin + 3, B, H / 2, W / 2, (int64_t)H * W * kNetInC, kNetInC, 1, s));
-    }
-    if (h->warp_raw && !nw) {
-        // warp_frame with --warp_raw (models/recurrent_model.py:149-152): HA(warp(remosaick(frame), raw-resolution flow)).
-        // remosaick(HA(raw)) is raw itself, so the next frame is warped as it came.  next4 is free in this mode: its
-        // first quarter holds the re-mosaicked previous output, the second the warped planes.
-        float* packed = h->next4;
-        float* warped = h->next4 + npix;
-        HIPCHK(h, launch_remosaick4(h->lastden4, packed, B, H, W, s));
-        HIPCHK(h, launch_warp_nchw(packed, flow_prev, warped, B, 4, H / 2, W / 2, s));
-        HIPCHK(h, launch_demosaic(warped, h->green, h->netin + 0, B, H / 2, W / 2, (int64_t)H * W * kNetInC, kNetInC, 1, s));
-        if (h->cfg.future) {
-            HIPCHK(h, launch_warp_nchw(raw_next, flow_next, warped, B, 4, H / 2, W / 2, s));
-            HIPCHK(h, launch_demosaic(warped, h->green, h->netin + 6, B, H / 2, W / 2, (int64_t)H * W * kNetInC, kNetInC, 1, s));
-        }
-    } else {
+    // the stages in front of the net, for sequences [b0, b0 + nb) (run_convunet calls it per sequence when the
+    // full-resolution stages run depth first)
+    const size_t rawf = (size_t)4 * (H / 2) * (W / 2), flowf = (size_t)2 * (H / 2) * (W / 2), img = (size_t)H * W;
+    Prologue prologue = [&](Sub sb) -> int {
+        const size_t o = (size_t)sb.b0;
+        const int n = sb.nb;
+        const float* rc_ = raw_cur + o * rawf;
+        const float* fp_ = flow_prev ? flow_prev + o * flowf : nullptr;
+        const float* rn_ = raw_next ? raw_next + o * rawf : nullptr;
+        const float* fn_ = flow_next ? flow_next + o * flowf : nullptr;
+        float* green = h->green + o * img;
+        float* netin = h->netin + o * img * kNetInC;
         {
-            Scope sc(h, s, "warp3_kernel", 0.0, npix * 32.0);
-            HIPCHK(h, launch_warp3(h->lastden4, flow_prev, h->netin + 0, kNetInC, B, H, W, s));
+            Scope sc(h, s, "demosaic(ha_green+ha_rb)", 0.0, (double)n * img * 16.0);
+            HIPCHK(h, launch_demosaic(rc_, green, netin + 3, n, H / 2, W / 2, (int64_t)H * W * kNetInC, kNetInC, 1, s));
         }
-        if (h->cfg.future) {
-            HIPCHK(h, launch_demosaic(raw_next, h->green, h->next4, B, H / 2, W / 2, (int64_t)H * W * 4, 4, 1, s));
-            HIPCHK(h, launch_warp3(h->next4, flow_next, h->netin + 6, kNetInC, B, H, W, s));
+        if (h->warp_raw && !nw) {
+            // warp_frame with --warp_raw (models/recurrent_model.py:149-152): HA(warp(remosaick(frame), raw-resolution flow)).
+            // remosaick(HA(raw)) is raw itself, so the next frame is warped as it came.  next4 is free in this mode: its
+            // first quarter holds the re-mosaicked previous output, the second the warped planes.
+            float* packed = h->next4 + o * img;
+            float* warped = h->next4 + npix + o * img;
+            HIPCHK(h, launch_remosaick4(h->lastden4 + o * img * 4, packed, n, H, W, s));
+            HIPCHK(h, launch_warp_nchw(packed, fp_, warped, n, 4, H / 2, W / 2, s));
+            HIPCHK(h, launch_demosaic(warped, green, netin + 0, n, H / 2, W / 2, (int64_t)H * W * kNetInC, kNetInC, 1, s));
+            if (h->cfg.future) {
+                HIPCHK(h, launch_warp_nchw(rn_, fn_, warped, n, 4, H / 2, W / 2, s));
+                HIPCHK(h, launch_demosaic(warped, green, netin + 6, n, H / 2, W / 2, (int64_t)H * W * kNetInC, kNetInC, 1, s));
+            }
+        } else {
+            {
+                Scope sc(h, s, "warp3_kernel", 0.0, (double)n * img * 32.0);
+                HIPCHK(h, launch_warp3(h->lastden4 + o * img * 4, fp_, netin + 0, kNetInC, n, H, W, s));
+            }
+            if (h->cfg.future) {
+                float* next4 = h->next4 + o * img * 4;
+                HIPCHK(h, launch_demosaic(rn_, green, next4, n, H / 2, W / 2, (int64_t)H * W * 4, 4, 1, s));
+                HIPCHK(h, launch_warp3(next4, fn_, netin + 6, kNetInC, n, H, W, s));
+            }
         }
-    }
-    if (h->has_feat() && !nw) {
-        Scope sc(h, s, "warp48_kernel", 0.0, npix * (384.0 + 2.0));
-        HIPCHK(h, launch_warp48(h->lastfeat, flow_prev, h->featw, B, H, W, s));
-    }
+        if (h->has_feat() && !nw) {
+            Scope sc(h, s, "warp48_kernel", 0.0, (double)n * img * (384.0 + 2.0));
+            HIPCHK(h, launch_warp48(h->lastfeat + o * img * kF, fp_, h->featw + o * img * kF, n, H, W, s));
+        }
+        return RVDD_OK;
+    };
     // without warping the previous features are read in place: the net consumes them in its first layer and only
     // its last one writes the new ones
-    const int rc = run_net(h, h->netin, nw ? h->lastfeat : h->featw, h->lastfeat, out_rgb, h->lastden4, s);
+    const int rc = run_net(h, h->netin, nw ? h->lastfeat : h->featw, h->lastfeat, out_rgb, h->lastden4, s, prologue);
     if (rc == RVDD_OK && h->prev_noisy)     // store_frame = the noisy current frame (models/recurrent_model.py:335-337)
         HIPCHK(h, launch_demosaic(raw_cur, h->green, h->lastden4, B, H / 2, W / 2, (int64_t)H * W * 4, 4, 1, s));
     return rc;
@@ -913,7 +981,7 @@ int rvdd_unet_forward(rvdd_t* h, const float* x, const float* feat_in, float* ou
     const int B = h->cfg.batch, H = h->cfg.height, W = h->cfg.width;
     HIPCHK(h, launch_nchw_to_nhwc(x, h->netin, B, h->cin_real(), H, W, kNetInC, s));
     if (h->has_feat()) HIPCHK(h, launch_nchw_to_nhwc(feat_in, h->featw, B, kF, H, W, kF, s));
-    RC(run_net(h, h->netin, h->featw, h->lv[0].t[2], out, nullptr, s));
+    RC(run_net(h, h->netin, h->featw, h->lv[0].t[2], out, nullptr, s, Prologue()));
     if (h->has_feat() && feat_out) HIPCHK(h, launch_nhwc_to_nchw(h->lv[0].t[2], feat_out, B, kF, H, W, kF, s));
     return RVDD_OK;
 }

@@ -348,9 +348,10 @@ def test_batch_of_four_720p_invariants():
     H, W = 720, 1280
     seqs = [synth.make_sequence(3, H, W, iso=3200, seed=2100 + b, device="cuda") for b in range(2)]
 
-    def run(which, conv=0):
+    def run(which, conv=0, seq_major=0):
         rt = RvddRuntime("convunet+feat", 0, len(which), H, W, 0)
         rt.set_option("conv_kernel", conv)
+        rt.set_option("seq_major", seq_major)
         rt.load_state_dict(sd)
         outs = []
         for t in (1, 2):
@@ -370,6 +371,11 @@ def test_batch_of_four_720p_invariants():
     alone_w = run([1], conv=2)
     for t in range(2):
         assert torch.equal(four_w[t][1], alone_w[t][0])
+    # the other schedule of the same work (full-resolution stages one sequence at a time, serpentine order over the
+    # frames): the same kernels on the same tiles, so the same bits
+    four_s = run([0, 1, 0, 1], seq_major=1)
+    for t in range(2):
+        assert torch.equal(four_s[t], four[t])
 
 
 def test_4k_frame_borders():
