@@ -77,10 +77,6 @@ struct UnitPos {
     int b, ty, tx;
 };
 
-#ifndef RVDD_WINO_SPLIT
-#define RVDD_WINO_SPLIT 1
-#endif
-
 template <int EPI, bool ACC_IN, int NJ>
 __device__ __forceinline__ void wino_body(const ConvArgs& a) {
     extern __shared__ __attribute__((aligned(16))) float U[];
@@ -92,35 +88,21 @@ __device__ __forceinline__ void wino_body(const ConvArgs& a) {
     const int lr = lane & 15;
     const int g = lane >> 4;
 
-    // transformed filter bank -> LDS (linear copy of the host arrangement), by LDS-DMA.  Every workgroup copies the
-    // same 1-KiB pieces: each starts at a different one, so that the 256 copies do not queue on the same L2 lines.
-    // NJ = 3: the pieces of input chunk 0 go first, then this wave's first patch, then the pieces of chunks 1 and 2:
-    // the first stage starts when a third of the bank is resident (vector-memory operations complete in order, so
-    // "all but the youngest 24" = chunk 0 and the patch), the rest lands under its MFMAs (SPLIT_BANK).
-    __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, UF * 4, 0x00020000);
-    auto dma_piece = [&](int k) {
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lds_void*)(U + k * 256), 16, (unsigned)(k * 1024 + lane * 16), 0, 0, 0);
-    };
-    constexpr bool SPLIT_BANK = NJ == 3 && RVDD_WINO_SPLIT;
-    if constexpr (!SPLIT_BANK) {
+    {   // transformed filter bank -> LDS (linear copy of the host arrangement)
+        __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, UF * 4, 0x00020000);
+        // every workgroup copies the same 1-KiB pieces: each starts at a different one, so that the 256 copies do not
+        // queue on the same L2 lines at the same time (+0.35 % on the frame rate; starting the first stage on the
+        // first third of the bank while the rest lands was measured and lost 1.5 %: two more barriers per launch)
         constexpr int NP = UF / 256;
         const int rot = (int)((blockIdx.x * 37u) % (unsigned)NP);
         for (int i = wave; i < NP; i += 4) {
             int k = i + rot;
             if (k >= NP) k -= NP;
-            dma_piece(k);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-    } else {
-        const int rot = (int)((blockIdx.x * 7u) % 48u);
-#pragma unroll
-        for (int i = 0; i < 12; ++i) {                 // chunk 0: 16 positions x 3 cout blocks
-            int q = wave + 4 * i + rot;
-            if (q >= 48) q -= 48;
-            dma_piece((q / 3) * 9 + q % 3);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lds_void*)(U + k * 256), 16, (unsigned)(k * 1024 + lane * 16), 0, 0, 0);
         }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
 
     const int units_per_img = a.tiles_x * a.tiles_y;
     const unsigned map_bytes = (unsigned)(a.H * a.W * kF * 4);      // 48-channel maps of the input's size (partial sums, residuals)
@@ -220,21 +202,8 @@ __device__ __forceinline__ void wino_body(const ConvArgs& a) {
     UnitPos cur, nxt;
     locate(unit, cur);
     load_patch(pb[0], cur, 0);
-    if constexpr (SPLIT_BANK) {
-        const int rot = (int)((blockIdx.x * 7u) % 96u);
-#pragma unroll
-        for (int i = 0; i < 24; ++i) {                 // chunks 1 and 2
-            int q = wave + 4 * i + rot;
-            if (q >= 96) q -= 96;
-            dma_piece((q / 6) * 9 + 3 + q % 6);
-        }
-        __builtin_amdgcn_sched_barrier(0);             // keep the transform (and its waits) behind the requests
-        asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
-    }
 #pragma unroll
     for (int sl = 0; sl < 8; ++sl) transform_slice(pb[0], sl);
-    if constexpr (SPLIT_BANK) __builtin_amdgcn_s_barrier();      // everybody's chunk-0 pieces are in LDS
-    bool bank_pending = SPLIT_BANK;
 
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
@@ -265,13 +234,6 @@ __device__ __forceinline__ void wino_body(const ConvArgs& a) {
         }
         if constexpr (NJ == 3) {
             stage(I0{}, XP{}, true, cur, 1);
-            if (bank_pending) {
-                // first unit only: this wave's pieces of chunks 1, 2 are older than the patch it has just transformed,
-                // hence landed; the barrier makes the other waves' pieces visible
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-                bank_pending = false;
-            }
             stage(I1{}, XQ{}, false, cur, 2);
             stage(I2{}, XP{}, false, nxt, 0);
         } else {
