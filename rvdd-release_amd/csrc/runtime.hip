@@ -112,6 +112,27 @@ struct rvdd_handle {
     size_t scratch_bytes = 0;
     Tvl1Workspace* tvl1 = nullptr;   // cached for the last (nx, ny)
 
+    // hipGraph replay of a frame-step (see rvdd_step)
+    struct StepKey {
+        const void* p[6];
+        int flags;
+        bool operator<(const StepKey& o) const {
+            const int c = std::memcmp(p, o.p, sizeof p);
+            return c ? c < 0 : flags < o.flags;
+        }
+    };
+    struct StepGraph {
+        hipGraph_t graph = nullptr;
+        hipGraphExec_t exec = nullptr;
+        uint64_t last_use = 0;
+    };
+    std::map<StepKey, StepGraph> graphs;
+    uint64_t graph_tick = 0;
+    int use_graphs = 0;             // RVDD_GRAPH=1 / rvdd_set_option "graphs" 1: replay captured frame-steps (measured slower, off)
+    bool ran_eagerly = false;       // the first step of a handle is never captured (it sets the kernels' attributes)
+    hipStream_t gstream = nullptr;  // the stream the graphs are captured on and replayed in
+    hipEvent_t g_in = nullptr, g_out = nullptr;
+
     // measurement
     bool prof_on = false;
     std::string prof_filter;      // empty = every kernel class
@@ -136,6 +157,14 @@ int fail(rvdd_t* h, int code, const char* fmt, ...) {
     va_end(ap);
     if (h) h->err = buf; else g_create_error = buf;
     return code;
+}
+
+void drop_graphs(rvdd_t* h) {
+    for (auto& kv : h->graphs) {
+        if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
+        if (kv.second.graph) (void)hipGraphDestroy(kv.second.graph);
+    }
+    h->graphs.clear();
 }
 
 #define ENTER(h)                                                                            \
@@ -674,6 +703,13 @@ int rvdd_create(const rvdd_cfg* cfg, rvdd_t** out) {
     }
     (void)hipEventCreate(&h->t0);
     (void)hipEventCreate(&h->t1);
+    if (const char* gv = std::getenv("RVDD_GRAPH")) h->use_graphs = std::atoi(gv) != 0;
+    if (hipStreamCreateWithFlags(&h->gstream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&h->g_in, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->g_out, hipEventDisableTiming) != hipSuccess) {
+        (void)hipGetLastError();
+        h->use_graphs = 0;
+    }
     *out = h;
     return RVDD_OK;
 }
@@ -682,6 +718,10 @@ void rvdd_destroy(rvdd_t* h) {
     if (!h) return;
     DeviceGuard guard(h->cfg.device);
     (void)hipDeviceSynchronize();
+    drop_graphs(h);
+    if (h->g_in) (void)hipEventDestroy(h->g_in);
+    if (h->g_out) (void)hipEventDestroy(h->g_out);
+    if (h->gstream) (void)hipStreamDestroy(h->gstream);
     for (void* p : h->allocs) (void)hipFree(p);
     if (h->scratch) (void)hipFree(h->scratch);
     tvl1_free(h->tvl1);
@@ -815,6 +855,15 @@ int64_t rvdd_tiff_lzw_decode(const uint8_t* in, int64_t n, uint8_t* out, int64_t
 
 int rvdd_set_option(rvdd_t* h, const char* name, int32_t value) {
     if (!h || !name) return RVDD_ERR_ARG;
+    {
+        ENTER(h);
+        (void)hipDeviceSynchronize();
+        drop_graphs(h);            // a captured step has the options it was captured with
+    }
+    if (std::strcmp(name, "graphs") == 0) {
+        h->use_graphs = value != 0 && h->gstream != nullptr;
+        return RVDD_OK;
+    }
     if (std::strcmp(name, "no_warp") == 0) {
         h->no_warp = value != 0;
         return RVDD_OK;
@@ -843,7 +892,7 @@ int rvdd_set_option(rvdd_t* h, const char* name, int32_t value) {
         h->force_wino = value == 2;
         return RVDD_OK;
     }
-    return fail(h, RVDD_ERR_ARG, "rvdd_set_option: unknown option '%s' (known: no_warp, warp_raw, prev_noisy_frame, conv_kernel, seq_major)", name);
+    return fail(h, RVDD_ERR_ARG, "rvdd_set_option: unknown option '%s' (known: no_warp, warp_raw, prev_noisy_frame, conv_kernel, seq_major, graphs)", name);
 }
 
 int rvdd_reset(rvdd_t* h) {
@@ -852,25 +901,21 @@ int rvdd_reset(rvdd_t* h) {
     return RVDD_OK;
 }
 
-int rvdd_step(rvdd_t* h, const float* raw_prev, const float* raw_cur, const float* raw_next,
-              const float* flow_prev, const float* flow_next, float* out_rgb, void* stream) {
-    if (!h) return RVDD_ERR_ARG;
-    ENTER(h);
-    if (!h->finalized) return fail(h, RVDD_ERR_STATE, "rvdd_step: weights not finalized");
+}  // extern "C"
+
+namespace {
+
+// Every launch of one frame-step, in order, on stream s.  `init` = first frame of a video.
+int enqueue_step(rvdd_t* h, const float* raw_prev, const float* raw_cur, const float* raw_next, const float* flow_prev,
+                 const float* flow_next, float* out_rgb, bool init, hipStream_t s) {
     const bool nw = h->no_warp;
-    if (!raw_cur || (!flow_prev && !nw) || !out_rgb) return fail(h, RVDD_ERR_ARG, "rvdd_step: raw_cur, flow_prev and out_rgb are required");
-    if (h->need_init && !raw_prev) return fail(h, RVDD_ERR_ARG, "rvdd_step: raw_prev is required on the first step of a video");
-    if (h->cfg.future && (!raw_next || (!flow_next && !nw))) return fail(h, RVDD_ERR_ARG, "rvdd_step: raw_next and flow_next are required when future=1");
-    if (nw) flow_prev = flow_next = nullptr;      // the flows are not looked at (the reference's dataset does not even load them)
-    hipStream_t s = static_cast<hipStream_t>(stream);
     const int B = h->cfg.batch, H = h->cfg.height, W = h->cfg.width;
     const size_t npix = (size_t)B * H * W;
-    if (h->need_init) {
+    if (init) {
         // lastden = n[:, :3] (demosaiced previous noisy frame), features = 0
         // (models/recurrent_model.py:233-245)
         HIPCHK(h, launch_demosaic(raw_prev, h->green, h->lastden4, B, H / 2, W / 2, (int64_t)H * W * 4, 4, 1, s));
         if (h->has_feat()) HIPCHK(h, hipMemsetAsync(h->lastfeat, 0, npix * kF * sizeof(float), s));
-        h->need_init = false;
     }
     // the stages in front of the net, for sequences [b0, b0 + nb) (run_convunet calls it per sequence when the
     // full-resolution stages run depth first)
@@ -924,6 +969,83 @@ int rvdd_step(rvdd_t* h, const float* raw_prev, const float* raw_cur, const floa
     if (rc == RVDD_OK && h->prev_noisy)     // store_frame = the noisy current frame (models/recurrent_model.py:335-337)
         HIPCHK(h, launch_demosaic(raw_cur, h->green, h->lastden4, B, H / 2, W / 2, (int64_t)H * W * 4, 4, 1, s));
     return rc;
+}
+
+constexpr size_t kMaxStepGraphs = 128;      // one per distinct set of caller buffers; least recently used goes first
+
+}  // namespace
+
+extern "C" {
+
+// A frame-step is ~30-45 launches.  The schedule is fixed by (configuration, options, first-frame flag) and the six
+// caller pointers, so each distinct pointer set can be captured once into a hipGraph (on a stream of the handle) and
+// replayed afterwards -- rvdd_set_option(h, "graphs", 1) or RVDD_GRAPH=1; the caller's stream is joined on both sides
+// with events, so stream order is what it would be launch by launch.  OFF by default: on ROCm 7.2 the replay is
+// SLOWER than the eager launches it replaces at every size measured (profiles/r02_e_hipgraph_step_ab.log: 256x256
+// B = 1 2110 vs 2440 frames/s, B = 4 5035 vs 5320; 720p B = 1 398.6 vs 404.5, B = 4 456.9 vs 459.4).  The eager path
+// is not host-bound -- launches are asynchronous and the queue stays full -- and kernel boundaries cost the same
+// either way, so a graph has only its own launch cost to add.  Parity is identical (the GPU suite passes in both modes).
+int rvdd_step(rvdd_t* h, const float* raw_prev, const float* raw_cur, const float* raw_next,
+              const float* flow_prev, const float* flow_next, float* out_rgb, void* stream) {
+    if (!h) return RVDD_ERR_ARG;
+    ENTER(h);
+    if (!h->finalized) return fail(h, RVDD_ERR_STATE, "rvdd_step: weights not finalized");
+    const bool nw = h->no_warp;
+    if (!raw_cur || (!flow_prev && !nw) || !out_rgb) return fail(h, RVDD_ERR_ARG, "rvdd_step: raw_cur, flow_prev and out_rgb are required");
+    if (h->need_init && !raw_prev) return fail(h, RVDD_ERR_ARG, "rvdd_step: raw_prev is required on the first step of a video");
+    if (h->cfg.future && (!raw_next || (!flow_next && !nw))) return fail(h, RVDD_ERR_ARG, "rvdd_step: raw_next and flow_next are required when future=1");
+    if (nw) flow_prev = flow_next = nullptr;      // the flows are not looked at (the reference's dataset does not even load them)
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const bool init = h->need_init;
+    h->need_init = false;
+    if (!h->use_graphs || h->prof_on || !h->ran_eagerly || !h->gstream) {
+        h->ran_eagerly = true;
+        return enqueue_step(h, raw_prev, raw_cur, raw_next, flow_prev, flow_next, out_rgb, init, s);
+    }
+    rvdd_handle::StepKey key{{init ? raw_prev : nullptr, raw_cur, raw_next, flow_prev, flow_next, out_rgb},
+                             (init ? 1 : 0) | (h->serpentine ? 2 : 0)};
+    auto it = h->graphs.find(key);
+    if (it == h->graphs.end()) {
+        hipGraph_t g = nullptr;
+        hipGraphExec_t ex = nullptr;
+        hipError_t e = hipStreamBeginCapture(h->gstream, hipStreamCaptureModeThreadLocal);
+        int rc = RVDD_OK;
+        if (e == hipSuccess) {
+            const bool serp = h->serpentine;
+            rc = enqueue_step(h, raw_prev, raw_cur, raw_next, flow_prev, flow_next, out_rgb, init, h->gstream);
+            h->serpentine = serp;                              // the replay below advances it
+            e = hipStreamEndCapture(h->gstream, &g);
+        }
+        if (e == hipSuccess && rc == RVDD_OK) e = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
+        if (e != hipSuccess || rc != RVDD_OK) {
+            // no graph for this process: say why once, run launch by launch from here on
+            if (g) (void)hipGraphDestroy(g);
+            (void)hipGetLastError();
+            h->use_graphs = 0;
+            if (rc != RVDD_OK) return rc;
+            return enqueue_step(h, raw_prev, raw_cur, raw_next, flow_prev, flow_next, out_rgb, init, s);
+        }
+        if (h->graphs.size() >= kMaxStepGraphs) {
+            auto old = h->graphs.begin();
+            for (auto jt = h->graphs.begin(); jt != h->graphs.end(); ++jt)
+                if (jt->second.last_use < old->second.last_use) old = jt;
+            (void)hipGraphExecDestroy(old->second.exec);
+            (void)hipGraphDestroy(old->second.graph);
+            h->graphs.erase(old);
+        }
+        rvdd_handle::StepGraph sg;
+        sg.graph = g;
+        sg.exec = ex;
+        it = h->graphs.emplace(key, sg).first;
+    }
+    it->second.last_use = ++h->graph_tick;
+    HIPCHK(h, hipEventRecord(h->g_in, s));
+    HIPCHK(h, hipStreamWaitEvent(h->gstream, h->g_in, 0));
+    HIPCHK(h, hipGraphLaunch(it->second.exec, h->gstream));
+    HIPCHK(h, hipEventRecord(h->g_out, h->gstream));
+    HIPCHK(h, hipStreamWaitEvent(s, h->g_out, 0));
+    if (seq_major_on(h)) h->serpentine = !h->serpentine;
+    return RVDD_OK;
 }
 
 int rvdd_get_state(rvdd_t* h, float* lastden, float* lastfeat, void* stream) {
