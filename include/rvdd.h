@@ -93,6 +93,15 @@ int rvdd_reset(rvdd_t* h);
 int rvdd_step(rvdd_t* h, const float* raw_prev, const float* raw_cur, const float* raw_next,
               const float* flow_prev, const float* flow_next, float* out_rgb, void* stream);
 
+/* rvdd_step on channel slices of the reference's own input tensors, without a copy: the model hands the net
+ * `n[:, 0:4]`, `n[:, 4:8]`, `n[:, 8:12]` of one [B,(2+f)*4,h,w] tensor and `flow[:, 0]`, `flow[:, 1]` of one
+ * [B,1+f,2,h,w] tensor (models/recurrent_model.py:299-324; data/infer4rec_dataset.py:226-230).  Each slice is dense
+ * inside a sequence ([4,h,w] / [2,h,w]) and `raw_batch_stride` / `flow_batch_stride` floats apart from one
+ * sequence to the next (0 = dense, i.e. 4hw / 2hw as rvdd_step assumes). */
+int rvdd_step_strided(rvdd_t* h, const float* raw_prev, const float* raw_cur, const float* raw_next,
+                      const float* flow_prev, const float* flow_next, int64_t raw_batch_stride,
+                      int64_t flow_batch_stride, float* out_rgb, void* stream);
+
 /* Recurrent state in the reference's layout, for get_current_features /
  * set_rec_features parity (networks/unet.py:814-818) and for tests.
  *   lastden  [B,3,H,W]; lastfeat [B,48,H,W] (NULL to skip either). */
@@ -175,6 +184,12 @@ int rvdd_srgb_metrics(rvdd_t* h, const uint8_t* a, const uint8_t* b, int32_t n, 
  *              Not defined with feature recurrence (the reference fails on the shapes there): error.
  *   "prev_noisy_frame" (--prev_noisy_frame, :33, :335-337): the frame handed to the next step as "previous" is the
  *              demosaiced NOISY current frame, not the denoised one (the feature recurrence is unaffected).
+ *   "conv_kernel": which kernel runs the 3x3 convs: 0 = by launch size (default), 1 = the direct kernel, 2 = the
+ *              Winograd kernel at every size (tests, A/B measurements).
+ *   "seq_major": 1 = the full-resolution stages of the convunet run one sequence at a time (measured slower; off).
+ *   "fuse_upsample": 0 = UpConv's bilinear x2 upsample runs as its own kernel instead of inside the Winograd patch
+ *              load of the conv behind it (default 1; same bits either way).
+ *   "graphs":   1 = frame-steps are captured into hipGraphs and replayed (measured slower on ROCm 7.2; off).
  * Unknown names are an error. */
 int rvdd_set_option(rvdd_t* h, const char* name, int32_t value);
 

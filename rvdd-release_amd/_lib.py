@@ -31,6 +31,7 @@ _PROTOS = {
     "rvdd_finalize_weights": (C.c_int, [_P]),
     "rvdd_reset": (C.c_int, [_P]),
     "rvdd_step": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P]),
+    "rvdd_step_strided": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int64, C.c_int64, _P, _P]),
     "rvdd_get_state": (C.c_int, [_P, _P, _P, _P]),
     "rvdd_set_state": (C.c_int, [_P, _P, _P, _P]),
     "rvdd_psnr_l1": (C.c_int, [_P, _P, _P, C.c_int64, C.POINTER(C.c_float), _P]),

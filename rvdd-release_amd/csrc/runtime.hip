@@ -88,6 +88,7 @@ struct rvdd_handle {
     bool no_warp = false;         // --no_warp (rvdd_set_option): previous output / features / next frame enter the net unwarped
     bool use_wino = true;         // 48->48 3x3 convs: Winograd F(2x2,3x3) (RVDD_CONV=direct selects the direct kernel)
     int seq_major = 0;            // 1 = full-resolution stages one sequence at a time (see seq_major_on)
+    bool fuse_upsample = true;    // UpConv's bilinear x2 inside the Winograd patch load (RVDD_FUSE_UPSAMPLE=0: separate kernel)
     bool serpentine = false;      // sequence order of the current frame-step (flips every step when seq_major is on)
     std::map<std::string, HostTensor> staged;
     std::vector<void*> allocs;
@@ -115,10 +116,12 @@ struct rvdd_handle {
     // hipGraph replay of a frame-step (see rvdd_step)
     struct StepKey {
         const void* p[6];
+        int64_t stride[2];
         int flags;
         bool operator<(const StepKey& o) const {
-            const int c = std::memcmp(p, o.p, sizeof p);
-            return c ? c < 0 : flags < o.flags;
+            if (const int c = std::memcmp(p, o.p, sizeof p)) return c < 0;
+            if (const int c = std::memcmp(stride, o.stride, sizeof stride)) return c < 0;
+            return flags < o.flags;
         }
     };
     struct StepGraph {
@@ -419,6 +422,7 @@ struct ConvCall {
     int Hout = 0, Wout = 0, oy = 0, ox = 0;
     float* out3_nchw = nullptr;    // EPI_RELU_OUT3 targets
     float* out3_nhwc4 = nullptr;
+    bool ups = false;        // `in` is the half-resolution map whose bilinear x2 upsample the conv reads (UpConv)
 };
 
 bool wino_applies(const rvdd_t* h, int H, int W) {
@@ -445,7 +449,8 @@ int run_conv(rvdd_t* h, const Conv3& L, const ConvCall& c, hipStream_t s, Sub su
     const int Ho = c.epi == EPI_POOL ? c.H / 2 : (c.Hout ? c.Hout : c.H), Wo = c.epi == EPI_POOL ? c.W / 2 : (c.Wout ? c.Wout : c.W);
     const size_t px_in = (size_t)sub.b0 * c.H * c.W, px_out = (size_t)sub.b0 * Ho * Wo;
     ConvArgs a{};
-    a.in = c.in + px_in * cin_in;
+    a.in = c.in + (c.ups ? px_in / 4 : px_in) * cin_in;
+    a.ups = c.ups ? 1 : 0;
     a.w = L.w[c.src];
     a.bias = L.bias;
     a.acc_in = c.acc_in ? c.acc_in + px_in * kF : nullptr;
@@ -480,9 +485,12 @@ int run_conv(rvdd_t* h, const Conv3& L, const ConvCall& c, hipStream_t s, Sub su
     a.out3_nchw = c.out3_nchw ? c.out3_nchw + px_in * 3 : nullptr;
     a.out3_nhwc4 = c.out3_nhwc4 ? c.out3_nhwc4 + px_in * 4 : nullptr;
     const bool c16_ok = cin != 48 && !c.acc_in && (c.epi == EPI_NONE || c.epi == EPI_RELU);
+    if (c.ups && !(cin == 48 && L.wu[c.src] && wino_applies(h, c.H, c.W)))
+        return fail(h, RVDD_ERR_STATE, "run_conv: the fused upsample exists in the Winograd kernel only");
+    if (c.ups) bytes -= px * 4.0 * 36.0;          // reads the quarter-size map
     if ((cin == 48 || c16_ok) && L.wu[c.src] && wino_applies(h, c.H, c.W)) {
         a.w = L.wu[c.src];
-        Scope sc(h, s, cin == 48 ? wino_name(c.epi, c.acc_in != nullptr)
+        Scope sc(h, s, c.ups ? "wino3x3_ups_kernel<1>" : cin == 48 ? wino_name(c.epi, c.acc_in != nullptr)
                                  : (c.epi == EPI_NONE ? "wino3x3_c16_kernel<0>" : "wino3x3_c16_kernel<1>"), flops, bytes);
         HIPCHK(h, launch_wino3x3(a, cin == 48 ? 48 : 16, c.epi, s));
         return RVDD_OK;
@@ -568,7 +576,10 @@ int run_convunet(rvdd_t* h, const float* netin, const float* featw, float* feat_
         const std::vector<Sub> one{all};
         for (const Sub sb : (hi == 0 ? subs : one)) {
             const size_t lo_px = (size_t)sb.b0 * lv[lo].H * lv[lo].W, hi_px = (size_t)sb.b0 * lv[hi].H * lv[hi].W;
-            {
+            // UpConv: bilinear x2, conv, ReLU (:137-142).  Where the Winograd kernel runs the conv, the interpolation
+            // happens in its patch load and the upsampled map is never written; elsewhere it is made first.
+            const bool fused = h->fuse_upsample && wino_applies(h, uh, uw);
+            if (!fused) {
                 Scope sc(h, s, "upsample2x_kernel", 0.0, (double)sb.nb * uh * uw * 192.0 * 1.25);
                 HIPCHK(h, launch_upsample2x(d + lo_px * kF, lv[hi].t[0] + (size_t)sb.b0 * uh * uw * kF, sb.nb, lv[lo].H, lv[lo].W, uh,
                                             uw, 0, 0, false, s));
@@ -576,7 +587,8 @@ int run_convunet(rvdd_t* h, const float* netin, const float* featw, float* feat_
             // conv + ReLU at the upsampled size, written into a map of the skip's size
             // (zero_pad_features, :151-170; identity when sizes agree)
             ConvCall c;
-            c.in = lv[hi].t[0]; c.out = lv[hi].t[1]; c.H = uh; c.W = uw; c.epi = EPI_RELU;
+            c.in = fused ? d : lv[hi].t[0]; c.ups = fused;
+            c.out = lv[hi].t[1]; c.H = uh; c.W = uw; c.epi = EPI_RELU;
             c.Hout = lv[hi].H; c.Wout = lv[hi].W;
             c.oy = (lv[hi].H - uh) / 2; c.ox = (lv[hi].W - uw) / 2;
             if (uh != lv[hi].H || uw != lv[hi].W)
@@ -664,7 +676,8 @@ int rvdd_create(const rvdd_cfg* cfg, rvdd_t** out) {
 
     rvdd_t* h = new rvdd_handle();
     h->cfg = *cfg;
-    if (const char* sm = std::getenv("RVDD_SEQ_MAJOR")) h->seq_major = std::atoi(sm) != 0;     // measurement switch
+    if (const char* sm = std::getenv("RVDD_SEQ_MAJOR")) h->seq_major = std::atoi(sm) != 0;     // measurement switches
+    if (const char* fu = std::getenv("RVDD_FUSE_UPSAMPLE")) h->fuse_upsample = std::atoi(fu) != 0;
     if (const char* cv = std::getenv("RVDD_CONV")) {     // direct | winograd (forced at every size) | anything else = auto
         h->use_wino = std::strcmp(cv, "direct") != 0;
         h->force_wino = std::strcmp(cv, "winograd") == 0;
@@ -878,6 +891,11 @@ int rvdd_set_option(rvdd_t* h, const char* name, int32_t value) {
         h->prev_noisy = value != 0;
         return RVDD_OK;
     }
+    if (std::strcmp(name, "fuse_upsample") == 0) {
+        // 0 = UpConv's bilinear x2 always as its own kernel (A/B reference of the fused Winograd patch load)
+        h->fuse_upsample = value != 0;
+        return RVDD_OK;
+    }
     if (std::strcmp(name, "seq_major") == 0) {
         // 1 = the full-resolution stages of the convunet run one sequence at a time (measured slower: see seq_major_on)
         if (value < 0 || value > 1) return fail(h, RVDD_ERR_ARG, "rvdd_set_option: seq_major must be 0 or 1");
@@ -892,7 +910,7 @@ int rvdd_set_option(rvdd_t* h, const char* name, int32_t value) {
         h->force_wino = value == 2;
         return RVDD_OK;
     }
-    return fail(h, RVDD_ERR_ARG, "rvdd_set_option: unknown option '%s' (known: no_warp, warp_raw, prev_noisy_frame, conv_kernel, seq_major, graphs)", name);
+    return fail(h, RVDD_ERR_ARG, "rvdd_set_option: unknown option '%s' (known: no_warp, warp_raw, prev_noisy_frame, conv_kernel, seq_major, graphs, fuse_upsample)", name);
 }
 
 int rvdd_reset(rvdd_t* h) {
@@ -907,20 +925,34 @@ namespace {
 
 // Every launch of one frame-step, in order, on stream s.  `init` = first frame of a video.
 int enqueue_step(rvdd_t* h, const float* raw_prev, const float* raw_cur, const float* raw_next, const float* flow_prev,
-                 const float* flow_next, float* out_rgb, bool init, hipStream_t s) {
+                 const float* flow_next, int64_t raw_stride, int64_t flow_stride, float* out_rgb, bool init, hipStream_t s) {
     const bool nw = h->no_warp;
     const int B = h->cfg.batch, H = h->cfg.height, W = h->cfg.width;
     const size_t npix = (size_t)B * H * W;
+    // sequences of the caller's raw / flow tensors that are not back to back (channel slices of a wider tensor):
+    // the stages that read them run once per sequence
+    const size_t rawf = raw_stride ? (size_t)raw_stride : (size_t)4 * (H / 2) * (W / 2);
+    const size_t flowf = flow_stride ? (size_t)flow_stride : (size_t)2 * (H / 2) * (W / 2);
+    const bool dense = rawf == (size_t)4 * (H / 2) * (W / 2) && flowf == (size_t)2 * (H / 2) * (W / 2);
+    const size_t img = (size_t)H * W;
+    auto per_sequence = [&](Sub sb, const std::function<int(Sub)>& f) -> int {
+        if (dense) return f(sb);
+        for (int b = sb.b0; b < sb.b0 + sb.nb; ++b) RC(f(Sub{b, 1}));
+        return RVDD_OK;
+    };
     if (init) {
         // lastden = n[:, :3] (demosaiced previous noisy frame), features = 0
         // (models/recurrent_model.py:233-245)
-        HIPCHK(h, launch_demosaic(raw_prev, h->green, h->lastden4, B, H / 2, W / 2, (int64_t)H * W * 4, 4, 1, s));
+        RC(per_sequence(Sub{0, B}, [&](Sub sb) -> int {
+            HIPCHK(h, launch_demosaic(raw_prev + sb.b0 * rawf, h->green + sb.b0 * img, h->lastden4 + sb.b0 * img * 4, sb.nb, H / 2,
+                                      W / 2, (int64_t)H * W * 4, 4, 1, s));
+            return RVDD_OK;
+        }));
         if (h->has_feat()) HIPCHK(h, hipMemsetAsync(h->lastfeat, 0, npix * kF * sizeof(float), s));
     }
     // the stages in front of the net, for sequences [b0, b0 + nb) (run_convunet calls it per sequence when the
     // full-resolution stages run depth first)
-    const size_t rawf = (size_t)4 * (H / 2) * (W / 2), flowf = (size_t)2 * (H / 2) * (W / 2), img = (size_t)H * W;
-    Prologue prologue = [&](Sub sb) -> int {
+    Prologue stages = [&](Sub sb) -> int {
         const size_t o = (size_t)sb.b0;
         const int n = sb.nb;
         const float* rc_ = raw_cur + o * rawf;
@@ -963,11 +995,16 @@ int enqueue_step(rvdd_t* h, const float* raw_prev, const float* raw_cur, const f
         }
         return RVDD_OK;
     };
+    Prologue prologue = [&](Sub sb) -> int { return per_sequence(sb, stages); };
     // without warping the previous features are read in place: the net consumes them in its first layer and only
     // its last one writes the new ones
     const int rc = run_net(h, h->netin, nw ? h->lastfeat : h->featw, h->lastfeat, out_rgb, h->lastden4, s, prologue);
     if (rc == RVDD_OK && h->prev_noisy)     // store_frame = the noisy current frame (models/recurrent_model.py:335-337)
-        HIPCHK(h, launch_demosaic(raw_cur, h->green, h->lastden4, B, H / 2, W / 2, (int64_t)H * W * 4, 4, 1, s));
+        RC(per_sequence(Sub{0, B}, [&](Sub sb) -> int {
+            HIPCHK(h, launch_demosaic(raw_cur + sb.b0 * rawf, h->green + sb.b0 * img, h->lastden4 + sb.b0 * img * 4, sb.nb, H / 2,
+                                      W / 2, (int64_t)H * W * 4, 4, 1, s));
+            return RVDD_OK;
+        }));
     return rc;
 }
 
@@ -987,9 +1024,21 @@ extern "C" {
 // either way, so a graph has only its own launch cost to add.  Parity is identical (the GPU suite passes in both modes).
 int rvdd_step(rvdd_t* h, const float* raw_prev, const float* raw_cur, const float* raw_next,
               const float* flow_prev, const float* flow_next, float* out_rgb, void* stream) {
+    return rvdd_step_strided(h, raw_prev, raw_cur, raw_next, flow_prev, flow_next, 0, 0, out_rgb, stream);
+}
+
+int rvdd_step_strided(rvdd_t* h, const float* raw_prev, const float* raw_cur, const float* raw_next,
+                      const float* flow_prev, const float* flow_next, int64_t raw_stride, int64_t flow_stride,
+                      float* out_rgb, void* stream) {
     if (!h) return RVDD_ERR_ARG;
     ENTER(h);
     if (!h->finalized) return fail(h, RVDD_ERR_STATE, "rvdd_step: weights not finalized");
+    {
+        const int64_t rd = (int64_t)4 * (h->cfg.height / 2) * (h->cfg.width / 2), fd = rd / 2;
+        if ((raw_stride && raw_stride < rd) || (flow_stride && flow_stride < fd))
+            return fail(h, RVDD_ERR_ARG, "rvdd_step_strided: a batch stride must be 0 (dense) or at least one sequence (%lld / %lld floats)",
+                        (long long)rd, (long long)fd);
+    }
     const bool nw = h->no_warp;
     if (!raw_cur || (!flow_prev && !nw) || !out_rgb) return fail(h, RVDD_ERR_ARG, "rvdd_step: raw_cur, flow_prev and out_rgb are required");
     if (h->need_init && !raw_prev) return fail(h, RVDD_ERR_ARG, "rvdd_step: raw_prev is required on the first step of a video");
@@ -1000,10 +1049,10 @@ int rvdd_step(rvdd_t* h, const float* raw_prev, const float* raw_cur, const floa
     h->need_init = false;
     if (!h->use_graphs || h->prof_on || !h->ran_eagerly || !h->gstream) {
         h->ran_eagerly = true;
-        return enqueue_step(h, raw_prev, raw_cur, raw_next, flow_prev, flow_next, out_rgb, init, s);
+        return enqueue_step(h, raw_prev, raw_cur, raw_next, flow_prev, flow_next, raw_stride, flow_stride, out_rgb, init, s);
     }
     rvdd_handle::StepKey key{{init ? raw_prev : nullptr, raw_cur, raw_next, flow_prev, flow_next, out_rgb},
-                             (init ? 1 : 0) | (h->serpentine ? 2 : 0)};
+                             {raw_stride, flow_stride}, (init ? 1 : 0) | (h->serpentine ? 2 : 0)};
     auto it = h->graphs.find(key);
     if (it == h->graphs.end()) {
         hipGraph_t g = nullptr;
@@ -1012,7 +1061,7 @@ int rvdd_step(rvdd_t* h, const float* raw_prev, const float* raw_cur, const floa
         int rc = RVDD_OK;
         if (e == hipSuccess) {
             const bool serp = h->serpentine;
-            rc = enqueue_step(h, raw_prev, raw_cur, raw_next, flow_prev, flow_next, out_rgb, init, h->gstream);
+            rc = enqueue_step(h, raw_prev, raw_cur, raw_next, flow_prev, flow_next, raw_stride, flow_stride, out_rgb, init, h->gstream);
             h->serpentine = serp;                              // the replay below advances it
             e = hipStreamEndCapture(h->gstream, &g);
         }
@@ -1023,7 +1072,7 @@ int rvdd_step(rvdd_t* h, const float* raw_prev, const float* raw_cur, const floa
             (void)hipGetLastError();
             h->use_graphs = 0;
             if (rc != RVDD_OK) return rc;
-            return enqueue_step(h, raw_prev, raw_cur, raw_next, flow_prev, flow_next, out_rgb, init, s);
+            return enqueue_step(h, raw_prev, raw_cur, raw_next, flow_prev, flow_next, raw_stride, flow_stride, out_rgb, init, s);
         }
         if (h->graphs.size() >= kMaxStepGraphs) {
             auto old = h->graphs.begin();

@@ -53,6 +53,8 @@ struct ConvArgs {
     int B, H, W;          // conv domain (input size = conv output size)
     int Hout, Wout;       // size of the map `out` points to
     int oy, ox;           // placement of the conv output inside it (zero_pad_features)
+    int ups;              // Winograd kernel, 48 -> 48, ReLU only: `in` is [B][H/2][W/2][48] and the conv input is its
+                          // bilinear x2 upsample (align_corners=False), interpolated in the patch load
     int tiles_x, tiles_y, ntiles;
     // EPI_RELU_OUT3: PostConvs[1] (networks/unet.py:713-720) fused into PostConvs[0]'s epilogue
     const float* w3;      // [3][48]

@@ -53,6 +53,12 @@ __device__ __forceinline__ f32x4 sub4(f32x4 a, f32x4 b) {
     return f32x4{lo[0], lo[1], hi[0], hi[1]};
 }
 
+// a * s + c with ONE rounding (the interpolation of the fused upsample: the same expression, written the same way, in
+// upsample2x_kernel of prestage.hip, so that both produce the same bits)
+__device__ __forceinline__ f32x4 fma4(f32x4 a, float s, f32x4 c) {
+    return __builtin_elementwise_fma(a, f32x4{s, s, s, s}, c);
+}
+
 // B^T d B in place on a 4x4 patch of float4 (p[y*4+x]), in 8 slices so that the caller can
 // spread it between MFMA groups: slices 0..3 = column pass (x = slice), 4..7 = row pass.
 __device__ __forceinline__ void transform_slice(f32x4 (&p)[16], int sl) {
@@ -77,7 +83,10 @@ struct UnitPos {
     int b, ty, tx;
 };
 
-template <int EPI, bool ACC_IN, int NJ>
+// UPS: the conv input is nn.Upsample(scale_factor=2, mode="bilinear") [align_corners=False] of the map `a.in`
+// points to ([B][H/2][W/2][48], networks/unet.py:113-118 UpConv): the 4x4 patch of a tile is interpolated in
+// registers from the 3x3 low-resolution pixels it depends on, the upsampled map is never written.
+template <int EPI, bool ACC_IN, int NJ, bool UPS = false>
 __device__ __forceinline__ void wino_body(const ConvArgs& a) {
     extern __shared__ __attribute__((aligned(16))) float U[];
     constexpr int CIN = 16 * NJ;          // channels per input pixel (NHWC); outputs and side inputs are always kF wide
@@ -142,6 +151,65 @@ __device__ __forceinline__ void wino_body(const ConvArgs& a) {
         }
     };
 
+    // ---- UPS: the 3x3 low-resolution pixels (rows ty-1..ty+1, columns tx-1..tx+1, indices clamped to the map as
+    // ATen's upsample_bilinear2d clamps them) behind a tile's 4x4 patch of the upsampled map
+    f32x4 lo[UPS ? 9 : 1];
+    auto load_lo = [&](const UnitPos& u, int j) {
+        const int hl = a.H >> 1, wl = a.W >> 1;
+        const float* img = a.in + (size_t)u.b * hl * wl * CIN;
+        unsigned off[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const int c = min(max(u.tx - 1 + d, 0), wl - 1);
+            off[d] = (unsigned)(c * (CIN * 4) + (16 * j + 4 * g) * 4);
+        }
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            // a tile row past the end of the map (the unit after the last one: its batch index is out of range too)
+            // reads nothing: zero records
+            const int yi = min(max(u.ty - 1 + r, 0), hl - 1);
+            __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+                (void*)(img + (ptrdiff_t)yi * wl * CIN), 0, u.ty < hl ? wl * CIN * 4 : 0, 0x00020000);
+#pragma unroll
+            for (int d = 0; d < 3; ++d) lo[r * 3 + d] = bload(rs, off[d]);
+        }
+    };
+    // Patch row pr / column pc of tile (ty, tx) is upsampled row 2 ty - 1 + pr / column 2 tx - 1 + pc:
+    //   pr 0: 0.75 d[i-1] + 0.25 d[i]   (the conv's zero padding when ty = 0)        i = ty, rows of `lo`: 0 = i-1, 1 = i, 2 = i+1
+    //   pr 1: 0.25 d[i-1] + 0.75 d[i]   (d[i] alone when ty = 0: the source index is clamped at 0 with weight 1)
+    //   pr 2: 0.75 d[i]   + 0.25 d[i+1]
+    //   pr 3: 0.25 d[i]   + 0.75 d[i+1] (zero padding when ty is the last row)
+    // the same along x; horizontal pass first, then vertical, as upsample2x_kernel (prestage.hip) evaluates it, so
+    // the fused conv and "upsample, then conv" see the same bits.
+    auto interp = [&](f32x4 (&p)[16], const UnitPos& u) {
+        const int hl = a.H >> 1, wl = a.W >> 1;
+        const bool x_first = u.tx == 0, x_last = u.tx >= wl - 1;
+        const float wx[4][2] = {{x_first ? 0.f : 0.75f, x_first ? 0.f : 0.25f},
+                                {x_first ? 0.f : 0.25f, x_first ? 1.f : 0.75f},
+                                {0.75f, 0.25f},
+                                {x_last ? 0.f : 0.25f, x_last ? 0.f : 0.75f}};
+        const bool y_first = u.ty == 0, y_last = u.ty >= hl - 1;
+        const float wy[4][2] = {{y_first ? 0.f : 0.75f, y_first ? 0.f : 0.25f},
+                                {y_first ? 0.f : 0.25f, y_first ? 1.f : 0.75f},
+                                {0.75f, 0.25f},
+                                {y_last ? 0.f : 0.25f, y_last ? 0.f : 0.75f}};
+        f32x4 hz[3][4];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int pc = 0; pc < 4; ++pc) {
+                const int c0 = pc < 2 ? 0 : 1;
+                hz[r][pc] = fma4(lo[r * 3 + c0 + 1], wx[pc][1], lo[r * 3 + c0] * wx[pc][0]);
+            }
+#pragma unroll
+        for (int pr = 0; pr < 4; ++pr)
+#pragma unroll
+            for (int pc = 0; pc < 4; ++pc) {
+                const int r0 = pr < 2 ? 0 : 1;
+                p[pr * 4 + pc] = fma4(hz[r0 + 1][pc], wy[pr][1], hz[r0][pc] * wy[pr][0]);
+            }
+    };
+
     const float* ub = U + lane * 4;     // lane-linear fragments: each ds_read_b128 lane group covers one bank row
     f32x4 pb[2][16];      // ping-pong patch buffers (raw patch -> transformed in place)
     f32x4 acc[16][3];
@@ -161,7 +229,8 @@ __device__ __forceinline__ void wino_body(const ConvArgs& a) {
         constexpr int J = decltype(JC)::value;
         constexpr int X = decltype(XC)::value;
         constexpr int Y = 1 - X;
-        load_patch(pb[Y], ld_u, ld_j);
+        if constexpr (UPS) load_lo(ld_u, ld_j);
+        else load_patch(pb[Y], ld_u, ld_j);
         f32x4 wq[2][3];
         // Position order: the accumulators that are SEEDED instead of zeroed come last, so that the
         // loads that seed them (issued at the start of the unit) have eleven steps to land:
@@ -180,6 +249,9 @@ __device__ __forceinline__ void wino_body(const ConvArgs& a) {
             if (st + 1 < 16) {
 #pragma unroll
                 for (int m = 0; m < 3; ++m) wq[(st + 1) & 1][m] = ldsA(J, ORD[st + 1], m);
+            }
+            if constexpr (UPS) {
+                if (st == 8) interp(pb[Y], ld_u);
             }
             if (st >= 8) transform_slice(pb[Y], st - 8);
             if (first && ACC_IN && (pos == 3 || pos == 12)) {
@@ -201,7 +273,12 @@ __device__ __forceinline__ void wino_body(const ConvArgs& a) {
     int unit = blockIdx.x;
     UnitPos cur, nxt;
     locate(unit, cur);
-    load_patch(pb[0], cur, 0);
+    if constexpr (UPS) {
+        load_lo(cur, 0);
+        interp(pb[0], cur);
+    } else {
+        load_patch(pb[0], cur, 0);
+    }
 #pragma unroll
     for (int sl = 0; sl < 8; ++sl) transform_slice(pb[0], sl);
 
@@ -355,12 +432,18 @@ template <int EPI>
 __global__ __launch_bounds__(256, 1) void wino3x3_c16_kernel(ConvArgs a) {
     wino_body<EPI, false, 1>(a);
 }
+// UpConv (networks/unet.py:88-147): bilinear x2 upsample fused into the patch load, conv, ReLU
+template <int EPI>
+__global__ __launch_bounds__(256, 1) void wino3x3_ups_kernel(ConvArgs a) {
+    wino_body<EPI, false, 3, true>(a);
+}
 
-template <int EPI, bool ACC_IN, int NJ>
+template <int EPI, bool ACC_IN, int NJ, bool UPS = false>
 hipError_t launch_w(const ConvArgs& a0, hipStream_t s) {
     static std::atomic<uint64_t> attr_done{0};
     void (*kern)(ConvArgs);
-    if constexpr (NJ == 3) kern = wino3x3_kernel<EPI, ACC_IN>;
+    if constexpr (UPS) kern = wino3x3_ups_kernel<EPI>;
+    else if constexpr (NJ == 3) kern = wino3x3_kernel<EPI, ACC_IN>;
     else kern = wino3x3_c16_kernel<EPI>;
     constexpr size_t U_LDS_BYTES = (size_t)u_floats(NJ) * 4;
     if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(kern), U_LDS_BYTES, attr_done); e != hipSuccess)
@@ -388,6 +471,11 @@ hipError_t launch_wino3x3(const ConvArgs& a, int cin, int epi, hipStream_t s) {
         return hipErrorInvalidValue;
     }
     if (cin != 48) return hipErrorInvalidValue;
+    if (a.ups) {       // a.in = the map to upsample, [B][H/2][W/2][48]
+        if (a.acc_in || epi != EPI_RELU || (a.H & 1) || (a.W & 1)) return hipErrorInvalidValue;
+        if ((size_t)a.Hout * a.Wout * kF * 4 >= 0x80000000ull) return hipErrorInvalidValue;
+        return launch_w<EPI_RELU, false, 3, true>(a, s);
+    }
     // stores and the side inputs (partial sums, residuals) address their map with one 32-bit byte offset whose
     // out-of-image sentinel is 2^31; the conv input is addressed per row and has no such limit
     if ((size_t)a.H * a.W * kF * 4 >= 0x80000000ull || (size_t)a.Hout * a.Wout * kF * 4 >= 0x80000000ull)

@@ -37,6 +37,27 @@ def _chk_dev(t: torch.Tensor, shape: Tuple[int, ...], name: str, device: Optiona
     return t if t.is_contiguous() else t.contiguous()
 
 
+def _batch_strided(t: Optional[torch.Tensor], shape: Tuple[int, ...], name: str, device: int):
+    """A [B,C,h,w] input of a step: dense inside a sequence, any stride from one sequence to the next (a channel
+    slice of the reference's `n` / `flow` tensors is exactly that).  -> (tensor, batch stride in floats); copies
+    only what is not laid out like that."""
+    if t is None:
+        return None, 0
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must be a GPU tensor (rvdd has no CPU path)")
+    if t.device.index != device:
+        raise RuntimeError(f"{name} lives on cuda:{t.device.index} but this runtime drives cuda:{device}")
+    if tuple(t.shape) != tuple(shape):
+        raise RuntimeError(f"{name} has shape {tuple(t.shape)}, expected {tuple(shape)}")
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"{name} must be float32")
+    C, h, w = shape[1:]
+    if t.stride()[1:] == (h * w, w, 1) and t.stride(0) >= C * h * w:
+        return t, t.stride(0)
+    t = t.contiguous()
+    return t, C * h * w
+
+
 class RvddRuntime:
     """One handle = one device, one (arch, future, B, H, W) configuration."""
 
@@ -96,23 +117,30 @@ class RvddRuntime:
     def step(self, raw_prev, raw_cur, raw_next, flow_prev, flow_next, out=None) -> torch.Tensor:
         B, H, W = self.B, self.H, self.W
         rs, fs = (B, 4, H // 2, W // 2), (B, 2, H // 2, W // 2)
-        raw_cur = _chk_dev(raw_cur, rs, "raw_cur", self.device)
         if getattr(self, "no_warp", False):
             flow_prev = flow_next = None
         elif flow_prev is None:
             raise RuntimeError("rvdd_step: flow_prev is required (no --no_warp option set on this runtime)")
-        flow_prev = None if flow_prev is None else _chk_dev(flow_prev, fs, "flow_prev", self.device)
-        raw_prev = None if raw_prev is None else _chk_dev(raw_prev, rs, "raw_prev", self.device)
-        raw_next = None if raw_next is None else _chk_dev(raw_next, rs, "raw_next", self.device)
-        flow_next = None if flow_next is None else _chk_dev(flow_next, fs, "flow_next", self.device)
+        raws = [_batch_strided(t, rs, n, self.device) for t, n in ((raw_prev, "raw_prev"), (raw_cur, "raw_cur"), (raw_next, "raw_next"))]
+        flows = [_batch_strided(t, fs, n, self.device) for t, n in ((flow_prev, "flow_prev"), (flow_next, "flow_next"))]
+        if raws[1][0] is None:
+            raise RuntimeError("rvdd_step: raw_cur is required")
+
+        def common_stride(items, dense):
+            strides = {st for t, st in items if t is not None}
+            if len(strides) > 1:        # slices of different tensors: fall back to dense copies
+                return [(None if t is None else t.contiguous(), dense) for t, _ in items], dense
+            return items, (strides.pop() if strides else dense)
+        raws, rstride = common_stride(raws, rs[1] * rs[2] * rs[3])
+        flows, fstride = common_stride(flows, fs[1] * fs[2] * fs[3])
         if out is None:
             out = torch.empty(B, 3, H, W, dtype=torch.float32, device=self._tdev)
         else:
             _chk_dev(out, (B, 3, H, W), "out", self.device)
             assert out.is_contiguous()
-        self._check(self.lib.rvdd_step(self.h, _ptr(raw_prev), _ptr(raw_cur), _ptr(raw_next),
-                                       _ptr(flow_prev), _ptr(flow_next), _ptr(out), self._stream()),
-                    "rvdd_step")
+        self._check(self.lib.rvdd_step_strided(self.h, _ptr(raws[0][0]), _ptr(raws[1][0]), _ptr(raws[2][0]),
+                                               _ptr(flows[0][0]), _ptr(flows[1][0]), rstride, fstride, _ptr(out),
+                                               self._stream()), "rvdd_step")
         return out
 
     def get_state(self, want_feat: bool = True):

@@ -222,6 +222,57 @@ def test_state_roundtrip_and_reset():
     assert torch.equal(o1, o1b)
 
 
+@pytest.mark.parametrize("B,H,W", [(1, 36, 52), (2, 72, 104), (1, 256, 256)])
+def test_fused_upsample_equals_upsample_then_conv(B, H, W):
+    """UpConv (networks/unet.py:88-147): the bilinear x2 upsample interpolated inside the Winograd patch load gives
+    the same bits as the upsample kernel followed by the conv (same operations in the same order), at sizes with
+    ragged tiles, clamped borders and the zero_pad_features placement."""
+    from rvdd_release_amd import synth
+    from rvdd_release_amd.runtime import RvddRuntime
+    sd = load_weights("recurrent-convunet+feat-iso3200")
+    seqs = [synth.make_sequence(3, H, W, iso=3200, seed=90 + b, device="cuda") for b in range(B)]
+    outs = []
+    for fused in (1, 0):
+        rt = RvddRuntime("convunet+feat", 0, B, H, W, 0)
+        rt.set_option("conv_kernel", 2)
+        rt.set_option("fuse_upsample", fused)
+        rt.load_state_dict(sd)
+        st = lambda f: torch.stack([f(s) for s in seqs], 0)
+        o = [rt.step(st(lambda s: s.raw[0]), st(lambda s: s.raw[1]), None, st(lambda s: s.flow_prev[1]), None).clone(),
+             rt.step(None, st(lambda s: s.raw[2]), None, st(lambda s: s.flow_prev[2]), None).clone()]
+        outs.append(o)
+        rt.close()
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+
+
+def test_step_on_channel_slices_without_copies():
+    """rvdd_step_strided: the model hands the runtime `n[:, 0:4]`, `n[:, 4:8]`, `n[:, 8:12]` and `flow[:, k]` of the
+    dataset's tensors; with B > 1 those are strided over the batch.  Same bits as the dense call, and no copy."""
+    from rvdd_release_amd import synth
+    from rvdd_release_amd.runtime import RvddRuntime, _batch_strided
+    sd = load_weights("recurrent-convunet+feat-future-iso12800")
+    B, H, W = 3, 40, 56
+    seqs = [synth.make_sequence(4, H, W, iso=12800, seed=80 + b, device="cuda") for b in range(B)]
+    n = torch.stack([torch.cat((s.raw[0], s.raw[1], s.raw[2]), 0) for s in seqs], 0)          # [B,12,h,w]
+    fl = torch.stack([torch.stack((s.flow_prev[1], s.flow_next[1]), 0) for s in seqs], 0)      # [B,2,2,h,w]
+    t, stride = _batch_strided(n[:, 4:8], (B, 4, H // 2, W // 2), "raw_cur", 0)
+    assert t.data_ptr() == n[:, 4:8].data_ptr() and stride == 12 * (H // 2) * (W // 2)       # a view, not a copy
+    outs = []
+    for dense in (False, True):
+        rt = RvddRuntime("convunet+feat", 1, B, H, W, 0)
+        rt.load_state_dict(sd)
+        c = (lambda x: x.contiguous()) if dense else (lambda x: x)
+        outs.append(rt.step(c(n[:, 0:4]), c(n[:, 4:8]), c(n[:, 8:12]), c(fl[:, 0]), c(fl[:, 1])).clone())
+        rt.close()
+    assert torch.equal(outs[0], outs[1])
+    rt = RvddRuntime("convunet", 0, 2, 32, 48, 0)
+    rt.load_state_dict(load_weights("recurrent-convunet-iso3200"))
+    z = torch.zeros(2, 4, 16, 24, device="cuda")
+    rc = rt.lib.rvdd_step_strided(rt.h, z.data_ptr(), z.data_ptr(), None, z.data_ptr(), None, 5, 0, z.data_ptr(), 0)
+    assert rc != 0 and b"batch stride" in rt.lib.rvdd_last_error(rt.h)
+
+
 def test_graph_replay_equals_eager():
     """rvdd_set_option("graphs", 1): frame-steps captured into hipGraphs and replayed (one graph per distinct set of
     caller buffers, the first frame of a video its own) give the same bits as launch-by-launch execution, across
