@@ -15,7 +15,7 @@ barrier/max that bracket it, one all-gather of the per-frame PSNR values
 afterwards and, with --collate-outputs, one all-gather of the output frames
 (timed on its own, outside the compute region).
 
-  N = 1   config C2 (the configuration the metric is quoted on), B = 4
+  N = 1   config C2 (the configuration the metric is quoted on), B = 8 sequences in lockstep
   N > 1   config C5 (B = 8 sequences of 90 frames per GPU: 64 sequences on 8 GPUs), weak scaling;
           --scaling strong fixes the total at --sequences (64) instead and runs each rank's share in groups of B
 
@@ -38,10 +38,10 @@ sys.path.insert(0, REPO)
 
 CONFIGS = {
     # name: (arch, weights stem, future, iso, H, W, T, default B, algorithmic GFLOP per output frame @ HxW)
-    "C1": ("convunet", "recurrent-convunet-iso3200", 0, 3200, 256, 256, 8, 4, 25.50),
-    "C2": ("convunet+feat", "recurrent-convunet+feat-iso3200", 0, 3200, 720, 1280, 30, 4, 435.025),
-    "C3": ("convunet+feat", "recurrent-convunet+feat-future-iso12800", 1, 12800, 720, 1280, 30, 4, 437.413),
-    "C4": ("next+feat", "recurrent-ConvNeXtUnet+feat-future-iso3200", 1, 3200, 720, 1280, 30, 4, 401.998),
+    "C1": ("convunet", "recurrent-convunet-iso3200", 0, 3200, 256, 256, 8, 8, 25.50),
+    "C2": ("convunet+feat", "recurrent-convunet+feat-iso3200", 0, 3200, 720, 1280, 30, 8, 435.025),
+    "C3": ("convunet+feat", "recurrent-convunet+feat-future-iso12800", 1, 12800, 720, 1280, 30, 8, 437.413),
+    "C4": ("next+feat", "recurrent-ConvNeXtUnet+feat-future-iso3200", 1, 3200, 720, 1280, 30, 8, 401.998),
     "C5": ("convunet+feat", "recurrent-convunet+feat-iso3200", 0, 3200, 720, 1280, 90, 8, 435.025),
 }
 DESCR = {

@@ -377,11 +377,11 @@ __global__ __launch_bounds__(192) void upsample2x_kernel(const float* __restrict
         const f32x4* s = reinterpret_cast<const f32x4*>(in) + (size_t)b * h * w * 12 + c4;
         const f32x4 v00 = s[(y0 * w + x0) * 12], v01 = s[(y0 * w + x1) * 12];
         const f32x4 v10 = s[(y1 * w + x0) * 12], v11 = s[(y1 * w + x1) * 12];
-        // horizontal pass, then vertical, each "a * wa, then one fused multiply-add": the expression of the fused
+        // vertical pass, then horizontal, each "a * wa, then one fused multiply-add": the expression of the fused
         // upsample in wino3x3.hip (`interp`), so that the two paths produce the same bits
         auto fma4 = [](f32x4 a, float s, f32x4 c) { return __builtin_elementwise_fma(a, f32x4{s, s, s, s}, c); };
-        const f32x4 h0 = fma4(v01, lx1, v00 * lx0), h1 = fma4(v11, lx1, v10 * lx0);
-        v = fma4(h1, ly1, h0 * ly0);
+        const f32x4 c0 = fma4(v10, ly1, v00 * ly0), c1 = fma4(v11, ly1, v01 * ly0);
+        v = fma4(c1, lx1, c0 * lx0);
     }
     reinterpret_cast<f32x4*>(out)[(((size_t)b * Hout + Y) * Wout + X) * 12 + c4] = v;
 }

@@ -110,6 +110,14 @@ __device__ __forceinline__ void wino_body(const ConvArgs& a) {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lds_void*)(U + k * 256), 16, (unsigned)(k * 1024 + lane * 16), 0, 0, 0);
         }
     }
+    // EPI_RELU_OUT3: the 1x1 conv's weights [3][48] and bias [3] behind the bank.  Read from global memory in the
+    // epilogue they sat behind the epilogue's own stores (loads and stores retire in order on one counter): every
+    // one of the 40 little loads waited for the stores before it, +190 us on a 616 us launch.
+    float* W3l = U + UF;
+    if constexpr (EPI == EPI_RELU_OUT3) {
+        if (tid < 3 * kF) W3l[tid] = a.w3[tid];
+        else if (tid < 3 * kF + 3) W3l[tid] = a.b3[tid - 3 * kF];
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
@@ -179,7 +187,7 @@ __device__ __forceinline__ void wino_body(const ConvArgs& a) {
     //   pr 1: 0.25 d[i-1] + 0.75 d[i]   (d[i] alone when ty = 0: the source index is clamped at 0 with weight 1)
     //   pr 2: 0.75 d[i]   + 0.25 d[i+1]
     //   pr 3: 0.25 d[i]   + 0.75 d[i+1] (zero padding when ty is the last row)
-    // the same along x; horizontal pass first, then vertical, as upsample2x_kernel (prestage.hip) evaluates it, so
+    // the same along x; vertical pass first, then horizontal, as upsample2x_kernel (prestage.hip) evaluates it, so
     // the fused conv and "upsample, then conv" see the same bits.
     auto interp = [&](f32x4 (&p)[16], const UnitPos& u) {
         const int hl = a.H >> 1, wl = a.W >> 1;
@@ -193,21 +201,19 @@ __device__ __forceinline__ void wino_body(const ConvArgs& a) {
                                 {y_first ? 0.f : 0.25f, y_first ? 1.f : 0.75f},
                                 {0.75f, 0.25f},
                                 {y_last ? 0.f : 0.25f, y_last ? 0.f : 0.75f}};
-        f32x4 hz[3][4];
+        // row by row, vertical pass first: three temporaries instead of twelve (the kernel has no registers to spare)
 #pragma unroll
-        for (int r = 0; r < 3; ++r)
+        for (int pr = 0; pr < 4; ++pr) {
+            const int r0 = pr < 2 ? 0 : 1;
+            f32x4 vt[3];
+#pragma unroll
+            for (int d = 0; d < 3; ++d) vt[d] = fma4(lo[(r0 + 1) * 3 + d], wy[pr][1], lo[r0 * 3 + d] * wy[pr][0]);
 #pragma unroll
             for (int pc = 0; pc < 4; ++pc) {
                 const int c0 = pc < 2 ? 0 : 1;
-                hz[r][pc] = fma4(lo[r * 3 + c0 + 1], wx[pc][1], lo[r * 3 + c0] * wx[pc][0]);
+                p[pr * 4 + pc] = fma4(vt[c0 + 1], wx[pc][1], vt[c0] * wx[pc][0]);
             }
-#pragma unroll
-        for (int pr = 0; pr < 4; ++pr)
-#pragma unroll
-            for (int pc = 0; pc < 4; ++pc) {
-                const int r0 = pr < 2 ? 0 : 1;
-                p[pr * 4 + pc] = fma4(hz[r0 + 1][pc], wy[pr][1], hz[r0][pc] * wy[pr][0]);
-            }
+        }
     };
 
     const float* ub = U + lane * 4;     // lane-linear fragments: each ds_read_b128 lane group covers one bank row
@@ -379,7 +385,7 @@ __device__ __forceinline__ void wino_body(const ConvArgs& a) {
                     if constexpr (EPI == EPI_RELU_OUT3) {
 #pragma unroll
                         for (int c = 0; c < 3; ++c) {
-                            const f32x4 w = *reinterpret_cast<const f32x4*>(a.w3 + c * kF + 16 * m + 4 * g);
+                            const f32x4 w = *reinterpret_cast<const f32x4*>(W3l + c * kF + 16 * m + 4 * g);
                             o3[q][c] += (v[0] * w[0] + v[1] * w[1]) + (v[2] * w[2] + v[3] * w[3]);
                         }
                     }
@@ -397,7 +403,7 @@ __device__ __forceinline__ void wino_body(const ConvArgs& a) {
                     float v = o3[q][c];
                     v += __shfl_xor(v, 16);
                     v += __shfl_xor(v, 32);
-                    t[c] = v + a.b3[c];
+                    t[c] = v + W3l[3 * kF + c];
                 }
                 const int yy = oy + (q >> 1), xx = ox + (q & 1);
                 if (g == 0 && yy < a.H && xx < a.W) {
@@ -445,7 +451,7 @@ hipError_t launch_w(const ConvArgs& a0, hipStream_t s) {
     if constexpr (UPS) kern = wino3x3_ups_kernel<EPI>;
     else if constexpr (NJ == 3) kern = wino3x3_kernel<EPI, ACC_IN>;
     else kern = wino3x3_c16_kernel<EPI>;
-    constexpr size_t U_LDS_BYTES = (size_t)u_floats(NJ) * 4;
+    constexpr size_t U_LDS_BYTES = (size_t)u_floats(NJ) * 4 + (EPI == EPI_RELU_OUT3 ? (3 * kF + 4) * 4 : 0);
     if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(kern), U_LDS_BYTES, attr_done); e != hipSuccess)
         return e;
     ConvArgs a = a0;
