@@ -216,11 +216,21 @@ __device__ __forceinline__ void wino_body(const ConvArgs& a) {
         }
     };
 
-    const float* ub = U + lane * 4;     // lane-linear fragments: each ds_read_b128 lane group covers one bank row
+    // lane-linear fragments: each ds_read_b128 lane group covers one bank row.  The bank spans 144 KiB, more than
+    // the 64 KiB a ds_read offset field reaches: three opaque LDS pointers (positions 0-6, 7-13, 14-15) keep every
+    // fragment address "register + immediate"; left to itself hipcc builds an address register per fragment beyond
+    // 64 KiB (76 v_add_u32 per unit, and the registers to hold them).
+    typedef __attribute__((address_space(3))) f32x4 lds_frag;
+    lds_frag* ubp[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        ubp[k] = (lds_frag*)U + lane + k * 7 * NJ * 3 * 64;
+        asm volatile("" : "+v"(ubp[k]));
+    }
     f32x4 pb[2][16];      // ping-pong patch buffers (raw patch -> transformed in place)
     f32x4 acc[16][3];
     auto ldsA = [&](int j, int pos, int m) {
-        return *reinterpret_cast<const f32x4*>(ub + ((pos * NJ + j) * 3 + m) * 256);
+        return ubp[pos / 7][(((pos % 7) * NJ + j) * 3 + m) * 64];
     };
 
     // One pipeline stage = chunk J of the current unit: 16 steps (positions) of 3 A fragments and

@@ -75,6 +75,51 @@ def test_ssim_analytic():
     assert abs(P.ssim(b, c) - np.mean(tot)) < 1e-10
 
 
+def _ssim_identities(ssim):
+    """Properties of the SSIM index (Wang, Bovik, Sheikh, Simoncelli 2004) in skimage's configuration: the pin that
+    is available here (scikit-image is not installed, the reference holds no SSIM fixture: parity with skimage itself
+    stays unpinned)."""
+    rng = np.random.default_rng(7)
+    a = rng.integers(20, 200, (26, 37, 3)).astype(np.uint8)
+    b = np.clip(a.astype(np.int32) + rng.integers(-25, 26, a.shape), 0, 255).astype(np.uint8)
+    sab = ssim(a, b)
+    assert abs(ssim(a, a) - 1.0) < 1e-12 and sab < 1.0                       # maximum 1, reached only at equality
+    assert abs(sab - ssim(b, a)) < 1e-12                                      # symmetry
+    assert abs(sab - ssim(a[::-1, ::-1].copy(), b[::-1, ::-1].copy())) < 1e-12   # the 7x7 window is symmetric
+    assert abs(sab - ssim(a.transpose(1, 0, 2).copy(), b.transpose(1, 0, 2).copy())) < 1e-12
+    per_channel = [ssim(a[..., c:c + 1].repeat(3, 2), b[..., c:c + 1].repeat(3, 2)) for c in range(3)]
+    assert abs(sab - np.mean(per_channel)) < 1e-12                            # multichannel = mean over the channels
+    # a constant shift leaves every (co)variance alone: the index reduces to the luminance term of the window means
+    c = 30
+    shifted = (a.astype(np.int32) + c).astype(np.uint8)                       # a <= 199: no saturation
+    C1 = (0.01 * 255) ** 2
+    want = []
+    for ch in range(3):
+        A = a[..., ch].astype(np.float64)
+        for y in range(3, A.shape[0] - 3):
+            for x in range(3, A.shape[1] - 3):
+                m = A[y - 3:y + 4, x - 3:x + 4].mean()
+                want.append((2 * m * (m + c) + C1) / (m * m + (m + c) ** 2 + C1))
+    assert abs(ssim(a, shifted) - np.mean(want)) < 1e-9
+    # contrast only: b = mean + k (a - mean) window-wise is not expressible in uint8; structure only: anticorrelated
+    # images score below uncorrelated ones
+    inv = (255 - a.astype(np.int32)).astype(np.uint8)
+    assert ssim(a, inv) < ssim(a, rng.integers(20, 200, a.shape).astype(np.uint8)) < sab
+
+
+def test_ssim_identities_oracle():
+    _ssim_identities(P.ssim)
+
+
+@pytest.mark.gpu
+def test_ssim_identities_hip():
+    from rvdd_release_amd.ppipe import srgb_metrics
+
+    def ssim(a, b):
+        return srgb_metrics(torch.from_numpy(a[None]).cuda(), torch.from_numpy(b[None]).cuda())[1][0]
+    _ssim_identities(ssim)
+
+
 def test_find_gains_table():
     from rvdd_release_amd.ppipe import find_gains, WHITE_BALANCE
     assert len(WHITE_BALANCE) == 30
