@@ -302,7 +302,12 @@ __device__ __forceinline__ float gelu_erf(float v) {
 // between MFMAs instead of two)
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f32x2 gelu_erf2(f32x2 v) {
-    const f32x2 t = {fminf(fabsf(v[0]), 6.36f), fminf(fabsf(v[1]), 6.36f)};
+    // min(|v|, 6.36) in ONE instruction each (the |.| source modifier): fminf(fabsf()) compiles to a canonicalising
+    // v_max_f32 |v|, |v| in front of the v_min_f32, 48 extra vector instructions per 16 pixels beside the MFMAs
+    f32x2 t;
+    const float cap = 6.36f;
+    asm("v_min_f32 %0, |%1|, %2" : "=v"(t[0]) : "v"(v[0]), "v"(cap));
+    asm("v_min_f32 %0, |%1|, %2" : "=v"(t[1]) : "v"(v[1]), "v"(cap));
     auto K = [](float c) { return f32x2{c, c}; };
     f32x2 p = K(-2.116853238476324e-06f);
     p = __builtin_elementwise_fma(p, t, K(3.1051968107931316e-05f));
