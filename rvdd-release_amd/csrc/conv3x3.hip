@@ -26,8 +26,9 @@
 // reads channels 16j+4g..+3 of its pixel with ONE ds_read_b128; MFMA number i
 // of that chunk consumes element i, i.e. k-slot g of MFMA i is channel
 // 16j+4g+i.  The weights are pre-arranged on the host (arrange_conv3x3,
-// runtime.hip) as [tap][j][cout][g][i] so that the matching A fragment is one
-// ds_read_b128 too and a wave's read covers a contiguous 1 KiB (conflict-free).
+// runtime.hip) as [tap][j][m][lane = 16g + cout&15][i] so that the matching A
+// fragment is one ds_read_b128 too, lane-linear: each of the four 16-lane groups
+// the read is served in covers one whole 256-B bank row (conflict-free).
 // Fragments for group n+1 are read while the 24 MFMAs of group n issue.
 #include "rvdd_internal.h"
 
@@ -164,7 +165,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_kernel(ConvArgs a) {
         // every wave is past the barrier that ended the previous tile: the other buffer is free
         if (tile + (int)gridDim.x < a.ntiles) issue_tile(tile + gridDim.x, Ibuf + (cur ^ 1) * G::I_FLOATS);
 
-        const float* wbase = Wl + lr * 16 + g * 4;
+        const float* wbase = Wl + lane * 4;      // lane-linear fragments: each ds_read_b128 lane group covers one bank row
         const float* ibase = Il + ((2 * wave) * IW + lr) * CIN + g * 4;
         f32x4 wa[2][3], xb[2][2];
         auto ld = [&](int grp, int slot) {

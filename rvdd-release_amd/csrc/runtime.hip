@@ -197,8 +197,8 @@ int upload(rvdd_t* h, float** dst, const std::vector<float>& v) {
     return RVDD_OK;
 }
 
-// OIHW [48][cin_total][3][3], channels [c0, c0+cn) -> [tap][j][cout][g][i] with
-// channel = c0 + 16j + 4g + i (zero beyond cn): the A-fragment order of conv3x3.hip.
+// OIHW [48][cin_total][3][3], channels [c0, c0+cn) -> [tap][j][m][lane = 16g + cout&15][i] with
+// channel = c0 + 16j + 4g + i (zero beyond cn): the A-fragment order of conv3x3.hip (lane-linear).
 std::vector<float> arrange_conv3x3(const HostTensor& t, int c0, int cn, int cin_pad) {
     const int cin_total = (int)t.shape[1];
     const int NJ = cin_pad / 16;
@@ -210,7 +210,7 @@ std::vector<float> arrange_conv3x3(const HostTensor& t, int c0, int cn, int cin_
                     for (int i = 0; i < 4; ++i) {
                         const int c = 16 * j + 4 * g + i;
                         if (c >= cn) continue;
-                        out[(((size_t)(tap * NJ + j) * 48 + co) * 4 + g) * 4 + i] =
+                        out[(((size_t)(tap * NJ + j) * 3 + co / 16) * 64 + g * 16 + co % 16) * 4 + i] =
                             t.data[(((size_t)co * cin_total + c0 + c) * 3 + tap / 3) * 3 + tap % 3];
                     }
     return out;

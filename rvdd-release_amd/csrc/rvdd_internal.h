@@ -44,7 +44,7 @@ enum ConvEpi { EPI_NONE = 0, EPI_RELU = 1, EPI_POOL = 2, EPI_RELU_ADD2 = 3, EPI_
 
 struct ConvArgs {
     const float* in;      // NHWC [B][H][W][CIN]
-    const float* w;       // arranged [9][CIN/16][48][16] (see arrange_conv3x3 in runtime.hip)
+    const float* w;       // arranged [9][CIN/16][3][64 lanes][4] (see arrange_conv3x3 / arrange_wino3x3 in runtime.hip)
     const float* bias;    // [48]   (ignored when acc_in != nullptr)
     const float* acc_in;  // NHWC48 [B][H][W] partial sums to start from, or nullptr
     const float* res1;    // EPI_RELU_ADD2: out = relu(conv) + res1 + res2
