@@ -273,6 +273,32 @@ def test_step_on_channel_slices_without_copies():
     assert rc != 0 and b"batch stride" in rt.lib.rvdd_last_error(rt.h)
 
 
+def test_two_devices_in_one_process():
+    """A process that drives two GPUs: per-device kernel attributes, every entry point on its handle's device
+    whatever the caller's current device is, and a tensor on the wrong device refused.  Needs two visible GPUs."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("one GPU visible")
+    from rvdd_release_amd import synth
+    from rvdd_release_amd.runtime import RvddRuntime
+    sd = load_weights("recurrent-convunet+feat-iso3200")
+    H, W = 64, 96
+    s = synth.make_sequence(3, H, W, seed=12)
+    outs = []
+    for dev in (0, 1):
+        rt = RvddRuntime("convunet+feat", 0, 1, H, W, dev)
+        rt.load_state_dict(sd)
+        torch.cuda.set_device(1 - dev)                           # the caller's current device is the OTHER one
+        d = f"cuda:{dev}"
+        o = rt.step(s.raw[0][None].to(d), s.raw[1][None].to(d), None, s.flow_prev[1][None].to(d), None)
+        assert torch.cuda.current_device() == 1 - dev            # and stays what it was
+        outs.append(o.cpu())
+        with pytest.raises(RuntimeError, match="lives on"):
+            rt.step(None, s.raw[2][None].to(f"cuda:{1 - dev}"), None, s.flow_prev[2][None].to(d), None)
+        rt.close()
+    torch.cuda.set_device(0)
+    assert torch.equal(outs[0], outs[1])
+
+
 def test_graph_replay_equals_eager():
     """rvdd_set_option("graphs", 1): frame-steps captured into hipGraphs and replayed (one graph per distinct set of
     caller buffers, the first frame of a video its own) give the same bits as launch-by-launch execution, across
