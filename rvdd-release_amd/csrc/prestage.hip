@@ -66,23 +66,11 @@ __global__ void ha_green_kernel(const float* __restrict__ raw, float* __restrict
     green[idx] = gval;
 }
 
-// algo2 (util/Hamilton_Adam_demo.py:145-172) for red (mode 1) and blue (mode 2)
-__global__ void ha_rb_kernel(const float* __restrict__ raw, const float* __restrict__ green,
-                             float* __restrict__ out, int n, int h, int w, int64_t bstride, int pstride,
-                             int cstride) {
-    const int H = 2 * h, W = 2 * w;
-    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (size_t)n * H * W) return;
-    const int x = idx % W;
-    const int y = (idx / W) % H;
-    const int b = idx / ((size_t)W * H);
-    Cfa c{raw + (size_t)b * 4 * h * w, h, w, H, W};
-    const float* gp = green + (size_t)b * H * W;
+// algo2 (util/Hamilton_Adam_demo.py:145-172) for red (k = 0) and blue (k = 1) at pixel (y, x); g0 = its green
+__device__ __forceinline__ void ha_red_blue(const Cfa& c, const float* __restrict__ gp, int H, int W, int y, int x, float g0,
+                                            float (&rb)[2]) {
     auto G = [&](int yy, int xx) { return gp[(size_t)clampi(yy, 0, H - 1) * W + clampi(xx, 0, W - 1)]; };
     const int site = ((y & 1) << 1) | (x & 1);   // 0 Gb(e,e) 1 B 2 R 3 Gr(o,o)
-    const float g0 = G(y, x);
-
-    float rb[2];
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
         const int own = k == 0 ? 2 : 1;          // the channel's own CFA site (R / B)
@@ -117,6 +105,22 @@ __global__ void ha_rb_kernel(const float* __restrict__ raw, const float* __restr
         }
         rb[k] = v;
     }
+}
+
+__global__ void ha_rb_kernel(const float* __restrict__ raw, const float* __restrict__ green,
+                             float* __restrict__ out, int n, int h, int w, int64_t bstride, int pstride,
+                             int cstride) {
+    const int H = 2 * h, W = 2 * w;
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)n * H * W) return;
+    const int x = idx % W;
+    const int y = (idx / W) % H;
+    const int b = idx / ((size_t)W * H);
+    Cfa c{raw + (size_t)b * 4 * h * w, h, w, H, W};
+    const float* gp = green + (size_t)b * H * W;
+    const float g0 = gp[(size_t)y * W + x];
+    float rb[2];
+    ha_red_blue(c, gp, H, W, y, x, g0, rb);
     float* o = out + (size_t)b * bstride + ((size_t)y * W + x) * pstride;
     o[0] = rb[0];
     o[cstride] = g0;
@@ -215,6 +219,57 @@ __global__ void warp3_kernel(const float* __restrict__ src4, const float* __rest
     o[0] = acc[0];
     o[1] = acc[1];
     o[2] = acc[2];
+}
+
+// The network input of a frame in ONE pass (models/recurrent_model.py:299-324): per pixel the bicubic warp of the
+// previous output (3 channels), the red / blue planes of the current frame's Hamilton-Adams demosaic (its green
+// plane comes from ha_green_kernel) and, with a future frame, the warp of the demosaicked next frame, written as the
+// pixel's whole NHWC16 vector -- three 16-B stores of full sectors.  Written by three kernels (red/blue, two warps)
+// every pixel's 64 bytes were touched three times with 12-B partial stores.  Same arithmetic as ha_rb_kernel and
+// warp3_kernel (the demosaic stays bit-exact).
+__device__ __forceinline__ f32x4 warp3_at(const f32x4* __restrict__ s, const float* __restrict__ flow_b, int h, int w, int H,
+                                          int W, int y, int x) {
+    if (!flow_b) return s[(size_t)y * W + x];          // --no_warp
+    float fx, fy;
+    flow_at(flow_b, h, w, H, W, y, x, fx, fy);
+    Taps t;
+    make_taps(fx, fy, x, y, H, W, t);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        f32x4 row = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) row = row + s[(size_t)t.yi[j] * W + t.xi[i]] * t.wx[i];
+        acc = acc + row * t.wy[j];
+    }
+    return acc;
+}
+
+__global__ __launch_bounds__(256) void netin_kernel(const float* __restrict__ raw_cur, const float* __restrict__ green,
+                                                    const float* __restrict__ prev4, const float* __restrict__ flow_prev,
+                                                    const float* __restrict__ next4, const float* __restrict__ flow_next,
+                                                    float* __restrict__ netin, int B, int h, int w) {
+    const int H = 2 * h, W = 2 * w;
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)B * H * W) return;
+    const int x = idx % W;
+    const int y = (idx / W) % H;
+    const int b = idx / ((size_t)W * H);
+    Cfa c{raw_cur + (size_t)b * 4 * h * w, h, w, H, W};
+    const float* gp = green + (size_t)b * H * W;
+    const float g0 = gp[(size_t)y * W + x];
+    float rb[2];
+    ha_red_blue(c, gp, H, W, y, x, g0, rb);
+    const f32x4 p = warp3_at(reinterpret_cast<const f32x4*>(prev4) + (size_t)b * H * W,
+                             flow_prev ? flow_prev + (size_t)b * 2 * h * w : nullptr, h, w, H, W, y, x);
+    f32x4 n = {0.f, 0.f, 0.f, 0.f};
+    if (next4)
+        n = warp3_at(reinterpret_cast<const f32x4*>(next4) + (size_t)b * H * W,
+                     flow_next ? flow_next + (size_t)b * 2 * h * w : nullptr, h, w, H, W, y, x);
+    f32x4* o = reinterpret_cast<f32x4*>(netin) + idx * 4;
+    o[0] = f32x4{p[0], p[1], p[2], rb[0]};
+    o[1] = f32x4{g0, rb[1], n[0], n[1]};
+    o[2] = f32x4{n[2], 0.f, 0.f, 0.f};
 }
 
 // grid = (ceil(W/32), H, B), 192 threads = 16 PAIRS of horizontally adjacent pixels x 12 float4 chunks.
@@ -547,6 +602,16 @@ hipError_t launch_warp3(const float* src4, const float* flow_raw, float* dst, in
     const size_t n = (size_t)B * H * W;
     hipLaunchKernelGGL(warp3_kernel, dim3(nblocks(n, 256)), dim3(256), 0, s, src4, flow_raw, dst, dpstride, B,
                        H, W);
+    return hipGetLastError();
+}
+
+hipError_t launch_netin(const float* raw_cur, float* green_scratch, const float* prev4, const float* flow_prev,
+                        const float* next4, const float* flow_next, float* netin, int B, int h, int w, hipStream_t s) {
+    const size_t n = (size_t)B * 4 * h * w;
+    if (!n) return hipSuccess;
+    hipLaunchKernelGGL(ha_green_kernel, dim3(nblocks(n, 256)), dim3(256), 0, s, raw_cur, green_scratch, B, h, w);
+    hipLaunchKernelGGL(netin_kernel, dim3(nblocks(n, 256)), dim3(256), 0, s, raw_cur, green_scratch, prev4, flow_prev, next4,
+                       flow_next, netin, B, h, w);
     return hipGetLastError();
 }
 

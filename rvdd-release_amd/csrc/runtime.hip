@@ -961,11 +961,11 @@ int enqueue_step(rvdd_t* h, const float* raw_prev, const float* raw_cur, const f
         const float* fn_ = flow_next ? flow_next + o * flowf : nullptr;
         float* green = h->green + o * img;
         float* netin = h->netin + o * img * kNetInC;
-        {
-            Scope sc(h, s, "demosaic(ha_green+ha_rb)", 0.0, (double)n * img * 16.0);
-            HIPCHK(h, launch_demosaic(rc_, green, netin + 3, n, H / 2, W / 2, (int64_t)H * W * kNetInC, kNetInC, 1, s));
-        }
         if (h->warp_raw && !nw) {
+            {
+                Scope sc(h, s, "demosaic(ha_green+ha_rb)", 0.0, (double)n * img * 16.0);
+                HIPCHK(h, launch_demosaic(rc_, green, netin + 3, n, H / 2, W / 2, (int64_t)H * W * kNetInC, kNetInC, 1, s));
+            }
             // warp_frame with --warp_raw (models/recurrent_model.py:149-152): HA(warp(remosaick(frame), raw-resolution flow)).
             // remosaick(HA(raw)) is raw itself, so the next frame is warped as it came.  next4 is free in this mode: its
             // first quarter holds the re-mosaicked previous output, the second the warped planes.
@@ -979,15 +979,15 @@ int enqueue_step(rvdd_t* h, const float* raw_prev, const float* raw_cur, const f
                 HIPCHK(h, launch_demosaic(warped, green, netin + 6, n, H / 2, W / 2, (int64_t)H * W * kNetInC, kNetInC, 1, s));
             }
         } else {
-            {
-                Scope sc(h, s, "warp3_kernel", 0.0, (double)n * img * 32.0);
-                HIPCHK(h, launch_warp3(h->lastden4 + o * img * 4, fp_, netin + 0, kNetInC, n, H, W, s));
-            }
+            // the whole NHWC16 input pixel in one pass: warp of the previous output | demosaic of the current frame |
+            // warp of the demosaicked next frame
+            float* next4 = nullptr;
             if (h->cfg.future) {
-                float* next4 = h->next4 + o * img * 4;
+                next4 = h->next4 + o * img * 4;
                 HIPCHK(h, launch_demosaic(rn_, green, next4, n, H / 2, W / 2, (int64_t)H * W * 4, 4, 1, s));
-                HIPCHK(h, launch_warp3(next4, fn_, netin + 6, kNetInC, n, H, W, s));
             }
+            Scope sc(h, s, "netin(ha_green+netin_kernel)", 0.0, (double)n * img * (16.0 + 16.0 + 48.0 + (next4 ? 16.0 : 0.0)));
+            HIPCHK(h, launch_netin(rc_, green, h->lastden4 + o * img * 4, fp_, next4, fn_, netin, n, H / 2, W / 2, s));
         }
         if (h->has_feat() && !nw) {
             Scope sc(h, s, "warp48_kernel", 0.0, (double)n * img * (384.0 + 2.0));

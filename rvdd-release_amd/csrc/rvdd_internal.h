@@ -81,6 +81,10 @@ hipError_t launch_demosaic(const float* raw, float* green_scratch, float* out, i
 // align_corners=True, times 2, fused).  src NHWC4 -> dst[(b*H*W + p)*dpstride + c], c<3.
 hipError_t launch_warp3(const float* src4, const float* flow_raw, float* dst, int dpstride, int B,
                         int H, int W, hipStream_t s);
+// The NHWC16 network input of a step in one pass: warp3 of prev4 | demosaic of raw_cur | warp3 of next4 (or zeros when
+// next4 == nullptr); flows nullptr = --no_warp.  Dense [B][4][h][w] raw, [B][2][h][w] flows; green_scratch [B][2h][2w].
+hipError_t launch_netin(const float* raw_cur, float* green_scratch, const float* prev4, const float* flow_prev,
+                        const float* next4, const float* flow_next, float* netin, int B, int h, int w, hipStream_t s);
 // src NHWC48 -> dst NHWC48.
 hipError_t launch_warp48(const float* src, const float* flow_raw, float* dst, int B, int H, int W,
                          hipStream_t s);
