@@ -486,6 +486,30 @@ def test_batch_of_four_720p_invariants():
         assert torch.equal(four_s[t], four[t])
 
 
+def test_1080p_frame_vs_oracle():
+    """1920x1080, B = 2, at full scale: the levels are 1080 / 540 / 270 / 135 rows by 1920 / 960 / 480 / 240 columns,
+    so the Winograd tiles (8x32 pixels) are ragged in y at every level below the first and in x AND y at the 1/8
+    level, which runs the Winograd kernel at this batch.  One step: sequence 0 against the oracle, both deterministic."""
+    from rvdd_release_amd import synth
+    from rvdd_release_amd.runtime import RvddRuntime
+    sd = load_weights("recurrent-convunet+feat-iso3200")
+    H, W = 1080, 1920
+    seqs = [synth.make_sequence(2, H, W, iso=3200, seed=5000 + b, device="cuda") for b in range(2)]
+    st = lambda f: torch.stack([f(s) for s in seqs], 0)
+    outs = []
+    for _ in range(2):
+        rt = RvddRuntime("convunet+feat", 0, 2, H, W, 0)
+        rt.load_state_dict(sd)
+        outs.append(rt.step(st(lambda s: s.raw[0]), st(lambda s: s.raw[1]), None, st(lambda s: s.flow_prev[1]), None).clone())
+        rt.close()
+    assert torch.equal(outs[0], outs[1])
+    c = lambda x: x[None].cpu()
+    s0 = seqs[0]
+    want = O.RecurrentOracle(sd, future=0).step(c(s0.raw[0]), c(s0.raw[1]), None, c(s0.flow_prev[1]), None, first=True)[0]
+    got = outs[0][0].cpu()
+    assert (got - want).abs().max() < 1e-4 and parity_psnr(got, want) > 120.0, float((got - want).abs().max())
+
+
 def test_4k_frame_borders():
     """A frame above 5.59 Mpx (one 48-channel map > 2^30 bytes): the padding-1 border of the 3x3 convs comes from
     the buffer range check, which must hold whatever the size of the map.  One step of config C2's net on a
