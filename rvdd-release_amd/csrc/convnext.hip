@@ -272,67 +272,75 @@ __global__ __launch_bounds__(256, 2) void dwln_kernel(const float* __restrict__ 
 // ---------------------------------------------------------------------- MLP --
 // LDS: fc1 arranged [j(3)][m(12)][lane = 16g+lr][i] = W1[16m+lr][16j+4g+i]     (9216 floats)
 //      fc2 arranged [m(12)][mo(3)][lane = 16g+lr][r] = W2[16mo+lr][16m+4g+r]   (9216 floats)
+//      fc1_b (192) | fc2_b (48) | layerscale (48)
 constexpr int M_W_FLOATS = 192 * 48;
-constexpr size_t M_LDS_BYTES = (size_t)2 * M_W_FLOATS * 4;
-constexpr int M_NPB = 1;                       // 16-pixel groups per wave iteration
-
-// nn.GELU() default = exact erf form (networks/new_unet.py:94): 0.5 v (1 + erf(v/sqrt2)).
-// On gfx950 the f32 MFMA and the VALU share the SIMD's fp32 lanes, so the 192 GELUs per pixel are not
-// hidden behind the MFMAs: this single-branch form costs 16 instructions instead of 27 for a
-// two-branch <1-ulp erf (and ocml's erff, inlined 48x per lane, spilled 260 registers).  erf(v/sqrt2) = sign(v) (1 - 2^(t P(t))), t = min(|v|, 6.36), P a
-// degree-7 polynomial fitted (weighted least squares, host, float32 Horner) to log2 erfc(t/sqrt2)/t:
-// max |GELU error| 4.3e-7 on [-9, 9] against the double-precision erf form (fp32 rounding of the
-// exact form is ~2e-7 there).
-__device__ __forceinline__ float gelu_erf(float v) {
-    const float t = fminf(fabsf(v), 6.36f);
-    float p = -2.116853238476324e-06f;
-    p = fmaf(p, t, 3.1051968107931316e-05f);
-    p = fmaf(p, t, -0.0001479804632253945f);
-    p = fmaf(p, t, -0.00022579463256988674f);
-    p = fmaf(p, t, 0.007174866273999214f);
-    p = fmaf(p, t, -0.05256997048854828f);
-    p = fmaf(p, t, -0.45918503403663635f);
-    p = fmaf(p, t, -1.1511077880859375f);
-    const float e = copysignf(1.0f - __builtin_amdgcn_exp2f(t * p), v);
-    const float hv = 0.5f * v;
-    return fmaf(hv, e, hv);
-}
-// the same function on two values at once: the polynomial and the two products on v_pk_fma_f32 / v_pk_mul_f32
-// (bit-identical results; a packed op occupies the fp32 lanes as long as two scalar ones, but takes one issue slot
-// between MFMAs instead of two)
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ f32x2 gelu_erf2(f32x2 v) {
-    // min(|v|, 6.36) in ONE instruction each (the |.| source modifier): fminf(fabsf()) compiles to a canonicalising
-    // v_max_f32 |v|, |v| in front of the v_min_f32, 48 extra vector instructions per 16 pixels beside the MFMAs
-    f32x2 t;
-    const float cap = 6.36f;
-    asm("v_min_f32 %0, |%1|, %2" : "=v"(t[0]) : "v"(v[0]), "v"(cap));
-    asm("v_min_f32 %0, |%1|, %2" : "=v"(t[1]) : "v"(v[1]), "v"(cap));
-    auto K = [](float c) { return f32x2{c, c}; };
-    f32x2 p = K(-2.116853238476324e-06f);
-    p = __builtin_elementwise_fma(p, t, K(3.1051968107931316e-05f));
-    p = __builtin_elementwise_fma(p, t, K(-0.0001479804632253945f));
-    p = __builtin_elementwise_fma(p, t, K(-0.00022579463256988674f));
-    p = __builtin_elementwise_fma(p, t, K(0.007174866273999214f));
-    p = __builtin_elementwise_fma(p, t, K(-0.05256997048854828f));
-    p = __builtin_elementwise_fma(p, t, K(-0.45918503403663635f));
-    p = __builtin_elementwise_fma(p, t, K(-1.1511077880859375f));
-    const f32x2 tp = t * p;
-    const f32x2 e = {copysignf(1.0f - __builtin_amdgcn_exp2f(tp[0]), v[0]), copysignf(1.0f - __builtin_amdgcn_exp2f(tp[1]), v[1])};
-    const f32x2 hv = v * K(0.5f);
-    return __builtin_elementwise_fma(hv, e, hv);
+
+// Two waves per SIMD (NW = 8 per workgroup, one workgroup per CU), each covering its own latencies.  Round 1's
+// kernel leant on three waves per SIMD to hide its loads, but on gfx950 the f32 MFMA and the VALU share the SIMD's
+// fp32 lanes, and a VALU instruction issued by ANOTHER wave among f32 MFMAs costs 7-40 cycles against 4.25 from the
+// wave's own stream (profiles/r02_mfma_valu_microbench.log): the GELUs of one wave stalled the MFMAs of the other
+// two.  Here a wave software-pipelines itself: the LayerNorm rows of its NEXT pixel group are requested before
+// fc1, the residual rows before fc2, weight fragments and biases are read from LDS one step ahead (across the
+// phases too), and the GELU of a pair of hidden blocks runs after the first MFMAs of the next pair.
+// SQ counters (profiles/r02_k_mlp_*): the wave is never idle - MFMA 76 %, GELU 14 %, waits 10 % of its cycles.
+typedef __attribute__((address_space(3))) f32x4 lds_frag;
+constexpr int M2_BV_FLOATS = 192 + 48 + 48;                       // fc1_b | fc2_b | layerscale
+constexpr size_t M2_LDS_BYTES = 84 * 1024;                        // 73.1 KiB used; past half of the CU's 160 KiB = one workgroup per CU
+
+__device__ __forceinline__ f32x4 bload(__amdgpu_buffer_rsrc_t r, unsigned off) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
+}
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void bstore(__amdgpu_buffer_rsrc_t r, unsigned off, f32x4 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, off, 0, 0);
 }
 
-__global__ __launch_bounds__(768) void mlp_kernel(const float* __restrict__ ln, const float* __restrict__ x,
-                                                     const float* __restrict__ fc1_w,
-                                                     const float* __restrict__ fc1_b,
-                                                     const float* __restrict__ fc2_w,
-                                                     const float* __restrict__ fc2_b,
-                                                     const float* __restrict__ ls, float* __restrict__ out,
-                                                     long npix) {
+// GELU(v) = v Phi(v) = max(v, 0) - |v| Phi(-|v|), Phi(-t) = erfc(t / sqrt2) / 2 = 2^(t P(t) - 1): P of degree 5,
+// a weighted minimax fit (host, Lawson iterations) of log2 erfc(t / sqrt2) / t on [0, 6.36] (beyond it the term is
+// below 1e-9).  max |error| 3.1e-7 on [-9, 9] in this float32 evaluation against the double-precision erf form;
+// 8 scalar (two of them v_exp_f32) + 6 packed instructions per two values; round 1's 0.5 v (1 + erf) form with a
+// degree-7 polynomial took 6 + 11.
+__device__ __forceinline__ f32x4 gelu_phi4(f32x4 v) {
+    // two packed Horner chains side by side: a v_pk_fma_f32 that reads the result of the one before it costs a
+    // wait state
+    const float cap = 6.36f, zero = 0.0f;
+    f32x2 t[2], p[2], q[2];
+    f32x4 relu, o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        // |.| as a source modifier, and no canonicalising v_max in front (fminf / fmaxf emit one)
+        asm("v_min_f32 %0, |%1|, %2" : "=v"(t[k >> 1][k & 1]) : "v"(v[k]), "v"(cap));
+        asm("v_max_f32 %0, %1, %2" : "=v"(relu[k]) : "v"(v[k]), "v"(zero));
+    }
+    auto K = [](float c) { return f32x2{c, c}; };
+    constexpr float C[6] = {2.992418740177527e-05f, -0.0007398742018267512f, 0.007977462373673916f,
+                            -0.05323818698525429f, -0.45891568064689636f, -1.1511471271514893f};
+    p[0] = p[1] = K(C[0]);
+#pragma unroll
+    for (int i = 1; i < 6; ++i) {
+        p[0] = __builtin_elementwise_fma(p[0], t[0], K(C[i]));
+        p[1] = __builtin_elementwise_fma(p[1], t[1], K(C[i]));
+    }
+    q[0] = __builtin_elementwise_fma(t[0], p[0], K(-1.0f));
+    q[1] = __builtin_elementwise_fma(t[1], p[1], K(-1.0f));
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o[k] = fmaf(-fabsf(v[k]), __builtin_amdgcn_exp2f(q[k >> 1][k & 1]), relu[k]);
+    return o;
+}
+
+template <int NPB, int NW>
+__global__ __launch_bounds__(64 * NW, NPB == 2 ? 1 : 8 / NW) void mlp_kernel(const float* __restrict__ ln, const float* __restrict__ x,
+                                                         const float* __restrict__ fc1_w,
+                                                         const float* __restrict__ fc1_b,
+                                                         const float* __restrict__ fc2_w,
+                                                         const float* __restrict__ fc2_b,
+                                                         const float* __restrict__ ls, float* __restrict__ out,
+                                                         long npix) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* W1 = smem;
     float* W2 = smem + M_W_FLOATS;
+    float* BV = smem + 2 * M_W_FLOATS;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -340,101 +348,153 @@ __global__ __launch_bounds__(768) void mlp_kernel(const float* __restrict__ ln, 
     {
         __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc((void*)fc1_w, 0, M_W_FLOATS * 4, 0x00020000);
         __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc((void*)fc2_w, 0, M_W_FLOATS * 4, 0x00020000);
-        const int nw = blockDim.x >> 6;
-        for (int k = wave; k < M_W_FLOATS / 256; k += nw) {
+        for (int k = wave; k < M_W_FLOATS / 256; k += NW) {
             dma16(r1, W1 + k * 256, (unsigned)(k * 1024 + lane * 16));
             dma16(r2, W2 + k * 256, (unsigned)(k * 1024 + lane * 16));
         }
+        for (int i = tid; i < M2_BV_FLOATS; i += 64 * NW)
+            BV[i] = i < 192 ? fc1_b[i] : (i < 240 ? fc2_b[i - 192] : ls[i - 240]);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    const float* w1b = W1 + lane * 4;      // lane-linear fragments: each ds_read_b128 lane group covers one bank row
-    const float* w2b = W2 + lane * 4;
-    const long nblk = (npix + 16 * M_NPB - 1) / (16 * M_NPB);
-    const long wave_global = (long)blockIdx.x * (blockDim.x >> 6) + wave;
-    const long nwaves = (long)gridDim.x * (blockDim.x >> 6);
-    for (long blk = wave_global; blk < nblk; blk += nwaves) {
-        long pix[M_NPB];
-        f32x4 xb[M_NPB][3];
+    // lane-linear fragments behind opaque LDS pointers: every read is "register + immediate"
+    lds_frag* w1p = (lds_frag*)W1 + lane;
+    lds_frag* w2p = (lds_frag*)W2 + lane;
+    lds_frag* bvp = (lds_frag*)BV + g;
+    asm volatile("" : "+v"(w1p), "+v"(w2p), "+v"(bvp));
+    auto F1 = [&](int j, int m) { return w1p[(j * 12 + m) * 64]; };
+    auto F2 = [&](int m, int mo) { return w2p[(m * 3 + mo) * 64]; };
+
+    constexpr int GP = 16 * NPB;                                  // pixels per wave iteration
+    const long nblk = (npix + GP - 1) / GP;
+    const long nwaves = (long)gridDim.x * NW;
+    const unsigned lane_off = (unsigned)(lr * (kF * 4) + g * 16);
+    // rows of a map that belong to block `blk`: a descriptor over exactly those pixels (none past the end of the
+    // map: loads return zeros there and stores are dropped), so no offset depends on the size of the map
+    auto rows = [&](const float* base, long blk) {
+        const long first = blk * GP, rem = npix - first;
+        const int recs = rem <= 0 ? 0 : (int)(rem < GP ? rem : GP) * (kF * 4);
+        return __builtin_amdgcn_make_buffer_rsrc((void*)(base + first * kF), 0, recs, 0x00020000);
+    };
+    auto load_rows = [&](f32x4 (&q)[NPB][3], const float* base, long blk) {
+        __amdgpu_buffer_rsrc_t r = rows(base, blk);
 #pragma unroll
-        for (int n = 0; n < M_NPB; ++n) {
-            pix[n] = (blk * M_NPB + n) * 16 + lr;
-            const long pc = pix[n] < npix ? pix[n] : npix - 1;
+        for (int n = 0; n < NPB; ++n)
 #pragma unroll
-            for (int j = 0; j < 3; ++j) xb[n][j] = *reinterpret_cast<const f32x4*>(ln + pc * kF + 16 * j + 4 * g);
-        }
-        // ---- fc1 + bias + GELU: hid[m][n][r] = hidden channel 16m+4g+r of pixel lr of group n.
-        // Two hidden blocks at a time: two independent accumulator chains per pixel group cover
-        // the 40-cycle dependent latency of the 32-cycle MFMA.
-        f32x4 hid[12][M_NPB];
+            for (int j = 0; j < 3; ++j) q[n][j] = bload(r, lane_off + (unsigned)(n * 16 * kF * 4 + 64 * j));
+    };
+    auto gelu_pair = [&](f32x4 (&h)[12][NPB], int m) {
 #pragma unroll
-        for (int m = 0; m < 12; m += 2) {
-            const f32x4 b1a = *reinterpret_cast<const f32x4*>(fc1_b + 16 * m + 4 * g);
-            const f32x4 b1b = *reinterpret_cast<const f32x4*>(fc1_b + 16 * (m + 1) + 4 * g);
+        for (int k = 0; k < 2; ++k)
 #pragma unroll
-            for (int n = 0; n < M_NPB; ++n) {
-                hid[m][n] = b1a;
-                hid[m + 1][n] = b1b;
-            }
+            for (int n = 0; n < NPB; ++n) h[m + k][n] = gelu_phi4(h[m + k][n]);
+    };
+
+    long blk = (long)blockIdx.x * NW + wave;
+    f32x4 xc[NPB][3], xn[NPB][3], xr[NPB][3];
+    load_rows(xc, ln, blk);
+    // hipcc's wait-count bookkeeping joins this path with the loop's back edge: rows still in flight here would
+    // become a "wait for all but the newest six" at the top of EVERY iteration, which also waits for the stores of
+    // the iteration before (vmcnt counts loads and stores in order)
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(xc[0][0]), "+v"(xc[0][1]), "+v"(xc[0][2]));
+    // Everything that comes from LDS is read one step before its use, across the phases too: the first fc2
+    // fragments and biases during the last fc1 step, the first fc1 fragments and biases of the NEXT iteration and the
+    // layerscale during the last fc2 step (an exposed ds_read_b128 costs the lone wave ~150 cycles; there were 11).
+    f32x4 wq[2][2], b1n[2];
+    wq[0][0] = F1(0, 0);
+    wq[0][1] = F1(0, 1);
+    b1n[0] = bvp[0];
+    b1n[1] = bvp[4];
+    for (; blk < nblk; blk += nwaves) {
+        load_rows(xn, ln, blk + nwaves);
+        // ---- fc1 (+bias) in 18 steps = (pair of hidden blocks m, m+1) x (input chunk j): two independent
+        // accumulator chains per pixel group
+        f32x4 hid[12][NPB];
+        f32x4 acc[3][NPB];
+        f32x4 vq[2][3];
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                const f32x4 wa0 = *reinterpret_cast<const f32x4*>(w1b + (j * 12 + m) * 256);
-                const f32x4 wa1 = *reinterpret_cast<const f32x4*>(w1b + (j * 12 + m + 1) * 256);
+        for (int st = 0; st < 18; ++st) {
+            const int m = 2 * (st / 3), j = st % 3;
+            if (j == 0) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int n = 0; n < M_NPB; ++n) {
-                        hid[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa0[i], xb[n][j][i], hid[m][n], 0, 0, 0);
-                        hid[m + 1][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa1[i], xb[n][j][i], hid[m + 1][n], 0, 0, 0);
-                    }
-            }
-#pragma unroll
-            for (int n = 0; n < M_NPB; ++n)
-#pragma unroll
-                for (int r = 0; r < 4; r += 2) {
-                    const f32x2 a = gelu_erf2(f32x2{hid[m][n][r], hid[m][n][r + 1]});
-                    const f32x2 c = gelu_erf2(f32x2{hid[m + 1][n][r], hid[m + 1][n][r + 1]});
-                    hid[m][n][r] = a[0];
-                    hid[m][n][r + 1] = a[1];
-                    hid[m + 1][n][r] = c[0];
-                    hid[m + 1][n][r + 1] = c[1];
+                for (int n = 0; n < NPB; ++n) {
+                    hid[m][n] = b1n[0];
+                    hid[m + 1][n] = b1n[1];
                 }
-            __builtin_amdgcn_sched_barrier(0);   // keep hipcc from hoisting every fragment read (it spills)
-        }
-        // ---- fc2: the hidden accumulators are the B fragments (k-slot g of step (m,r) = 16m+4g+r)
-        f32x4 acc[3][M_NPB];
-#pragma unroll
-        for (int mo = 0; mo < 3; ++mo) {
-            const f32x4 b2 = *reinterpret_cast<const f32x4*>(fc2_b + 16 * mo + 4 * g);
-#pragma unroll
-            for (int n = 0; n < M_NPB; ++n) acc[mo][n] = b2;
-        }
-#pragma unroll
-        for (int m = 0; m < 12; ++m)
-#pragma unroll
-            for (int mo = 0; mo < 3; ++mo) {
-                const f32x4 wa = *reinterpret_cast<const f32x4*>(w2b + (m * 3 + mo) * 256);
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-#pragma unroll
-                    for (int n = 0; n < M_NPB; ++n)
-                        acc[mo][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[r], hid[m][n][r], acc[mo][n], 0, 0, 0);
-                if (mo == 2) __builtin_amdgcn_sched_barrier(0);
             }
-        // ---- out = x + layerscale * r
-#pragma unroll
-        for (int n = 0; n < M_NPB; ++n) {
-            if (pix[n] < npix) {
+            if (st + 1 < 18) {
+                wq[(st + 1) & 1][0] = F1((st + 1) % 3, 2 * ((st + 1) / 3));
+                wq[(st + 1) & 1][1] = F1((st + 1) % 3, 2 * ((st + 1) / 3) + 1);
+                if (j == 2) {
+                    b1n[0] = bvp[4 * (m + 2)];
+                    b1n[1] = bvp[4 * (m + 3)];
+                }
+            } else {
 #pragma unroll
                 for (int mo = 0; mo < 3; ++mo) {
-                    const size_t o = (size_t)pix[n] * kF + 16 * mo + 4 * g;
-                    const f32x4 xv = *reinterpret_cast<const f32x4*>(x + o);
-                    const f32x4 lv = *reinterpret_cast<const f32x4*>(ls + 16 * mo + 4 * g);
-                    *reinterpret_cast<f32x4*>(out + o) = xv + lv * acc[mo][n];
+                    vq[0][mo] = F2(0, mo);
+                    const f32x4 b2 = bvp[48 + 4 * mo];
+#pragma unroll
+                    for (int n = 0; n < NPB; ++n) acc[mo][n] = b2;
                 }
             }
+            if (j == 1 && m >= 2) gelu_pair(hid, m - 2);          // the previous pair, its MFMAs long retired
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int n = 0; n < NPB; ++n) {
+                    hid[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[st & 1][0][i], xc[n][j][i], hid[m][n], 0, 0, 0);
+                    hid[m + 1][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[st & 1][1][i], xc[n][j][i], hid[m + 1][n], 0, 0, 0);
+                }
+            __builtin_amdgcn_sched_barrier(0);
         }
+        // ---- fc2 in 12 steps (hidden block m), three output blocks each: the hidden accumulators are the B
+        // fragments (k-slot g of step (m, r) = hidden channel 16m+4g+r); consecutive MFMAs rotate over the three
+        // output blocks, so none waits for its own predecessor.  The residual rows are requested first; the last
+        // pair's GELU runs after the first hidden block has been consumed.
+        load_rows(xr, x, blk);
+        f32x4 lv[3];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < 12; ++m) {
+            if (m + 1 < 12) {
+#pragma unroll
+                for (int mo = 0; mo < 3; ++mo) vq[(m + 1) & 1][mo] = F2(m + 1, mo);
+            } else {
+                wq[0][0] = F1(0, 0);
+                wq[0][1] = F1(0, 1);
+                b1n[0] = bvp[0];
+                b1n[1] = bvp[4];
+#pragma unroll
+                for (int mo = 0; mo < 3; ++mo) lv[mo] = bvp[60 + 4 * mo];
+            }
+            if (m == 1) gelu_pair(hid, 10);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int n = 0; n < NPB; ++n)
+#pragma unroll
+                    for (int mo = 0; mo < 3; ++mo)
+                        acc[mo][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(vq[m & 1][mo][r], hid[m][n][r], acc[mo][n], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // ---- out = x + layerscale * r
+        {
+            __amdgpu_buffer_rsrc_t ro = rows(out, blk);
+#pragma unroll
+            for (int mo = 0; mo < 3; ++mo)
+#pragma unroll
+                for (int n = 0; n < NPB; ++n)
+                    bstore(ro, lane_off + (unsigned)(n * 16 * kF * 4 + 64 * mo), xr[n][mo] + lv[mo] * acc[mo][n]);
+        }
+#pragma unroll
+        for (int n = 0; n < NPB; ++n)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) xc[n][j] = xn[n][j];
     }
 }
 
@@ -489,18 +549,17 @@ hipError_t launch_next_dwln(const float* x, float* ln_out, const NextBlockW& w, 
 
 hipError_t launch_next_mlp(const float* ln, const float* x, float* out, const NextBlockW& w, int64_t npix,
                            hipStream_t s) {
-    static std::atomic<uint64_t> attr{0};
-    if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(mlp_kernel), M_LDS_BYTES, attr); e != hipSuccess)
-        return e;
+    // one 16-pixel group per wave iteration, eight waves per workgroup: measured against <2, 4> and <1, 4>
+    // (profiles/r02_k_mlp_variants.json)
+    constexpr int NPB = 1, NW = 8;
     if (npix <= 0) return hipSuccess;
-    const long nblk = (npix + 16 * M_NPB - 1) / (16 * M_NPB);
-    // one workgroup of 12 waves per CU: three waves per SIMD share one LDS copy of the two weight matrices
-    constexpr int kMlpWaves = 12;
-    long blocks = (nblk + kMlpWaves - 1) / kMlpWaves;
-    const long cap = (long)num_cus();
-    if (blocks > cap) blocks = cap;
-    hipLaunchKernelGGL(mlp_kernel, dim3((unsigned)blocks), dim3(64 * kMlpWaves), M_LDS_BYTES, s, ln, x, w.fc1_w, w.fc1_b, w.fc2_w,
-                       w.fc2_b, w.ls, out, (long)npix);
+    static std::atomic<uint64_t> attr{0};
+    if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(mlp_kernel<NPB, NW>), M2_LDS_BYTES, attr); e != hipSuccess)
+        return e;
+    const long nblk = (npix + 16 * NPB - 1) / (16 * NPB);
+    const long blocks = std::min<long>((nblk + NW - 1) / NW, num_cus());
+    hipLaunchKernelGGL((mlp_kernel<NPB, NW>), dim3((unsigned)blocks), dim3(64 * NW), M2_LDS_BYTES, s, ln, x, w.fc1_w, w.fc1_b,
+                       w.fc2_w, w.fc2_b, w.ls, out, (long)npix);
     return hipGetLastError();
 }
 
