@@ -229,6 +229,7 @@ __device__ __forceinline__ void wino_body(const ConvArgs& a) {
     }
     f32x4 pb[2][16];      // ping-pong patch buffers (raw patch -> transformed in place)
     f32x4 acc[16][3];
+    f32x4 wq[2][3];       // A fragments: the step in flight and the one after it
     auto ldsA = [&](int j, int pos, int m) {
         return ubp[pos / 7][(((pos % 7) * NJ + j) * 3 + m) * 64];
     };
@@ -247,7 +248,6 @@ __device__ __forceinline__ void wino_body(const ConvArgs& a) {
         constexpr int Y = 1 - X;
         if constexpr (UPS) load_lo(ld_u, ld_j);
         else load_patch(pb[Y], ld_u, ld_j);
-        f32x4 wq[2][3];
         // Position order: the accumulators that are SEEDED instead of zeroed come last, so that the
         // loads that seed them (issued at the start of the unit) have eleven steps to land:
         //   position (1,1) <- bias:        A^T M A with only M11 = b is b on all four outputs;
@@ -255,17 +255,16 @@ __device__ __forceinline__ void wino_body(const ConvArgs& a) {
         //   convs): M00 = P00, M03 = -P01, M30 = -P10, M33 = P11 give exactly Y += P.
         // Neither costs an epilogue add.
         constexpr int ORD[16] = {1, 2, 4, 6, 7, 8, 9, 10, 11, 13, 14, 5, 0, 3, 12, 15};
-#pragma unroll
-        for (int m = 0; m < 3; ++m) wq[0][m] = ldsA(J, ORD[0], m);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int st = 0; st < 16; ++st) {
             const int pos = ORD[st];
             const bool seeded = ACC_IN ? (pos == 0 || pos == 3 || pos == 12 || pos == 15) : pos == 5;
-            if (st + 1 < 16) {
+            // the fragments of the step after this one; the last step reads the first fragments of the NEXT stage
+            // (chunks follow each other 0, 1, 2, 0, ...), so that no stage opens on an exposed LDS read
 #pragma unroll
-                for (int m = 0; m < 3; ++m) wq[(st + 1) & 1][m] = ldsA(J, ORD[st + 1], m);
-            }
+            for (int m = 0; m < 3; ++m)
+                wq[(st + 1) & 1][m] = st + 1 < 16 ? ldsA(J, ORD[st + 1], m) : ldsA((J + 1) % NJ, ORD[0], m);
             if constexpr (UPS) {
                 if (st == 8) interp(pb[Y], ld_u);
             }
@@ -297,6 +296,8 @@ __device__ __forceinline__ void wino_body(const ConvArgs& a) {
     }
 #pragma unroll
     for (int sl = 0; sl < 8; ++sl) transform_slice(pb[0], sl);
+#pragma unroll
+    for (int m = 0; m < 3; ++m) wq[0][m] = ldsA(0, 1, m);      // position ORD[0] of chunk 0: the first step of the first stage
 
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
