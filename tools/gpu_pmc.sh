@@ -1,6 +1,7 @@
 #!/bin/bash
 # One rocprofv3 --pmc pass per GROUP of counters (groups separated by ':', counters inside a group by ',';
-# a group must fit the block's slots: 8 SQ counters, FETCH_SIZE alone, WRITE_SIZE alone).
+# a group must fit the block's slots: 8 SQ counters, two of TA / TCP / TCC, FETCH_SIZE alone, WRITE_SIZE alone --
+# "Request exceeds the capabilities of the hardware" otherwise, after which rocprofv3 hangs until the timeout).
 # usage (GPU box, repo root): bash tools/gpu_pmc.sh <tag> "<group>:<group>..." <bench args...>
 set -o pipefail
 TAG=$1; GROUPS_=$2; shift 2
@@ -13,7 +14,7 @@ rc=0; i=0
 IFS=':' read -ra GS <<< "$GROUPS_"
 for G in "${GS[@]}"; do
   i=$((i+1))
-  timeout -k 10 400 rocprofv3 --pmc ${G//,/ } --output-format csv -d $OUT/g$i -- $BENCH > $OUT/g$i.log 2>&1 || { rc=$?; tail -5 $OUT/g$i.log; break; }
+  timeout -k 10 ${PMC_TIMEOUT:-240} rocprofv3 --pmc ${G//,/ } --output-format csv -d $OUT/g$i -- $BENCH > $OUT/g$i.log 2>&1 || { rc=$?; tail -5 $OUT/g$i.log; break; }
 done
 ls $OUT | head -20
 exit $rc
