@@ -486,26 +486,35 @@ def test_batch_of_four_720p_invariants():
         assert torch.equal(four_s[t], four[t])
 
 
-def test_1080p_frame_vs_oracle():
+@pytest.mark.parametrize("arch,stem,fut", [
+    ("convunet+feat", "recurrent-convunet+feat-iso3200", 0),
+    ("next+feat", "recurrent-ConvNeXtUnet+feat-future-iso3200", 1),
+])
+def test_1080p_frame_vs_oracle(arch, stem, fut):
     """1920x1080, B = 2, at full scale: the levels are 1080 / 540 / 270 / 135 rows by 1920 / 960 / 480 / 240 columns,
     so the Winograd tiles (8x32 pixels) are ragged in y at every level below the first and in x AND y at the 1/8
-    level, which runs the Winograd kernel at this batch.  One step: sequence 0 against the oracle, both deterministic."""
+    level, which runs the Winograd kernel at this batch; for ConvNeXtUnet the 16x16 tiles of the depth-wise kernel are
+    ragged at every level and the 135-row level is zero-padded against its 136-row skip (new_unet.py:56-66).
+    One step: sequence 0 against the oracle, both deterministic."""
     from rvdd_release_amd import synth
     from rvdd_release_amd.runtime import RvddRuntime
-    sd = load_weights("recurrent-convunet+feat-iso3200")
+    sd = load_weights(stem)
     H, W = 1080, 1920
-    seqs = [synth.make_sequence(2, H, W, iso=3200, seed=5000 + b, device="cuda") for b in range(2)]
+    seqs = [synth.make_sequence(3, H, W, iso=3200, seed=5000 + b, device="cuda") for b in range(2)]
     st = lambda f: torch.stack([f(s) for s in seqs], 0)
+    nxt = (lambda f: st(f)) if fut else (lambda f: None)
     outs = []
     for _ in range(2):
-        rt = RvddRuntime("convunet+feat", 0, 2, H, W, 0)
+        rt = RvddRuntime(arch, fut, 2, H, W, 0)
         rt.load_state_dict(sd)
-        outs.append(rt.step(st(lambda s: s.raw[0]), st(lambda s: s.raw[1]), None, st(lambda s: s.flow_prev[1]), None).clone())
+        outs.append(rt.step(st(lambda s: s.raw[0]), st(lambda s: s.raw[1]), nxt(lambda s: s.raw[2]), st(lambda s: s.flow_prev[1]),
+                            nxt(lambda s: s.flow_next[1])).clone())
         rt.close()
     assert torch.equal(outs[0], outs[1])
     c = lambda x: x[None].cpu()
     s0 = seqs[0]
-    want = O.RecurrentOracle(sd, future=0).step(c(s0.raw[0]), c(s0.raw[1]), None, c(s0.flow_prev[1]), None, first=True)[0]
+    want = O.RecurrentOracle(sd, future=fut).step(c(s0.raw[0]), c(s0.raw[1]), c(s0.raw[2]) if fut else None, c(s0.flow_prev[1]),
+                                                  c(s0.flow_next[1]) if fut else None, first=True)[0]
     got = outs[0][0].cpu()
     assert (got - want).abs().max() < 1e-4 and parity_psnr(got, want) > 120.0, float((got - want).abs().max())
 
