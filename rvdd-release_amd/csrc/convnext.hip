@@ -329,14 +329,24 @@ __device__ __forceinline__ f32x4 gelu_phi4(f32x4 v) {
     return o;
 }
 
-template <int NPB, int NW>
+// OUT3: the network's last block also applies the 1x1 conv 48 -> 3 of the post-processing (new_unet.py:414-430) to the
+// map it has just formed, instead of a kernel that reads the 48-channel map back: each lane multiplies its 12 channels,
+// two shuffles sum the four channel groups of a pixel, lane group 0 stores the planar frame and the NHWC4 copy.
+struct Out3 {
+    const float* w;        // [3][48]
+    const float* b;        // [3]
+    float* nchw;           // [B][3][hw] or null
+    float* nhwc4;          // [B][hw][4] or null
+    int hw;                // pixels per image
+};
+template <int NPB, int NW, bool OUT3>
 __global__ __launch_bounds__(64 * NW, NPB == 2 ? 1 : 8 / NW) void mlp_kernel(const float* __restrict__ ln, const float* __restrict__ x,
                                                          const float* __restrict__ fc1_w,
                                                          const float* __restrict__ fc1_b,
                                                          const float* __restrict__ fc2_w,
                                                          const float* __restrict__ fc2_b,
                                                          const float* __restrict__ ls, float* __restrict__ out,
-                                                         long npix) {
+                                                         long npix, Out3 o3) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* W1 = smem;
     float* W2 = smem + M_W_FLOATS;
@@ -354,6 +364,9 @@ __global__ __launch_bounds__(64 * NW, NPB == 2 ? 1 : 8 / NW) void mlp_kernel(con
         }
         for (int i = tid; i < M2_BV_FLOATS; i += 64 * NW)
             BV[i] = i < 192 ? fc1_b[i] : (i < 240 ? fc2_b[i - 192] : ls[i - 240]);
+        if constexpr (OUT3) {
+            for (int i = tid; i < 147; i += 64 * NW) BV[M2_BV_FLOATS + i] = i < 144 ? o3.w[i] : o3.b[i - 144];
+        }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -485,11 +498,45 @@ __global__ __launch_bounds__(64 * NW, NPB == 2 ? 1 : 8 / NW) void mlp_kernel(con
         // ---- out = x + layerscale * r
         {
             __amdgpu_buffer_rsrc_t ro = rows(out, blk);
+            float part[NPB][3];
+#pragma unroll
+            for (int n = 0; n < NPB; ++n) part[n][0] = part[n][1] = part[n][2] = 0.f;
 #pragma unroll
             for (int mo = 0; mo < 3; ++mo)
 #pragma unroll
-                for (int n = 0; n < NPB; ++n)
-                    bstore(ro, lane_off + (unsigned)(n * 16 * kF * 4 + 64 * mo), xr[n][mo] + lv[mo] * acc[mo][n]);
+                for (int n = 0; n < NPB; ++n) {
+                    const f32x4 v = xr[n][mo] + lv[mo] * acc[mo][n];
+                    bstore(ro, lane_off + (unsigned)(n * 16 * kF * 4 + 64 * mo), v);
+                    if constexpr (OUT3) {
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) {
+                            const f32x4 w = bvp[M2_BV_FLOATS / 4 + c * 12 + 4 * mo];     // w[c][16 mo + 4 g ..]
+                            part[n][c] += (v[0] * w[0] + v[1] * w[1]) + (v[2] * w[2] + v[3] * w[3]);
+                        }
+                    }
+                }
+            if constexpr (OUT3) {
+#pragma unroll
+                for (int n = 0; n < NPB; ++n) {
+                    float t[3];
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        float v = part[n][c];
+                        v += __shfl_xor(v, 16);
+                        v += __shfl_xor(v, 32);
+                        t[c] = v + BV[M2_BV_FLOATS + 144 + c];
+                    }
+                    const long pix = (blk * NPB + n) * 16 + lr;
+                    if (g == 0 && pix < npix) {
+                        const long b = pix / o3.hw, p = pix - b * o3.hw;
+                        if (o3.nchw) {
+#pragma unroll
+                            for (int c = 0; c < 3; ++c) o3.nchw[(b * 3 + c) * o3.hw + p] = t[c];
+                        }
+                        if (o3.nhwc4) reinterpret_cast<f32x4*>(o3.nhwc4)[pix] = f32x4{t[0], t[1], t[2], 0.f};
+                    }
+                }
+            }
         }
 #pragma unroll
         for (int n = 0; n < NPB; ++n)
@@ -547,20 +594,32 @@ hipError_t launch_next_dwln(const float* x, float* ln_out, const NextBlockW& w, 
     return hipGetLastError();
 }
 
-hipError_t launch_next_mlp(const float* ln, const float* x, float* out, const NextBlockW& w, int64_t npix,
-                           hipStream_t s) {
+template <bool OUT3>
+static hipError_t launch_mlp(const float* ln, const float* x, float* out, const NextBlockW& w, int64_t npix, Out3 o3, hipStream_t s) {
     // one 16-pixel group per wave iteration, eight waves per workgroup: measured against <2, 4> and <1, 4>
     // (profiles/r02_k_mlp_variants.json)
     constexpr int NPB = 1, NW = 8;
-    if (npix <= 0) return hipSuccess;
     static std::atomic<uint64_t> attr{0};
-    if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(mlp_kernel<NPB, NW>), M2_LDS_BYTES, attr); e != hipSuccess)
+    if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(mlp_kernel<NPB, NW, OUT3>), M2_LDS_BYTES, attr); e != hipSuccess)
         return e;
     const long nblk = (npix + 16 * NPB - 1) / (16 * NPB);
     const long blocks = std::min<long>((nblk + NW - 1) / NW, num_cus());
-    hipLaunchKernelGGL((mlp_kernel<NPB, NW>), dim3((unsigned)blocks), dim3(64 * NW), M2_LDS_BYTES, s, ln, x, w.fc1_w, w.fc1_b,
-                       w.fc2_w, w.fc2_b, w.ls, out, (long)npix);
+    hipLaunchKernelGGL((mlp_kernel<NPB, NW, OUT3>), dim3((unsigned)blocks), dim3(64 * NW), M2_LDS_BYTES, s, ln, x, w.fc1_w,
+                       w.fc1_b, w.fc2_w, w.fc2_b, w.ls, out, (long)npix, o3);
     return hipGetLastError();
+}
+
+hipError_t launch_next_mlp(const float* ln, const float* x, float* out, const NextBlockW& w, int64_t npix,
+                           hipStream_t s) {
+    if (npix <= 0) return hipSuccess;
+    return launch_mlp<false>(ln, x, out, w, npix, Out3{}, s);
+}
+
+hipError_t launch_next_mlp_out3(const float* ln, const float* x, float* out, const NextBlockW& w, int64_t npix,
+                                const float* w3x48, const float* b3, float* out_nchw, float* out_nhwc4, int hw,
+                                hipStream_t s) {
+    if (npix <= 0) return hipSuccess;
+    return launch_mlp<true>(ln, x, out, w, npix, Out3{w3x48, b3, out_nchw, out_nhwc4, hw}, s);
 }
 
 hipError_t launch_pad_copy(const float* src, float* dst, int B, int h, int w, int H, int W, int oy, int ox,
