@@ -199,6 +199,38 @@ def test_sequence_vs_oracle(arch, stem, fut, B, H, W, conv_kernel):
             assert abs(O.psnr(out[b][None], gt) - O.psnr(want[b][t - 1][None], gt)) < 0.01
 
 
+@pytest.mark.parametrize("arch,stem,fut", [
+    ("convunet+feat", "recurrent-convunet+feat-iso3200", 0),
+    ("convunet", "recurrent-convunet-future-iso3200", 1),
+    ("next+feat", "recurrent-ConvNeXtUnet+feat-future-iso3200", 1),
+    ("next", "recurrent-ConvNeXtUnet-iso3200", 0),
+])
+def test_odd_shapes_vs_oracle(arch, stem, fut, conv_kernel):
+    """Frames that are tiny, very wide or very tall, none a multiple of 8 or of a kernel's tile: every level ragged,
+    zero-pad placement at every decoder stage, whole levels smaller than one tile.  Batch 3, two frame-steps each.
+    (tools/shape_sweep.py runs the long form of this: 11 shapes x B in {1, 3}.)"""
+    from rvdd_release_amd import synth
+    from rvdd_release_amd.runtime import RvddRuntime
+    if arch.startswith("next") and conv_kernel == "winograd":
+        pytest.skip("the conv kernel choice does not enter ConvNeXtUnet")
+    sd = load_weights(stem)
+    T, B = 3 + fut, 3
+    for H, W in ((16, 16), (18, 34), (22, 130), (130, 22), (50, 66)):
+        seqs = [synth.make_sequence(T, H, W, iso=3200, seed=900 + b) for b in range(B)]
+        want = [O.RecurrentOracle(sd, future=fut).run_sequence(s.raw, s.flow_prev, s.flow_next) for s in seqs]
+        raw = torch.stack([s.raw for s in seqs], 0).cuda()
+        fp = torch.stack([s.flow_prev for s in seqs], 0).cuda()
+        fn = torch.stack([s.flow_next for s in seqs], 0).cuda()
+        rt = RvddRuntime(arch, fut, B, H, W, 0)
+        rt.load_state_dict(sd)
+        for t in range(1, T - fut):
+            out = rt.step(raw[:, t - 1], raw[:, t], raw[:, t + 1] if fut else None, fp[:, t], fn[:, t] if fut else None).cpu()
+            for b in range(B):
+                d = (out[b] - want[b][t - 1]).abs().max()
+                assert d < 1e-4, (H, W, t, b, float(d))
+        rt.close()
+
+
 def test_state_roundtrip_and_reset():
     from rvdd_release_amd import synth
     from rvdd_release_amd.runtime import RvddRuntime
