@@ -52,8 +52,8 @@ typedef struct rvdd_cfg {
     int32_t arch;     /* enum rvdd_arch */
     int32_t future;   /* --future_patch_depth: 0 or 1 (options/base_options.py:56) */
     int32_t batch;    /* B sequences advanced in lockstep */
-    int32_t height;   /* RGB frame height H (even); raw frames are 4 x H/2 x W/2 */
-    int32_t width;    /* RGB frame width  W (even) */
+    int32_t height;   /* RGB frame height H (even, >= 16); raw frames are 4 x H/2 x W/2 */
+    int32_t width;    /* RGB frame width  W (even, >= 16); H x W x 192 bytes < 2 GiB (11.1 Mpx: 3840 x 2176 fits) */
     int32_t device;   /* HIP device ordinal */
 } rvdd_cfg;
 

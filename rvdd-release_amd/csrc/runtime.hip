@@ -664,6 +664,10 @@ int rvdd_create(const rvdd_cfg* cfg, rvdd_t** out) {
     if (cfg->batch < 1) return fail(nullptr, RVDD_ERR_ARG, "rvdd_create: batch must be >= 1");
     if (cfg->height < 16 || cfg->width < 16 || (cfg->height & 1) || (cfg->width & 1))
         return fail(nullptr, RVDD_ERR_ARG, "rvdd_create: frame size %dx%d must be even and >= 16", cfg->height, cfg->width);
+    // byte offsets inside one 48-channel map are 32-bit in every kernel (buffer addressing): the map must stay below 2 GiB
+    if ((size_t)cfg->height * cfg->width * kF * sizeof(float) >= 0x80000000ull)
+        return fail(nullptr, RVDD_ERR_ARG, "rvdd_create: frame %dx%d too large: one 48-channel map must stay below 2 GiB (11.1 Mpx)",
+                    cfg->height, cfg->width);
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev <= 0)

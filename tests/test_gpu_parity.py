@@ -384,6 +384,10 @@ def test_error_paths():
         rt3.step(None, z, None, f, None)
     with pytest.raises(RuntimeError, match="GPU tensor"):
         rt3.step(z.cpu(), z, None, f, None)
+    with pytest.raises(RuntimeError, match="too large"):       # 5120x2880: a 48-channel map of 2.8 GB
+        RvddRuntime("convunet+feat", 0, 1, 2880, 5120, 0)
+    with pytest.raises(RuntimeError, match="even and >= 16"):
+        RvddRuntime("convunet+feat", 0, 1, 33, 32, 0)
 
 
 def test_full_size_720p_vs_oracle_and_invariants():
