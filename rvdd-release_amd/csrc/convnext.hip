@@ -100,7 +100,8 @@ constexpr int D_W_FLOATS = 49 * kF;                       // 2352: the 7x7 taps 
 constexpr int E_TH = 16, E_TW = 16, E_IH = E_TH + 6, E_PITCH = 24;
 constexpr int E_BUF_FLOATS = E_IH * E_PITCH * 16;          // 8448 floats = 33 KiB: one 16-channel chunk of the halo tile
 constexpr int E_PIECES = E_BUF_FLOATS / 256;                // 33 LDS-DMA pieces of 1 KiB
-constexpr size_t E_LDS_BYTES = (size_t)(D_W_FLOATS + 2 * E_BUF_FLOATS) * 4;
+constexpr int E_PAR_FLOATS = 3 * kF;                         // dw bias | LayerNorm weight | LayerNorm bias
+constexpr size_t E_LDS_BYTES = (size_t)(D_W_FLOATS + E_PAR_FLOATS + 2 * E_BUF_FLOATS) * 4;
 
 __global__ __launch_bounds__(256, 2) void dwln_kernel(const float* __restrict__ x, const float* __restrict__ dw_w,
                                                       const float* __restrict__ dw_b, const float* __restrict__ ln_w,
@@ -108,7 +109,12 @@ __global__ __launch_bounds__(256, 2) void dwln_kernel(const float* __restrict__ 
                                                       int B, int H, int W, int tiles_x, int tiles_y, int ntiles) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Wl = smem;                        // [49][48]
-    float* Tl = smem + D_W_FLOATS;           // two chunk buffers
+    // The three per-channel vectors live in LDS, not in registers (the kernel has none to spare) and not in global
+    // memory: vmcnt counts in order, so a wait for a 16-byte global load issued after a chunk's LDS-DMA is a wait for
+    // the whole chunk -- reloading the bias at the top of a tile and the LayerNorm vectors before the stores
+    // serialised the DMA of the next chunk with this one's arithmetic (the "38 us of overlap" of the phase timings).
+    float* Pl = smem + D_W_FLOATS;           // dw_b | ln_w | ln_b
+    float* Tl = Pl + E_PAR_FLOATS;           // two chunk buffers
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -168,6 +174,8 @@ __global__ __launch_bounds__(256, 2) void dwln_kernel(const float* __restrict__ 
     dma_chunk(cur, 0, 0);
     for (int q = tid; q < D_W_FLOATS / 4; q += 256)
         reinterpret_cast<f32x4*>(Wl)[q] = reinterpret_cast<const f32x4*>(dw_w)[q];
+    if (tid < E_PAR_FLOATS) Pl[tid] = tid < kF ? dw_b[tid] : (tid < 2 * kF ? ln_w[tid - kF] : ln_b[tid - 2 * kF]);
+    __syncthreads();                         // the bias is read before the first barrier of the tile loop
 
     // read addresses: pixel (row + ky, 4 quad + dx) -> R = (row + ky) * 6 + quad + (dx >> 2); float offset =
     // R * 64 + (((dx & 3) ^ (R & 3)) * 4 + g) * 4.  (R & 3) = (2 row + quad + 2 ky + (dx >> 2)) & 3: sixteen
@@ -189,7 +197,7 @@ __global__ __launch_bounds__(256, 2) void dwln_kernel(const float* __restrict__ 
 #pragma unroll
         for (int j = 0; j < 3; ++j)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) acc[i][j] = *reinterpret_cast<const f32x4*>(dw_b + 16 * j + 4 * g);
+            for (int i = 0; i < 4; ++i) acc[i][j] = *reinterpret_cast<const f32x4*>(Pl + 16 * j + 4 * g);
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -227,8 +235,8 @@ __global__ __launch_bounds__(256, 2) void dwln_kernel(const float* __restrict__ 
         f32x4 lw[3], lb[3];
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
-            lw[j] = *reinterpret_cast<const f32x4*>(ln_w + 16 * j + 4 * g);
-            lb[j] = *reinterpret_cast<const f32x4*>(ln_b + 16 * j + 4 * g);
+            lw[j] = *reinterpret_cast<const f32x4*>(Pl + kF + 16 * j + 4 * g);
+            lb[j] = *reinterpret_cast<const f32x4*>(Pl + 2 * kF + 16 * j + 4 * g);
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
