@@ -331,18 +331,20 @@ def test_two_devices_in_one_process():
     assert torch.equal(outs[0], outs[1])
 
 
-def test_graph_replay_equals_eager():
+@pytest.mark.parametrize("arch,stem", [("convunet+feat", "recurrent-convunet+feat-future-iso12800"),
+                                       ("next+feat", "recurrent-ConvNeXtUnet+feat-future-iso12800")])
+def test_graph_replay_equals_eager(arch, stem):
     """rvdd_set_option("graphs", 1): frame-steps captured into hipGraphs and replayed (one graph per distinct set of
     caller buffers, the first frame of a video its own) give the same bits as launch-by-launch execution, across
     a reset and with buffers that repeat."""
     from rvdd_release_amd import synth
     from rvdd_release_amd.runtime import RvddRuntime
-    sd = load_weights("recurrent-convunet+feat-future-iso12800")
+    sd = load_weights(stem)
     H, W, T = 48, 64, 6
     s = synth.make_sequence(T, H, W, iso=12800, seed=31, device="cuda")
     outs = {}
     for graphs in (0, 1):
-        rt = RvddRuntime("convunet+feat", 1, 1, H, W, 0)
+        rt = RvddRuntime(arch, 1, 1, H, W, 0)
         rt.load_state_dict(sd)
         rt.set_option("graphs", graphs)
         buf = torch.empty(2, 1, 3, H, W, device="cuda")           # two output buffers, reused alternately
