@@ -84,6 +84,8 @@ def parse_args(argv=None):
                     help="after the timed region, all-gather the output frames of the last group (timed separately)")
     ap.add_argument("--cpu-frames", type=int, default=10, help="timed frames of the CPU-oracle sample (0 = skip)")
     ap.add_argument("--cpu-frames-8", type=int, default=4, help="timed frames of the second CPU sample at 8 threads (0 = skip)")
+    ap.add_argument("--cpu-frames-wide", type=int, default=3,
+                    help="timed frames of a third CPU sample at min(affinity, cgroup quota, 64) threads, when that exceeds 16 (0 = skip)")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--all-kernel-events", action="store_true",
                     help="diagnostic: bracket EVERY launch of every kernel (costs ~6 %% of the frame rate); "
@@ -94,6 +96,11 @@ def parse_args(argv=None):
 def self_launch(args) -> int:
     """`python bench.py --gpus N` outside torch.distributed.run: start the N ranks as a CHILD process group
     (nothing in this process has touched the GPU), relay their output, return their exit code."""
+    if "rocprof" in os.environ.get("LD_PRELOAD", "").lower() or any(k.startswith("ROCPROF") for k in os.environ):
+        # under rocprofv3 the profiler's preloaded library has ALREADY initialised the GPU in this process (with --pmc
+        # it has): starting a launcher from here is a fork + exec behind an initialised GPU, which takes GPU boxes down
+        raise SystemExit("bench.py --gpus N cannot start its own ranks under rocprofv3: profile one rank "
+                         "(`rocprofv3 ... -- python3 bench.py --config C5`), or put the profiler inside the launcher")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)
@@ -143,8 +150,43 @@ class StubRuntime:
         return []
 
 
+def host_cpu_share():
+    """What this process may use of the host's CPUs: affinity mask and cgroup quota (the evidence behind `cores`)."""
+    info = {"host_cpus": os.cpu_count()}
+    try:
+        info["affinity"] = len(os.sched_getaffinity(0))
+    except Exception:
+        info["affinity"] = None
+    info["cgroup_cpu_max"] = None
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().strip()
+        except OSError:
+            continue
+        info["cgroup_cpu_max"] = f"{path}: {txt}"
+        try:
+            if path.endswith("cpu.max"):
+                q, per = txt.split()
+                info["cgroup_cpus"] = None if q == "max" else round(int(q) / int(per), 2)
+            else:
+                q = int(txt)
+                per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                info["cgroup_cpus"] = None if q < 0 else round(q / per, 2)
+        except Exception:
+            info["cgroup_cpus"] = None
+        break
+    try:
+        info["loadavg_1min"] = os.getloadavg()[0]
+    except OSError:
+        pass
+    return info
+
+
 def main():
     args = parse_args()
+    # the host driver only supports dmabuf IPC: RCCL (and any sharing of device memory between processes) needs this
+    # before the first HIP call of the process, whoever started it (torch.distributed.run directly, or self_launch)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(self_launch(args))
     if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
@@ -241,6 +283,12 @@ def main():
 
     elapsed = shard.max_over_ranks(wall, dist, coll_dev)
     n_ranks_seen = shard.count_ranks(dist, coll_dev)             # from the collective itself, not from the environment
+    # which library ran those collectives, on tensors living where (a plain `python bench.py` has no group at all)
+    distributed = {"process_group": dist is not None,
+                   "backend": dist.get_backend() if dist is not None else None,
+                   "collective_tensors_on": str(coll_dev) if coll_dev is not None else "cpu",
+                   "n_ranks_seen_from": "all_reduce(SUM) of ones" if dist is not None else "no collective (single process)",
+                   "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")}
     frames_total = args.steps * n_out * total_seqs
     fps = frames_total / elapsed
 
@@ -308,13 +356,12 @@ def main():
     if world == 1 and args.cpu_frames > 0 and not stub:
         sys.path.insert(0, os.path.join(REPO, "oracle"))
         import rvdd_oracle as O
-        cores = os.cpu_count() or 1
-        try:
-            cores = len(os.sched_getaffinity(0))
-        except Exception:
-            pass
+        share = host_cpu_share()
+        cores = share["affinity"] or os.cpu_count() or 1
+        if share.get("cgroup_cpus"):
+            cores = min(cores, max(1, int(share["cgroup_cpus"])))
         # a 1-GPU box grants a 16-CPU share of a larger host: more threads than the share only
-        # oversubscribe it (256 threads measured 40x slower than 16)
+        # oversubscribe it (256 threads measured 40x slower than 16); `host_cpu_share` is the evidence
         cores = int(os.environ.get("RVDD_CPU_THREADS", min(cores, 16)))
         raw0, fprev0, fnext0 = inputs[-1]
         r0, p0 = raw0[:, 0].cpu(), fprev0[:, 0].cpu()
@@ -325,6 +372,7 @@ def main():
             orc = O.RecurrentOracle(sd, future=fut)
             nf = min(warm + timed, n_out)
             times, worst, ppsnr = [], 0.0, 1e9
+            task_cpu, task_gpu = [], []
             for t in range(1, 1 + nf):
                 tc = time.perf_counter()
                 den = orc.step(r0[t - 1][None], r0[t][None], r0[t + 1][None] if fut else None, p0[t][None],
@@ -335,18 +383,34 @@ def main():
                     worst = max(worst, float(d.abs().max()))
                     mse = float((d * d).mean())
                     ppsnr = min(ppsnr, 200.0 if mse == 0 else 10 * torch.log10(torch.tensor(4.0 / mse)).item())
+                    # task PSNR (models/recurrent_model.py:512-525) of the SAME frames from both sides: the north
+                    # star's 0.01 dB bar is on this difference
+                    g0 = gt[t, 0].cpu()[None]
+                    task_cpu.append(O.psnr(den, g0))
+                    task_gpu.append(O.psnr(outs[t - 1, 0].cpu()[None], g0))
             tt = times[warm:] if len(times) > warm else times
-            return len(tt) / sum(tt), len(tt), worst, ppsnr
+            return len(tt) / sum(tt), len(tt), worst, ppsnr, task_cpu, task_gpu
 
-        v, n_t, worst, ppsnr = cpu_sample(cores, 2, args.cpu_frames, True)
+        v, n_t, worst, ppsnr, task_cpu, task_gpu = cpu_sample(cores, 2, args.cpu_frames, True)
         cpu = {"value": round(v, 4), "unit": "frames/s", "cores": cores, "kind": "port",
                "sample": f"{n_t} frame(s) of sequence 0 of the same workload after 2 warm-up frames, B = 1, "
                          f"torch {torch.__version__} CPU ops, {cores} threads of {os.cpu_count()} host CPUs",
-               "gpu_vs_cpu_max_abs_diff": worst, "gpu_vs_cpu_parity_psnr_db": round(ppsnr, 2)}
+               "host_cpu_share": share,
+               "gpu_vs_cpu_max_abs_diff": worst, "gpu_vs_cpu_parity_psnr_db": round(ppsnr, 2),
+               "task_psnr_db_cpu": round(sum(task_cpu) / len(task_cpu), 4),
+               "task_psnr_db_gpu_same_frames": round(sum(task_gpu) / len(task_gpu), 4),
+               "task_psnr_max_abs_diff_db": round(max(abs(a - b) for a, b in zip(task_cpu, task_gpu)), 6)}
         if args.cpu_frames_8 > 0 and cores > 8:
-            v8, n8, _, _ = cpu_sample(8, 1, args.cpu_frames_8, False)
+            v8, n8 = cpu_sample(8, 1, args.cpu_frames_8, False)[:2]
             cpu["value_8_threads"] = round(v8, 4)
             cpu["sample_8_threads"] = f"{n8} frame(s) after 1 warm-up frame, 8 threads (BASELINE.md section 2 used 8)"
+        wide = min(share["affinity"] or 0, 64)
+        if share.get("cgroup_cpus"):
+            wide = min(wide, int(share["cgroup_cpus"]))
+        if args.cpu_frames_wide > 0 and wide > cores:
+            vw, nw = cpu_sample(wide, 1, args.cpu_frames_wide, False)[:2]
+            cpu["value_wide"] = round(vw, 4)
+            cpu["sample_wide"] = f"{nw} frame(s) after 1 warm-up frame, {wide} threads = min(affinity, cgroup quota, 64)"
 
     par = (f"{total_seqs} sequences sharded over {world} GPU(s), {len(groups)} group(s) of {B} in lockstep per GPU"
            if args.scaling == "strong" else f"sequences sharded over {world} GPU(s), {B} per GPU in lockstep")
@@ -357,7 +421,7 @@ def main():
         data += " (STUB: CPU stand-in for the HIP runtime, launcher/collective test only, not a measurement)"
     line = {
         "metric": "frames/sec (whole job), recurrent video denoise+demosaic inference", "value": round(fps, 3),
-        "unit": "frames/s", "n_gpus": world, "n_ranks_seen": n_ranks_seen, "steps": args.steps, "warmup": args.warmup,
+        "unit": "frames/s", "n_gpus": world, "n_ranks_seen": n_ranks_seen, "distributed": distributed, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": args.scaling,
         "vs_baseline": None, "dtype": "f32", "data": data,
         "config": {"workload": f"{config}: {DESCR[config]}" + (f" (run with --frames {T})" if args.frames else ""),

@@ -34,15 +34,16 @@ struct Cfa {
 };
 
 // algo1 (util/Hamilton_Adam_demo.py:123-142)
+// rbs = floats from one sequence's raw frame to the next one's (4hw when dense; more for a channel slice of a wider tensor)
 __global__ void ha_green_kernel(const float* __restrict__ raw, float* __restrict__ green, int n, int h,
-                                int w) {
+                                int w, int64_t rbs) {
     const int H = 2 * h, W = 2 * w;
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (size_t)n * H * W) return;
     const int x = idx % W;
     const int y = (idx / W) % H;
     const int b = idx / ((size_t)W * H);
-    Cfa c{raw + (size_t)b * 4 * h * w, h, w, H, W};
+    Cfa c{raw + (size_t)b * rbs, h, w, H, W};
     const float cc = c.at(y, x);
     float gval;
     if (((y ^ x) & 1) == 0) {
@@ -109,14 +110,14 @@ __device__ __forceinline__ void ha_red_blue(const Cfa& c, const float* __restric
 
 __global__ void ha_rb_kernel(const float* __restrict__ raw, const float* __restrict__ green,
                              float* __restrict__ out, int n, int h, int w, int64_t bstride, int pstride,
-                             int cstride) {
+                             int cstride, int64_t rbs) {
     const int H = 2 * h, W = 2 * w;
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (size_t)n * H * W) return;
     const int x = idx % W;
     const int y = (idx / W) % H;
     const int b = idx / ((size_t)W * H);
-    Cfa c{raw + (size_t)b * 4 * h * w, h, w, H, W};
+    Cfa c{raw + (size_t)b * rbs, h, w, H, W};
     const float* gp = green + (size_t)b * H * W;
     const float g0 = gp[(size_t)y * W + x];
     float rb[2];
@@ -248,24 +249,25 @@ __device__ __forceinline__ f32x4 warp3_at(const f32x4* __restrict__ s, const flo
 __global__ __launch_bounds__(256) void netin_kernel(const float* __restrict__ raw_cur, const float* __restrict__ green,
                                                     const float* __restrict__ prev4, const float* __restrict__ flow_prev,
                                                     const float* __restrict__ next4, const float* __restrict__ flow_next,
-                                                    float* __restrict__ netin, int B, int h, int w) {
+                                                    float* __restrict__ netin, int B, int h, int w, int64_t rbs,
+                                                    int64_t fbs) {
     const int H = 2 * h, W = 2 * w;
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (size_t)B * H * W) return;
     const int x = idx % W;
     const int y = (idx / W) % H;
     const int b = idx / ((size_t)W * H);
-    Cfa c{raw_cur + (size_t)b * 4 * h * w, h, w, H, W};
+    Cfa c{raw_cur + (size_t)b * rbs, h, w, H, W};
     const float* gp = green + (size_t)b * H * W;
     const float g0 = gp[(size_t)y * W + x];
     float rb[2];
     ha_red_blue(c, gp, H, W, y, x, g0, rb);
     const f32x4 p = warp3_at(reinterpret_cast<const f32x4*>(prev4) + (size_t)b * H * W,
-                             flow_prev ? flow_prev + (size_t)b * 2 * h * w : nullptr, h, w, H, W, y, x);
+                             flow_prev ? flow_prev + (size_t)b * fbs : nullptr, h, w, H, W, y, x);
     f32x4 n = {0.f, 0.f, 0.f, 0.f};
     if (next4)
         n = warp3_at(reinterpret_cast<const f32x4*>(next4) + (size_t)b * H * W,
-                     flow_next ? flow_next + (size_t)b * 2 * h * w : nullptr, h, w, H, W, y, x);
+                     flow_next ? flow_next + (size_t)b * fbs : nullptr, h, w, H, W, y, x);
     f32x4* o = reinterpret_cast<f32x4*>(netin) + idx * 4;
     o[0] = f32x4{p[0], p[1], p[2], rb[0]};
     o[1] = f32x4{g0, rb[1], n[0], n[1]};
@@ -283,7 +285,7 @@ __global__ __launch_bounds__(256) void netin_kernel(const float* __restrict__ ra
 //    a pixel is the same in both.
 __global__ __launch_bounds__(192) void warp48_kernel(const float* __restrict__ src,
                                                      const float* __restrict__ flow_raw,
-                                                     float* __restrict__ dst, int B, int H, int W) {
+                                                     float* __restrict__ dst, int B, int H, int W, int64_t fbs) {
     __shared__ int s_i[32][8];      // xi[4], yi[4] * W
     __shared__ float s_w[32][8];    // wx[4], wy[4]
     const int y = blockIdx.y, b = blockIdx.z, x0 = blockIdx.x * 32;
@@ -292,7 +294,7 @@ __global__ __launch_bounds__(192) void warp48_kernel(const float* __restrict__ s
         if (x < W) {
             const int h = H / 2, w = W / 2;
             float fx, fy;
-            flow_at(flow_raw + (size_t)b * 2 * h * w, h, w, H, W, y, x, fx, fy);
+            flow_at(flow_raw + (size_t)b * fbs, h, w, H, W, y, x, fx, fy);
             Taps t;
             make_taps(fx, fy, x, y, H, W, t);
 #pragma unroll
@@ -566,12 +568,13 @@ inline unsigned nblocks(size_t n, int bs) { return (unsigned)((n + bs - 1) / bs)
 }  // namespace
 
 hipError_t launch_demosaic(const float* raw, float* green_scratch, float* out, int n, int h, int w,
-                           int64_t bstride, int pstride, int cstride, hipStream_t s) {
+                           int64_t bstride, int pstride, int cstride, hipStream_t s, int64_t raw_bstride) {
     const size_t npix = (size_t)n * 4 * h * w;
     if (!npix) return hipSuccess;
-    hipLaunchKernelGGL(ha_green_kernel, dim3(nblocks(npix, 256)), dim3(256), 0, s, raw, green_scratch, n, h, w);
+    const int64_t rbs = raw_bstride ? raw_bstride : (int64_t)4 * h * w;
+    hipLaunchKernelGGL(ha_green_kernel, dim3(nblocks(npix, 256)), dim3(256), 0, s, raw, green_scratch, n, h, w, rbs);
     hipLaunchKernelGGL(ha_rb_kernel, dim3(nblocks(npix, 256)), dim3(256), 0, s, raw, green_scratch, out, n, h,
-                       w, bstride, pstride, cstride);
+                       w, bstride, pstride, cstride, rbs);
     return hipGetLastError();
 }
 
@@ -606,19 +609,22 @@ hipError_t launch_warp3(const float* src4, const float* flow_raw, float* dst, in
 }
 
 hipError_t launch_netin(const float* raw_cur, float* green_scratch, const float* prev4, const float* flow_prev,
-                        const float* next4, const float* flow_next, float* netin, int B, int h, int w, hipStream_t s) {
+                        const float* next4, const float* flow_next, float* netin, int B, int h, int w, hipStream_t s,
+                        int64_t raw_bstride, int64_t flow_bstride) {
     const size_t n = (size_t)B * 4 * h * w;
     if (!n) return hipSuccess;
-    hipLaunchKernelGGL(ha_green_kernel, dim3(nblocks(n, 256)), dim3(256), 0, s, raw_cur, green_scratch, B, h, w);
+    const int64_t rbs = raw_bstride ? raw_bstride : (int64_t)4 * h * w, fbs = flow_bstride ? flow_bstride : (int64_t)2 * h * w;
+    hipLaunchKernelGGL(ha_green_kernel, dim3(nblocks(n, 256)), dim3(256), 0, s, raw_cur, green_scratch, B, h, w, rbs);
     hipLaunchKernelGGL(netin_kernel, dim3(nblocks(n, 256)), dim3(256), 0, s, raw_cur, green_scratch, prev4, flow_prev, next4,
-                       flow_next, netin, B, h, w);
+                       flow_next, netin, B, h, w, rbs, fbs);
     return hipGetLastError();
 }
 
 hipError_t launch_warp48(const float* src, const float* flow_raw, float* dst, int B, int H, int W,
-                         hipStream_t s) {
+                         hipStream_t s, int64_t flow_bstride) {
     if (!B || !H || !W) return hipSuccess;
-    hipLaunchKernelGGL(warp48_kernel, dim3((W + 31) / 32, H, B), dim3(192), 0, s, src, flow_raw, dst, B, H, W);
+    hipLaunchKernelGGL(warp48_kernel, dim3((W + 31) / 32, H, B), dim3(192), 0, s, src, flow_raw, dst, B, H, W,
+                       flow_bstride ? flow_bstride : (int64_t)2 * (H / 2) * (W / 2));
     return hipGetLastError();
 }
 

@@ -9,7 +9,6 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
-#include <functional>
 #include <map>
 #include <string>
 #include <vector>
@@ -68,6 +67,44 @@ struct DeviceGuard {
     DeviceGuard& operator=(const DeviceGuard&) = delete;
 };
 
+// The 3x3 conv layers of the convunet by position in the schedule (run_convunet): names are resolved ONCE, in
+// rvdd_finalize_weights, into h->cu[]; a frame-step touches no string and no map.
+enum CuLayer {
+    CU_PRE, CU_ENC0_0, CU_ENC0_1, CU_DOWN0, CU_ENC1_0, CU_ENC1_1, CU_DOWN1, CU_ENC2_0, CU_ENC2_1, CU_DOWN2, CU_ENC3_0,
+    CU_ENC3_1, CU_BOT0, CU_BOT1, CU_UP0, CU_DEC0_0, CU_DEC0_1, CU_UP1, CU_DEC1_0, CU_DEC1_1, CU_UP2, CU_DEC2_0, CU_DEC2_1,
+    CU_POST, CU_COUNT
+};
+const char* const kCuNames[CU_COUNT] = {
+    "preprocessing_layer", "EncoderConvs.0.blocks.0.0", "EncoderConvs.0.blocks.1.0", "EncoderDown.0.conv",
+    "EncoderConvs.1.blocks.0.0", "EncoderConvs.1.blocks.1.0", "EncoderDown.1.conv", "EncoderConvs.2.blocks.0.0",
+    "EncoderConvs.2.blocks.1.0", "EncoderDown.2.conv", "EncoderConvs.3.blocks.0.0", "EncoderConvs.3.blocks.1.0",
+    "bottleneck.0.0", "bottleneck.1.0", "DecoderUp.0.up.1", "DecoderConvs.0.blocks.0.0", "DecoderConvs.0.blocks.1.0",
+    "DecoderUp.1.up.1", "DecoderConvs.1.blocks.0.0", "DecoderConvs.1.blocks.1.0", "DecoderUp.2.up.1",
+    "DecoderConvs.2.blocks.0.0", "DecoderConvs.2.blocks.1.0", "PostConvs.0.0"};
+constexpr int cu_enc(int level, int j) { return level == 0 ? CU_ENC0_0 + j : CU_ENC1_0 + 3 * (level - 1) + j; }
+constexpr int cu_down(int i) { return CU_DOWN0 + 3 * i; }
+constexpr int cu_up(int i) { return CU_UP0 + 3 * i; }
+constexpr int cu_dec(int i, int j) { return CU_DEC0_0 + 3 * i + j; }
+
+// The ConvBlocks of the ConvNeXt net by position in the schedule (run_convnext), resolved once like the above.
+enum NxBlock {
+    NX_PRE, NX_ENC0_0, NX_ENC0_1, NX_DOWN0, NX_ENC1_0, NX_ENC1_1, NX_DOWN1, NX_ENC2_0, NX_ENC2_1, NX_DOWN2, NX_ENC3_0,
+    NX_ENC3_1, NX_BOT0, NX_BOT1, NX_UP0, NX_DEC0_0, NX_DEC0_1, NX_UP1, NX_DEC1_0, NX_DEC1_1, NX_UP2, NX_DEC2_0, NX_DEC2_1,
+    NX_POST0, NX_POST1, NX_COUNT
+};
+const char* const kNxNames[NX_COUNT] = {
+    "preprocessing_layer.blocks.0", "encoder_convs.0.blocks.0", "encoder_convs.0.blocks.1", "encoder_downs.0.postconv",
+    "encoder_convs.1.blocks.0", "encoder_convs.1.blocks.1", "encoder_downs.1.postconv", "encoder_convs.2.blocks.0",
+    "encoder_convs.2.blocks.1", "encoder_downs.2.postconv", "encoder_convs.3.blocks.0", "encoder_convs.3.blocks.1",
+    "bottleneck.blocks.0", "bottleneck.blocks.1", "decoder_ups.0.postconv", "decoder_convs.0.blocks.0",
+    "decoder_convs.0.blocks.1", "decoder_ups.1.postconv", "decoder_convs.1.blocks.0", "decoder_convs.1.blocks.1",
+    "decoder_ups.2.postconv", "decoder_convs.2.blocks.0", "decoder_convs.2.blocks.1", "postprocessing.0.blocks.0",
+    "postprocessing.0.blocks.1"};
+constexpr int nx_enc(int level, int j) { return level == 0 ? NX_ENC0_0 + j : NX_ENC1_0 + 3 * (level - 1) + j; }
+constexpr int nx_down(int i) { return NX_DOWN0 + 3 * i; }
+constexpr int nx_up(int i) { return NX_UP0 + 3 * i; }
+constexpr int nx_dec(int i, int j) { return NX_DEC0_0 + 3 * i + j; }
+
 struct Level {
     int H = 0, W = 0;
     float* t[3] = {nullptr, nullptr, nullptr};
@@ -94,10 +131,10 @@ struct rvdd_handle {
     std::vector<void*> allocs;
 
     // weights
-    std::map<std::string, Conv3> conv3;
+    Conv3 cu[CU_COUNT];       // convunet layers in schedule order (CuLayer)
     float* w_out = nullptr;   // [3][48]
     float* b_out = nullptr;   // [3]
-    std::map<std::string, NextBlk> next_blk;   // ConvNeXt blocks by name
+    NextBlk nx[NX_COUNT];     // ConvNeXt blocks in schedule order (NxBlock)
 
     // workspace
     Level lv[4];
@@ -249,15 +286,7 @@ struct KeySpec {
 
 std::vector<std::string> convunet_conv_names(bool feat) {
     std::vector<std::string> n;
-    if (feat) n.push_back("preprocessing_layer");
-    for (int i = 0; i < 4; ++i)
-        for (int j = 0; j < 2; ++j) n.push_back("EncoderConvs." + std::to_string(i) + ".blocks." + std::to_string(j) + ".0");
-    for (int i = 0; i < 3; ++i) n.push_back("EncoderDown." + std::to_string(i) + ".conv");
-    for (int i = 0; i < 2; ++i) n.push_back("bottleneck." + std::to_string(i) + ".0");
-    for (int i = 0; i < 3; ++i) n.push_back("DecoderUp." + std::to_string(i) + ".up.1");
-    for (int i = 0; i < 3; ++i)
-        for (int j = 0; j < 2; ++j) n.push_back("DecoderConvs." + std::to_string(i) + ".blocks." + std::to_string(j) + ".0");
-    n.push_back("PostConvs.0.0");
+    for (int i = feat ? 0 : 1; i < CU_COUNT; ++i) n.push_back(kCuNames[i]);
     return n;
 }
 
@@ -271,21 +300,7 @@ int convunet_cin(const rvdd_t* h, const std::string& name) {
 
 std::vector<std::string> next_block_names(bool feat) {
     std::vector<std::string> n;
-    if (feat) n.push_back("preprocessing_layer.blocks.0");
-    for (int i = 0; i < 4; ++i) {
-        n.push_back("encoder_convs." + std::to_string(i) + ".blocks.0");
-        n.push_back("encoder_convs." + std::to_string(i) + ".blocks.1");
-        if (i < 3) n.push_back("encoder_downs." + std::to_string(i) + ".postconv");
-    }
-    n.push_back("bottleneck.blocks.0");
-    n.push_back("bottleneck.blocks.1");
-    for (int i = 0; i < 3; ++i) {
-        n.push_back("decoder_ups." + std::to_string(i) + ".postconv");
-        n.push_back("decoder_convs." + std::to_string(i) + ".blocks.0");
-        n.push_back("decoder_convs." + std::to_string(i) + ".blocks.1");
-    }
-    n.push_back("postprocessing.0.blocks.0");
-    n.push_back("postprocessing.0.blocks.1");
+    for (int i = feat ? 0 : 1; i < NX_COUNT; ++i) n.push_back(kNxNames[i]);
     return n;
 }
 
@@ -506,66 +521,71 @@ int run_conv(rvdd_t* h, const Conv3& L, const ConvCall& c, hipStream_t s, Sub su
         if (rc__) return rc__; \
     } while (0)
 
-// What rvdd_step does in front of the net for sequences [b0, b0 + nb) (demosaic, warps); empty for rvdd_unet_forward.
-using Prologue = std::function<int(Sub)>;
+// What rvdd_step does in front of the net (demosaic, warps): the caller's frame and flow pointers of one step.
+// run_convunet calls it per sequence when the full-resolution stages run depth first; null for rvdd_unet_forward.
+struct StepInputs {
+    const float* raw_cur = nullptr;
+    const float* raw_next = nullptr;
+    const float* flow_prev = nullptr;
+    const float* flow_next = nullptr;
+    size_t rawf = 0, flowf = 0;       // floats from one sequence to the next in the caller's raw / flow tensors
+};
+int run_prologue(rvdd_t* h, const StepInputs& in, Sub sb, hipStream_t s);
 
 // networks/unet.py:544-588 as specialised by UNet_FixedFeatures[_feat] (:595-825).
 int run_convunet(rvdd_t* h, const float* netin, const float* featw, float* feat_dst, float* out_nchw,
-                 float* out_nhwc4, hipStream_t s, const Prologue& prologue) {
+                 float* out_nhwc4, hipStream_t s, const StepInputs* prologue) {
     const bool feat = h->has_feat();
     const int B = h->cfg.batch;
     Level* lv = h->lv;
-    auto L = [&](const std::string& n) -> const Conv3& { return h->conv3.at(n); };
-    auto conv = [&](const std::string& name, const float* in, float* out, int lvl, int epi, Sub sub) {
+    const Conv3* cu = h->cu;
+    auto conv = [&](int layer, const float* in, float* out, int lvl, int epi, Sub sub) {
         ConvCall c;
         c.in = in; c.out = out; c.H = lv[lvl].H; c.W = lv[lvl].W; c.epi = epi;
-        return run_conv(h, L(name), c, s, sub);
+        return run_conv(h, cu[layer], c, s, sub);
     };
     // two-source (virtual concat) conv: pass 1 leaves bias + sum over source A in `part`
-    auto conv2 = [&](const std::string& name, const float* inA, const float* inB, float* out, int lvl, Sub sub) {
+    auto conv2 = [&](int layer, const float* inA, const float* inB, float* out, int lvl, Sub sub) {
         ConvCall c;
         c.in = inA; c.src = 0; c.out = lv[lvl].part; c.H = lv[lvl].H; c.W = lv[lvl].W; c.epi = EPI_NONE;
-        RC(run_conv(h, L(name), c, s, sub));
+        RC(run_conv(h, cu[layer], c, s, sub));
         c.in = inB; c.src = 1; c.acc_in = lv[lvl].part; c.out = out; c.epi = EPI_RELU;
-        return run_conv(h, L(name), c, s, sub);
+        return run_conv(h, cu[layer], c, s, sub);
     };
     const Sub all{0, B};
     // the full-resolution stages run per sequence when that keeps their maps in the Infinity Cache (seq_major_on),
     // in an order that alternates from frame to frame so that a step begins with the sequence the last one ended on
     const bool per_seq = seq_major_on(h);
-    std::vector<Sub> subs;
-    if (per_seq)
-        for (int k = 0; k < B; ++k) subs.push_back(Sub{h->serpentine ? B - 1 - k : k, 1});
-    else
-        subs.push_back(all);
+    const int nsub = per_seq ? B : 1;
+    auto sub_at = [&](int k) { return per_seq ? Sub{h->serpentine ? B - 1 - k : k, 1} : all; };
 
     // ---- pre-stages + encoder level 0
-    for (const Sub sb : subs) {
-        if (prologue) RC(prologue(sb));
+    for (int k = 0; k < nsub; ++k) {
+        const Sub sb = sub_at(k);
+        if (prologue) RC(run_prologue(h, *prologue, sb, s));
         if (feat) {
-            RC(conv("preprocessing_layer", netin, lv[0].t[0], 0, EPI_NONE, sb));            // :742 (no activation)
-            RC(conv2("EncoderConvs.0.blocks.0.0", lv[0].t[0], featw, lv[0].t[1], 0, sb));  // cat[y, old_features] :743
+            RC(conv(CU_PRE, netin, lv[0].t[0], 0, EPI_NONE, sb));                           // :742 (no activation)
+            RC(conv2(CU_ENC0_0, lv[0].t[0], featw, lv[0].t[1], 0, sb));                     // cat[y, old_features] :743
         } else {
-            RC(conv("EncoderConvs.0.blocks.0.0", netin, lv[0].t[1], 0, EPI_RELU, sb));
+            RC(conv(CU_ENC0_0, netin, lv[0].t[1], 0, EPI_RELU, sb));
         }
-        RC(conv("EncoderConvs.0.blocks.1.0", lv[0].t[1], lv[0].skip, 0, EPI_RELU, sb));
-        RC(conv("EncoderDown.0.conv", lv[0].skip, lv[1].t[0], 0, EPI_POOL, sb));            // :207-208
+        RC(conv(CU_ENC0_1, lv[0].t[1], lv[0].skip, 0, EPI_RELU, sb));
+        RC(conv(CU_DOWN0, lv[0].skip, lv[1].t[0], 0, EPI_POOL, sb));                        // :207-208
     }
     // ---- encoder levels 1..3 (all sequences per launch: these levels need the batch to fill the chip)
     for (int i = 1; i <= 3; ++i) {
-        const std::string e = "EncoderConvs." + std::to_string(i);
-        if (i > 1) RC(conv("EncoderDown." + std::to_string(i - 1) + ".conv", lv[i - 1].skip, lv[i].t[0], i - 1, EPI_POOL, all));
-        RC(conv(e + ".blocks.0.0", lv[i].t[0], lv[i].t[1], i, EPI_RELU, all));
-        RC(conv(e + ".blocks.1.0", lv[i].t[1], i < 3 ? lv[i].skip : lv[3].t[2], i, EPI_RELU, all));
+        if (i > 1) RC(conv(cu_down(i - 1), lv[i - 1].skip, lv[i].t[0], i - 1, EPI_POOL, all));
+        RC(conv(cu_enc(i, 0), lv[i].t[0], lv[i].t[1], i, EPI_RELU, all));
+        RC(conv(cu_enc(i, 1), lv[i].t[1], i < 3 ? lv[i].skip : lv[3].t[2], i, EPI_RELU, all));
     }
     // ---- bottleneck: d = e3 + d1 + d2 (:561-567)
     float* e3 = lv[3].t[2];
-    RC(conv("bottleneck.0.0", e3, lv[3].t[0], 3, EPI_RELU, all));
+    RC(conv(CU_BOT0, e3, lv[3].t[0], 3, EPI_RELU, all));
     {
         ConvCall c;
         c.in = lv[3].t[0]; c.out = lv[3].t[1]; c.H = lv[3].H; c.W = lv[3].W;
         c.epi = EPI_RELU_ADD2; c.res1 = e3; c.res2 = lv[3].t[0];
-        RC(run_conv(h, L("bottleneck.1.0"), c, s));
+        RC(run_conv(h, cu[CU_BOT1], c, s));
     }
     const float* d = lv[3].t[1];
     // ---- decoder (:570-579); its last level again per sequence, together with the post convs
@@ -573,8 +593,8 @@ int run_convunet(rvdd_t* h, const float* netin, const float* featw, float* feat_
     for (int i = 0; i < 3; ++i) {
         const int lo = 3 - i, hi = 2 - i;
         const int uh = 2 * lv[lo].H, uw = 2 * lv[lo].W;      // size after nn.Upsample(x2)
-        const std::vector<Sub> one{all};
-        for (const Sub sb : (hi == 0 ? subs : one)) {
+        for (int k = 0; k < (hi == 0 ? nsub : 1); ++k) {
+            const Sub sb = hi == 0 ? sub_at(k) : all;
             const size_t lo_px = (size_t)sb.b0 * lv[lo].H * lv[lo].W, hi_px = (size_t)sb.b0 * lv[hi].H * lv[hi].W;
             // UpConv: bilinear x2, conv, ReLU (:137-142).  Where the Winograd kernel runs the conv, the interpolation
             // happens in its patch load and the upsampled map is never written; elsewhere it is made first.
@@ -593,10 +613,9 @@ int run_convunet(rvdd_t* h, const float* netin, const float* featw, float* feat_
             c.oy = (lv[hi].H - uh) / 2; c.ox = (lv[hi].W - uw) / 2;
             if (uh != lv[hi].H || uw != lv[hi].W)
                 HIPCHK(h, hipMemsetAsync(lv[hi].t[1] + hi_px * kF, 0, (size_t)sb.nb * lv[hi].H * lv[hi].W * kF * sizeof(float), s));
-            RC(run_conv(h, L("DecoderUp." + std::to_string(i) + ".up.1"), c, s, sb));
-            const std::string dc = "DecoderConvs." + std::to_string(i);
-            RC(conv2(dc + ".blocks.0.0", lv[hi].skip, lv[hi].t[1], lv[hi].t[0], hi, sb));   // cat(skip, dec) :541
-            RC(conv(dc + ".blocks.1.0", lv[hi].t[0], lv[hi].t[1], hi, EPI_RELU, sb));
+            RC(run_conv(h, cu[cu_up(i)], c, s, sb));
+            RC(conv2(cu_dec(i, 0), lv[hi].skip, lv[hi].t[1], lv[hi].t[0], hi, sb));        // cat(skip, dec) :541
+            RC(conv(cu_dec(i, 1), lv[hi].t[0], lv[hi].t[1], hi, EPI_RELU, sb));
             if (hi > 0) continue;
             // ---- post: hooked 48-ch map = next frame's features (:808-812), then 1x1 -> 3
             if (wino_applies(h, lv[0].H, lv[0].W)) {
@@ -604,9 +623,9 @@ int run_convunet(rvdd_t* h, const float* netin, const float* featw, float* feat_
                 ConvCall pc;
                 pc.in = lv[0].t[1]; pc.out = fdst; pc.H = lv[0].H; pc.W = lv[0].W; pc.epi = EPI_RELU_OUT3;
                 pc.out3_nchw = out_nchw; pc.out3_nhwc4 = out_nhwc4;
-                RC(run_conv(h, L("PostConvs.0.0"), pc, s, sb));
+                RC(run_conv(h, cu[CU_POST], pc, s, sb));
             } else {
-                RC(conv("PostConvs.0.0", lv[0].t[1], fdst, 0, EPI_RELU, sb));
+                RC(conv(CU_POST, lv[0].t[1], fdst, 0, EPI_RELU, sb));
                 const size_t px0 = (size_t)sb.b0 * h->cfg.height * h->cfg.width;
                 const double px = (double)sb.nb * h->cfg.height * h->cfg.width;
                 Scope sc(h, s, "conv1x1_out_kernel", 2.0 * 48 * 3 * px, px * (192.0 + 12.0 + 16.0));
@@ -621,7 +640,7 @@ int run_convunet(rvdd_t* h, const float* netin, const float* featw, float* feat_
 }
 
 int run_net(rvdd_t* h, const float* netin, const float* featw, float* feat_dst, float* out_nchw,
-            float* out_nhwc4, hipStream_t s, const Prologue& prologue);
+            float* out_nhwc4, hipStream_t s, const StepInputs* prologue);
 
 int ensure_scratch(rvdd_t* h, size_t bytes) {
     if (h->scratch_bytes >= bytes) return RVDD_OK;
@@ -642,9 +661,9 @@ int ensure_scratch(rvdd_t* h, size_t bytes) {
 
 namespace {
 int run_net(rvdd_t* h, const float* netin, const float* featw, float* feat_dst, float* out_nchw,
-            float* out_nhwc4, hipStream_t s, const Prologue& prologue) {
+            float* out_nhwc4, hipStream_t s, const StepInputs* prologue) {
     if (!h->is_next()) return run_convunet(h, netin, featw, feat_dst, out_nchw, out_nhwc4, s, prologue);
-    if (prologue) RC(prologue(Sub{0, h->cfg.batch}));
+    if (prologue) RC(run_prologue(h, *prologue, Sub{0, h->cfg.batch}, s));
     return run_convnext(h, netin, featw, feat_dst, out_nchw, out_nhwc4, s);
 }
 }  // namespace
@@ -803,7 +822,8 @@ int rvdd_finalize_weights(rvdd_t* h) {
                 RC(upload(h, &L.wu[0], cin == 48 ? arrange_wino3x3(wt, 0) : arrange_wino3x3(wt, 0, 1)));
             }
             RC(upload(h, &L.bias, h->staged.at(n + ".bias").data));
-            h->conv3[n] = L;
+            for (int li = 0; li < CU_COUNT; ++li)
+                if (n == kCuNames[li]) h->cu[li] = L;
         }
         RC(upload(h, &h->w_out, h->staged.at("PostConvs.1.weight").data));
         RC(upload(h, &h->b_out, h->staged.at("PostConvs.1.bias").data));
@@ -927,88 +947,84 @@ int rvdd_reset(rvdd_t* h) {
 
 namespace {
 
+// The stages in front of the net for sequences [sb.b0, sb.b0 + sb.nb): one launch covers them all -- the kernels take
+// the caller's batch strides (channel slices of the reference's wider `n` / `flow` tensors are strided over the batch).
+int run_prologue(rvdd_t* h, const StepInputs& in, Sub sb, hipStream_t s) {
+    const bool nw = h->no_warp;
+    const int H = h->cfg.height, W = h->cfg.width;
+    const size_t img = (size_t)H * W, npix = (size_t)h->cfg.batch * img;
+    const size_t o = (size_t)sb.b0;
+    const int n = sb.nb;
+    const float* rc_ = in.raw_cur + o * in.rawf;
+    const float* fp_ = in.flow_prev ? in.flow_prev + o * in.flowf : nullptr;
+    const float* rn_ = in.raw_next ? in.raw_next + o * in.rawf : nullptr;
+    const float* fn_ = in.flow_next ? in.flow_next + o * in.flowf : nullptr;
+    float* green = h->green + o * img;
+    float* netin = h->netin + o * img * kNetInC;
+    if (h->warp_raw && !nw) {
+        // warp_frame with --warp_raw (models/recurrent_model.py:149-152): HA(warp(remosaick(frame), raw-resolution flow)).
+        // remosaick(HA(raw)) is raw itself, so the next frame is warped as it came.  next4 is free in this mode: its
+        // first quarter holds the re-mosaicked previous output, the second the warped planes.  The generic NCHW warp
+        // takes dense tensors: one sequence at a time when the caller's are strided (a mode without checkpoints of its own).
+        const bool dense = in.rawf == (size_t)4 * (H / 2) * (W / 2) && in.flowf == (size_t)2 * (H / 2) * (W / 2);
+        {
+            Scope sc(h, s, "demosaic(ha_green+ha_rb)", 0.0, (double)n * img * 16.0);
+            HIPCHK(h, launch_demosaic(rc_, green, netin + 3, n, H / 2, W / 2, (int64_t)H * W * kNetInC, kNetInC, 1, s, (int64_t)in.rawf));
+        }
+        for (int b = 0; b < n; b += dense ? n : 1) {
+            const int nb = dense ? n : 1;
+            float* packed = h->next4 + (o + b) * img;
+            float* warped = h->next4 + npix + (o + b) * img;
+            HIPCHK(h, launch_remosaick4(h->lastden4 + (o + b) * img * 4, packed, nb, H, W, s));
+            HIPCHK(h, launch_warp_nchw(packed, fp_ + b * in.flowf, warped, nb, 4, H / 2, W / 2, s));
+            HIPCHK(h, launch_demosaic(warped, green + b * img, netin + b * img * kNetInC + 0, nb, H / 2, W / 2, (int64_t)H * W * kNetInC,
+                                      kNetInC, 1, s));
+            if (h->cfg.future) {
+                HIPCHK(h, launch_warp_nchw(rn_ + b * in.rawf, fn_ + b * in.flowf, warped, nb, 4, H / 2, W / 2, s));
+                HIPCHK(h, launch_demosaic(warped, green + b * img, netin + b * img * kNetInC + 6, nb, H / 2, W / 2,
+                                          (int64_t)H * W * kNetInC, kNetInC, 1, s));
+            }
+        }
+    } else {
+        // the whole NHWC16 input pixel in one pass: warp of the previous output | demosaic of the current frame |
+        // warp of the demosaicked next frame
+        float* next4 = nullptr;
+        if (h->cfg.future) {
+            next4 = h->next4 + o * img * 4;
+            HIPCHK(h, launch_demosaic(rn_, green, next4, n, H / 2, W / 2, (int64_t)H * W * 4, 4, 1, s, (int64_t)in.rawf));
+        }
+        Scope sc(h, s, "netin(ha_green+netin_kernel)", 0.0, (double)n * img * (16.0 + 16.0 + 48.0 + (next4 ? 16.0 : 0.0)));
+        HIPCHK(h, launch_netin(rc_, green, h->lastden4 + o * img * 4, fp_, next4, fn_, netin, n, H / 2, W / 2, s, (int64_t)in.rawf,
+                               (int64_t)in.flowf));
+    }
+    if (h->has_feat() && !nw) {
+        Scope sc(h, s, "warp48_kernel", 0.0, (double)n * img * (384.0 + 2.0));
+        HIPCHK(h, launch_warp48(h->lastfeat + o * img * kF, fp_, h->featw + o * img * kF, n, H, W, s, (int64_t)in.flowf));
+    }
+    return RVDD_OK;
+}
+
 // Every launch of one frame-step, in order, on stream s.  `init` = first frame of a video.
 int enqueue_step(rvdd_t* h, const float* raw_prev, const float* raw_cur, const float* raw_next, const float* flow_prev,
                  const float* flow_next, int64_t raw_stride, int64_t flow_stride, float* out_rgb, bool init, hipStream_t s) {
     const bool nw = h->no_warp;
     const int B = h->cfg.batch, H = h->cfg.height, W = h->cfg.width;
     const size_t npix = (size_t)B * H * W;
-    // sequences of the caller's raw / flow tensors that are not back to back (channel slices of a wider tensor):
-    // the stages that read them run once per sequence
-    const size_t rawf = raw_stride ? (size_t)raw_stride : (size_t)4 * (H / 2) * (W / 2);
-    const size_t flowf = flow_stride ? (size_t)flow_stride : (size_t)2 * (H / 2) * (W / 2);
-    const bool dense = rawf == (size_t)4 * (H / 2) * (W / 2) && flowf == (size_t)2 * (H / 2) * (W / 2);
-    const size_t img = (size_t)H * W;
-    auto per_sequence = [&](Sub sb, const std::function<int(Sub)>& f) -> int {
-        if (dense) return f(sb);
-        for (int b = sb.b0; b < sb.b0 + sb.nb; ++b) RC(f(Sub{b, 1}));
-        return RVDD_OK;
-    };
+    StepInputs in;
+    in.raw_cur = raw_cur; in.raw_next = raw_next; in.flow_prev = flow_prev; in.flow_next = flow_next;
+    in.rawf = raw_stride ? (size_t)raw_stride : (size_t)4 * (H / 2) * (W / 2);
+    in.flowf = flow_stride ? (size_t)flow_stride : (size_t)2 * (H / 2) * (W / 2);
     if (init) {
         // lastden = n[:, :3] (demosaiced previous noisy frame), features = 0
         // (models/recurrent_model.py:233-245)
-        RC(per_sequence(Sub{0, B}, [&](Sub sb) -> int {
-            HIPCHK(h, launch_demosaic(raw_prev + sb.b0 * rawf, h->green + sb.b0 * img, h->lastden4 + sb.b0 * img * 4, sb.nb, H / 2,
-                                      W / 2, (int64_t)H * W * 4, 4, 1, s));
-            return RVDD_OK;
-        }));
+        HIPCHK(h, launch_demosaic(raw_prev, h->green, h->lastden4, B, H / 2, W / 2, (int64_t)H * W * 4, 4, 1, s, (int64_t)in.rawf));
         if (h->has_feat()) HIPCHK(h, hipMemsetAsync(h->lastfeat, 0, npix * kF * sizeof(float), s));
     }
-    // the stages in front of the net, for sequences [b0, b0 + nb) (run_convunet calls it per sequence when the
-    // full-resolution stages run depth first)
-    Prologue stages = [&](Sub sb) -> int {
-        const size_t o = (size_t)sb.b0;
-        const int n = sb.nb;
-        const float* rc_ = raw_cur + o * rawf;
-        const float* fp_ = flow_prev ? flow_prev + o * flowf : nullptr;
-        const float* rn_ = raw_next ? raw_next + o * rawf : nullptr;
-        const float* fn_ = flow_next ? flow_next + o * flowf : nullptr;
-        float* green = h->green + o * img;
-        float* netin = h->netin + o * img * kNetInC;
-        if (h->warp_raw && !nw) {
-            {
-                Scope sc(h, s, "demosaic(ha_green+ha_rb)", 0.0, (double)n * img * 16.0);
-                HIPCHK(h, launch_demosaic(rc_, green, netin + 3, n, H / 2, W / 2, (int64_t)H * W * kNetInC, kNetInC, 1, s));
-            }
-            // warp_frame with --warp_raw (models/recurrent_model.py:149-152): HA(warp(remosaick(frame), raw-resolution flow)).
-            // remosaick(HA(raw)) is raw itself, so the next frame is warped as it came.  next4 is free in this mode: its
-            // first quarter holds the re-mosaicked previous output, the second the warped planes.
-            float* packed = h->next4 + o * img;
-            float* warped = h->next4 + npix + o * img;
-            HIPCHK(h, launch_remosaick4(h->lastden4 + o * img * 4, packed, n, H, W, s));
-            HIPCHK(h, launch_warp_nchw(packed, fp_, warped, n, 4, H / 2, W / 2, s));
-            HIPCHK(h, launch_demosaic(warped, green, netin + 0, n, H / 2, W / 2, (int64_t)H * W * kNetInC, kNetInC, 1, s));
-            if (h->cfg.future) {
-                HIPCHK(h, launch_warp_nchw(rn_, fn_, warped, n, 4, H / 2, W / 2, s));
-                HIPCHK(h, launch_demosaic(warped, green, netin + 6, n, H / 2, W / 2, (int64_t)H * W * kNetInC, kNetInC, 1, s));
-            }
-        } else {
-            // the whole NHWC16 input pixel in one pass: warp of the previous output | demosaic of the current frame |
-            // warp of the demosaicked next frame
-            float* next4 = nullptr;
-            if (h->cfg.future) {
-                next4 = h->next4 + o * img * 4;
-                HIPCHK(h, launch_demosaic(rn_, green, next4, n, H / 2, W / 2, (int64_t)H * W * 4, 4, 1, s));
-            }
-            Scope sc(h, s, "netin(ha_green+netin_kernel)", 0.0, (double)n * img * (16.0 + 16.0 + 48.0 + (next4 ? 16.0 : 0.0)));
-            HIPCHK(h, launch_netin(rc_, green, h->lastden4 + o * img * 4, fp_, next4, fn_, netin, n, H / 2, W / 2, s));
-        }
-        if (h->has_feat() && !nw) {
-            Scope sc(h, s, "warp48_kernel", 0.0, (double)n * img * (384.0 + 2.0));
-            HIPCHK(h, launch_warp48(h->lastfeat + o * img * kF, fp_, h->featw + o * img * kF, n, H, W, s));
-        }
-        return RVDD_OK;
-    };
-    Prologue prologue = [&](Sub sb) -> int { return per_sequence(sb, stages); };
     // without warping the previous features are read in place: the net consumes them in its first layer and only
     // its last one writes the new ones
-    const int rc = run_net(h, h->netin, nw ? h->lastfeat : h->featw, h->lastfeat, out_rgb, h->lastden4, s, prologue);
+    const int rc = run_net(h, h->netin, nw ? h->lastfeat : h->featw, h->lastfeat, out_rgb, h->lastden4, s, &in);
     if (rc == RVDD_OK && h->prev_noisy)     // store_frame = the noisy current frame (models/recurrent_model.py:335-337)
-        RC(per_sequence(Sub{0, B}, [&](Sub sb) -> int {
-            HIPCHK(h, launch_demosaic(raw_cur + sb.b0 * rawf, h->green + sb.b0 * img, h->lastden4 + sb.b0 * img * 4, sb.nb, H / 2,
-                                      W / 2, (int64_t)H * W * 4, 4, 1, s));
-            return RVDD_OK;
-        }));
+        HIPCHK(h, launch_demosaic(raw_cur, h->green, h->lastden4, B, H / 2, W / 2, (int64_t)H * W * 4, 4, 1, s, (int64_t)in.rawf));
     return rc;
 }
 
@@ -1049,11 +1065,17 @@ int rvdd_step_strided(rvdd_t* h, const float* raw_prev, const float* raw_cur, co
     if (h->cfg.future && (!raw_next || (!flow_next && !nw))) return fail(h, RVDD_ERR_ARG, "rvdd_step: raw_next and flow_next are required when future=1");
     if (nw) flow_prev = flow_next = nullptr;      // the flows are not looked at (the reference's dataset does not even load them)
     hipStream_t s = static_cast<hipStream_t>(stream);
+    // need_init is cleared only once the step has been enqueued: a step that failed half way leaves the handle asking
+    // for the first frame of a video again (raw_prev, zeroed features), never a later frame on stale state
     const bool init = h->need_init;
-    h->need_init = false;
+    auto eager = [&]() -> int {
+        const int rc = enqueue_step(h, raw_prev, raw_cur, raw_next, flow_prev, flow_next, raw_stride, flow_stride, out_rgb, init, s);
+        if (rc == RVDD_OK) h->need_init = false;
+        return rc;
+    };
     if (!h->use_graphs || h->prof_on || !h->ran_eagerly || !h->gstream) {
         h->ran_eagerly = true;
-        return enqueue_step(h, raw_prev, raw_cur, raw_next, flow_prev, flow_next, raw_stride, flow_stride, out_rgb, init, s);
+        return eager();
     }
     rvdd_handle::StepKey key{{init ? raw_prev : nullptr, raw_cur, raw_next, flow_prev, flow_next, out_rgb},
                              {raw_stride, flow_stride}, (init ? 1 : 0) | (h->serpentine ? 2 : 0)};
@@ -1071,12 +1093,12 @@ int rvdd_step_strided(rvdd_t* h, const float* raw_prev, const float* raw_cur, co
         }
         if (e == hipSuccess && rc == RVDD_OK) e = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
         if (e != hipSuccess || rc != RVDD_OK) {
-            // no graph for this process: say why once, run launch by launch from here on
+            // no graph for this process: run this step and every later one launch by launch, on the caller's stream
+            // (whatever failed -- the capture, the instantiation or a launch inside the capture -- nothing has run yet)
             if (g) (void)hipGraphDestroy(g);
             (void)hipGetLastError();
             h->use_graphs = 0;
-            if (rc != RVDD_OK) return rc;
-            return enqueue_step(h, raw_prev, raw_cur, raw_next, flow_prev, flow_next, raw_stride, flow_stride, out_rgb, init, s);
+            return eager();
         }
         if (h->graphs.size() >= kMaxStepGraphs) {
             auto old = h->graphs.begin();
@@ -1097,6 +1119,7 @@ int rvdd_step_strided(rvdd_t* h, const float* raw_prev, const float* raw_cur, co
     HIPCHK(h, hipGraphLaunch(it->second.exec, h->gstream));
     HIPCHK(h, hipEventRecord(h->g_out, h->gstream));
     HIPCHK(h, hipStreamWaitEvent(s, h->g_out, 0));
+    h->need_init = false;
     if (seq_major_on(h)) h->serpentine = !h->serpentine;
     return RVDD_OK;
 }
@@ -1156,7 +1179,7 @@ int rvdd_unet_forward(rvdd_t* h, const float* x, const float* feat_in, float* ou
     const int B = h->cfg.batch, H = h->cfg.height, W = h->cfg.width;
     HIPCHK(h, launch_nchw_to_nhwc(x, h->netin, B, h->cin_real(), H, W, kNetInC, s));
     if (h->has_feat()) HIPCHK(h, launch_nchw_to_nhwc(feat_in, h->featw, B, kF, H, W, kF, s));
-    RC(run_net(h, h->netin, h->featw, h->lv[0].t[2], out, nullptr, s, Prologue()));
+    RC(run_net(h, h->netin, h->featw, h->lv[0].t[2], out, nullptr, s, nullptr));
     if (h->has_feat() && feat_out) HIPCHK(h, launch_nhwc_to_nchw(h->lv[0].t[2], feat_out, B, kF, H, W, kF, s));
     return RVDD_OK;
 }
@@ -1309,7 +1332,7 @@ int rvdd_debug_conv_bench(rvdd_t* h, int32_t variant, int32_t level, int32_t ite
     conv3x3_set_variant(variant == 3 ? 0 : variant);
     ConvCall c;
     c.in = h->lv[level].t[0]; c.out = h->lv[level].t[1]; c.H = h->lv[level].H; c.W = h->lv[level].W; c.epi = EPI_RELU;
-    const Conv3& L = h->conv3.at("EncoderConvs.1.blocks.1.0");
+    const Conv3& L = h->cu[CU_ENC1_1];
     int rc = run_conv(h, L, c, s);   // warm-up (also sets the function attribute)
     if (rc == RVDD_OK) {
         (void)hipEventRecord(h->t0, s);

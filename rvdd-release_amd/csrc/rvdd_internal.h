@@ -73,21 +73,24 @@ void conv3x3_set_variant(int v);   // A/B switch used by rvdd_debug_conv_bench o
 
 // -------------------------------------------------------------- pre-stages --
 // Hamilton-Adams: raw [n][4][h][w] -> green plane scratch [n][2h][2w] -> RGB
-// written at out[b*bstride + (y*W+x)*pstride + c*cstride].
+// written at out[b*bstride + (y*W+x)*pstride + c*cstride].  raw_bstride: floats between the raw frames of consecutive
+// sequences (0 = dense, 4hw): the caller's raw frames may be channel slices of a wider [B][4k][h][w] tensor.
 hipError_t launch_demosaic(const float* raw, float* green_scratch, float* out, int n, int h, int w,
-                           int64_t bstride, int pstride, int cstride, hipStream_t s);
+                           int64_t bstride, int pstride, int cstride, hipStream_t s, int64_t raw_bstride = 0);
 
 // bicubic backward warp with the raw-resolution flow (x2 bilinear upsample,
 // align_corners=True, times 2, fused).  src NHWC4 -> dst[(b*H*W + p)*dpstride + c], c<3.
 hipError_t launch_warp3(const float* src4, const float* flow_raw, float* dst, int dpstride, int B,
                         int H, int W, hipStream_t s);
 // The NHWC16 network input of a step in one pass: warp3 of prev4 | demosaic of raw_cur | warp3 of next4 (or zeros when
-// next4 == nullptr); flows nullptr = --no_warp.  Dense [B][4][h][w] raw, [B][2][h][w] flows; green_scratch [B][2h][2w].
+// next4 == nullptr); flows nullptr = --no_warp.  [B][4][h][w] raw, [B][2][h][w] flows, dense inside a sequence, with
+// raw_bstride / flow_bstride floats from one sequence to the next (0 = dense); green_scratch [B][2h][2w].
 hipError_t launch_netin(const float* raw_cur, float* green_scratch, const float* prev4, const float* flow_prev,
-                        const float* next4, const float* flow_next, float* netin, int B, int h, int w, hipStream_t s);
+                        const float* next4, const float* flow_next, float* netin, int B, int h, int w, hipStream_t s,
+                        int64_t raw_bstride = 0, int64_t flow_bstride = 0);
 // src NHWC48 -> dst NHWC48.
 hipError_t launch_warp48(const float* src, const float* flow_raw, float* dst, int B, int H, int W,
-                         hipStream_t s);
+                         hipStream_t s, int64_t flow_bstride = 0);
 // generic NCHW warp with a full-resolution flow (util.flow_utils.warp).
 hipError_t launch_remosaick4(const float* rgb4, float* raw, int B, int H, int W, hipStream_t s);
 hipError_t launch_warp_nchw(const float* x, const float* flow, float* y, int n, int c, int H, int W,

@@ -72,7 +72,7 @@ class recurrentModel(BaseModel):
         if C != 4 * (2 + fD) or (not no_warp and self.flow.shape[1] != 1 + fD):
             raise RuntimeError(f"input 'n' has {C} channels / 'flow' {None if no_warp else tuple(self.flow.shape)}; "
                                f"expected {4 * (2 + fD)} raw channels and {1 + fD} flows")
-        rt = self._netDenoise.runtime_for(B, 2 * h, 2 * w)
+        rt = self._netDenoise.runtime_for(B, 2 * h, 2 * w, pin=True)
         if rt is not self._rt:
             self._rt = rt
             rt.set_option("no_warp", int(no_warp))

@@ -95,17 +95,21 @@ class HipDenoiser:
     # sizes only.  A validation run sees one or two sizes; a loop over many sizes must not pile them up.
     MAX_CACHED_RUNTIMES = 2
 
-    def runtime_for(self, B: int, H: int, W: int) -> RvddRuntime:
+    def runtime_for(self, B: int, H: int, W: int, pin: bool = False) -> RvddRuntime:
+        """The runtime of one frame size.  `pin=True` (recurrentModel.forward) marks it as the one that holds a
+        video's recurrent state: it is never evicted by calls at other sizes, only replaced by the next pin."""
         key = (B, H, W)
+        if pin:
+            self._pinned = key
         rt = self._rt.get(key)
         if rt is not None:
             self._rt.move_to_end(key)
             return rt
         if self._sd is None:
             raise RuntimeError("rvdd: weights not loaded (call load_state_dict / model.setup first)")
-        while len(self._rt) >= self.MAX_CACHED_RUNTIMES:
-            _, old = self._rt.popitem(last=False)
-            old.close()
+        evictable = [k for k in self._rt if k != getattr(self, "_pinned", None)]      # least recently used first
+        while len(self._rt) >= self.MAX_CACHED_RUNTIMES and evictable:
+            self._rt.pop(evictable.pop(0)).close()
         rt = RvddRuntime(self._arch, self.future, B, H, W, self.device_index)
         rt.load_state_dict(self._sd)
         self._rt[key] = rt

@@ -78,6 +78,9 @@ class RvddRuntime:
 
     # -- helpers ----------------------------------------------------------
     def _check(self, rc: int, what: str):
+        if rc != 0 and not (getattr(self, "h", None) is not None and self.h.value):
+            raise RuntimeError(f"{what}: this RvddRuntime is closed (evicted from the denoiser's cache of frame sizes, or "
+                               "closed explicitly) -- fetch a live one with net.runtime_for(B, H, W)")
         if rc != 0:
             raise RuntimeError(f"{what} failed ({rc}): {self.lib.rvdd_last_error(self.h).decode()}")
 

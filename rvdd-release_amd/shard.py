@@ -21,12 +21,20 @@ import torch
 
 def init_distributed(backend: Optional[str] = None, device: Optional[torch.device] = None):
     """-> (rank, local_rank, world, dist_module_or_None).  Reads the
-    torch.distributed.run environment; a single process needs no group."""
+    torch.distributed.run environment.  Whenever a launcher has set RANK and
+    WORLD_SIZE the process group IS initialised -- at world size 1 too, so that
+    `torch.distributed.run --nproc-per-node 1` runs the same RCCL init and the
+    same collectives on device tensors as the 8-GPU job does; only a plain
+    `python bench.py` (no launcher environment) runs without a group."""
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world == 1:
+    if "RANK" not in os.environ or "WORLD_SIZE" not in os.environ:
+        if world != 1:
+            raise RuntimeError("WORLD_SIZE is set without RANK: start the ranks with torch.distributed.run")
         return rank, local_rank, world, None
+    # the host driver only supports dmabuf IPC; RCCL's intra-node transport needs this before its first call
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch.distributed as dist
     if not dist.is_initialized():
         if backend is None:

@@ -22,6 +22,29 @@ VARIANTS = {
 }
 
 
+# whole-sequence fixtures (tools/make_golden_long.py): name -> (weights stem, arch, BASELINE config mirrored)
+LONG = {
+    "long30-feat-iso3200": ("recurrent-convunet+feat-iso3200", "convunet+feat", "C2"),
+    "long30-feat-future-iso12800": ("recurrent-convunet+feat-future-iso12800", "convunet+feat", "C3"),
+    "long30-next-feat-future-iso3200": ("recurrent-ConvNeXtUnet+feat-future-iso3200", "next+feat", "C4"),
+    "long90-feat-iso3200": ("recurrent-convunet+feat-iso3200", "convunet+feat", "C5"),
+}
+
+
+def load_long(name):
+    """-> (fixture dict of tensors, the regenerated input sequence).  The fixture stores the generator arguments and
+    every 7th input frame; the regenerated inputs must agree with those (float noise of another CPU's libm aside)."""
+    import numpy as np
+    import torch
+    from rvdd_release_amd import synth
+    g = {k: torch.from_numpy(v) for k, v in np.load(os.path.join(GOLDEN, f"seq_{name}.npz")).items()}
+    T, H, W, iso, seed, fut = (int(v) for v in g["args"])
+    seq = synth.make_sequence(T, H, W, iso=iso, seed=seed)
+    for key, got in (("raw", seq.raw), ("flow_prev", seq.flow_prev), ("flow_next", seq.flow_next), ("gt", seq.gt)):
+        assert (got[::7] - g[key + "_check"]).abs().max() < 1e-5, f"{name}: regenerated {key} differs from the fixture's"
+    return g, seq
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

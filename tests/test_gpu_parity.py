@@ -719,3 +719,49 @@ def test_warp_raw_model_surface(name, stem, fut):
     from rvdd_release_amd.runtime import RvddRuntime
     with pytest.raises(RuntimeError, match="feature recurrence"):
         RvddRuntime("convunet+feat", 0, 1, 32, 48, 0).set_option("warp_raw", 1)
+
+
+def test_model_runtime_survives_denoiser_calls_at_other_sizes():
+    """The denoiser keeps the runtimes of the last two frame sizes; the one that holds a video's recurrent state
+    (handed to recurrentModel.forward) is pinned: direct calls of the net at other sizes must not evict it, and the
+    video continues bit for bit.  A runtime that WAS closed says so."""
+    from rvdd_release_amd.models import create_model
+    from rvdd_release_amd.options import make_opt
+    from rvdd_release_amd.runtime import RvddRuntime
+    g = _npz("seq_feat-iso3200.npz")
+    stem = "recurrent-convunet+feat-iso3200"
+
+    def frames(model, disturb):
+        outs = []
+        for t in range(1, 4):
+            data = {"n": torch.cat((g["raw"][t - 1], g["raw"][t]), 0)[None], "flow": g["flow_prev"][t][None, None],
+                    "gt": torch.cat((g["gt"][t - 1], g["gt"][t]), 0)[None], "n_path": ["a"], "gt_path": ["a"],
+                    "FirstOfVideo": t == 1}
+            model.set_input(data)
+            model.test()
+            if disturb:
+                net = model._netDenoise
+                saved = net.get_current_features()
+                for (H, W) in ((16, 24), (24, 16), (40, 40)):
+                    net.get_rec_nil_features(1, H, W)
+                    net(torch.zeros(1, 6, H, W).cuda())
+                net.set_rec_features(saved)
+            model.compute_losses()                        # on the pinned runtime, still alive
+            outs.append(model.get_current_visuals()["denoised"].clone())
+        return outs
+
+    def make():
+        opt = make_opt(netDenoiser="convunet-mode=fixedfeatures+feat", feature_rec=True, path2epoch=os.path.join(WEIGHTS, stem), gpu_ids=[0])
+        m = create_model(opt)
+        m.setup(opt)
+        opt.isTrain = m.isTrain = False
+        return m.eval() or m
+
+    a, b = frames(make(), False), frames(make(), True)
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+    rt = RvddRuntime("convunet+feat", 0, 1, 32, 48, 0)
+    rt.load_state_dict(load_weights(stem))
+    rt.close()
+    with pytest.raises(RuntimeError, match="is closed"):
+        rt.reset()

@@ -11,7 +11,7 @@ import pytest
 import torch
 
 import rvdd_oracle as O
-from conftest import GOLDEN, VARIANTS, load_weights
+from conftest import GOLDEN, LONG, VARIANTS, load_long, load_weights
 
 
 def _npz(name):
@@ -102,3 +102,23 @@ def test_warp_raw_sequence_matches_reference(name, stem, fut):
         den = rec.step(g["raw"][t - 1][None], g["raw"][t][None], g["raw"][t + 1][None] if fut else None,
                        g["flow_prev"][t][None], g["flow_next"][t][None] if fut else None, first=(t == 1))
         assert (den[0] - g["denoised"][k]).abs().max() < 2e-5
+
+
+@pytest.mark.parametrize("name", sorted(LONG))
+def test_whole_sequence_matches_reference(name):
+    """30 / 90 dependent steps (models/recurrent_model.py:335-345 feeds each output back): the oracle against the
+    reference's own run over BASELINE's sequence lengths (tools/make_golden_long.py) -- stored frames, last features,
+    and the reference's L1 / PSNR of EVERY frame."""
+    stem, _, _ = LONG[name]
+    g, seq = load_long(name)
+    fut = int(g["args"][5])
+    orc = O.RecurrentOracle(load_weights(stem), future=fut)
+    outs = orc.run_sequence(seq.raw, seq.flow_prev, seq.flow_next)
+    assert outs.shape[0] == g["PSNR"].shape[0]
+    curve = [float((outs[int(k)] - g["denoised"][i]).abs().max()) for i, k in enumerate(g["keep"])]
+    assert max(curve) < 2e-5, curve
+    assert (orc.lastfeat[0] - g["feat_last"]).abs().max() < 5e-5
+    for i in range(outs.shape[0]):
+        gt = seq.gt[i + 1][None]
+        assert abs(O.psnr(outs[i][None], gt) - float(g["PSNR"][i])) < 1e-3, i
+        assert abs(O.l1_loss(outs[i][None], gt) - float(g["L1"][i])) < 1e-4, i

@@ -4,6 +4,9 @@
 # "Request exceeds the capabilities of the hardware" otherwise, after which rocprofv3 hangs until the timeout).
 # usage (GPU box, repo root): bash tools/gpu_pmc.sh <tag> "<group>:<group>..." <bench args...>
 set -o pipefail
+# single-GPU tool: `bench.py --gpus N` starts its ranks as child processes, and a launcher hop behind the profiler's
+# preload (which has already initialised the GPU in the python process) is the re-exec this pool forbids
+for a in "$@"; do case "$a" in --gpus|--gpus=*) echo "$0: do not pass --gpus (profile one rank: python3 bench.py ...)" >&2; exit 2;; esac; done
 TAG=$1; GROUPS_=$2; shift 2
 ROOT=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$ROOT/gpurun_out/pmc_$TAG

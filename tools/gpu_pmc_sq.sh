@@ -2,6 +2,9 @@
 # SQ counters of the bench kernels (MFMA utilisation, VALU activity, LDS bank conflicts), one --pmc pass each.
 # usage (GPU box, repo root): bash tools/gpu_pmc_sq.sh <tag> [bench args...]
 set -o pipefail
+# single-GPU tool: `bench.py --gpus N` starts its ranks as child processes, and a launcher hop behind the profiler's
+# preload (which has already initialised the GPU in the python process) is the re-exec this pool forbids
+for a in "$@"; do case "$a" in --gpus|--gpus=*) echo "$0: do not pass --gpus (profile one rank: python3 bench.py ...)" >&2; exit 2;; esac; done
 TAG=${1:-r01}; shift
 ROOT=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$ROOT/gpurun_out/sq_$TAG

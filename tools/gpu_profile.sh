@@ -3,6 +3,9 @@
 # traffic counters in their own passes (FETCH_SIZE and WRITE_SIZE do not fit one pass).
 # usage (on the GPU box, from the repo root): bash tools/gpu_profile.sh <tag> [bench args...]
 set -o pipefail
+# single-GPU tool: `bench.py --gpus N` starts its ranks as child processes, and a launcher hop behind the profiler's
+# preload (which has already initialised the GPU in the python process) is the re-exec this pool forbids
+for a in "$@"; do case "$a" in --gpus|--gpus=*) echo "$0: do not pass --gpus (profile one rank: python3 bench.py ...)" >&2; exit 2;; esac; done
 TAG=${1:-r01}; shift
 ROOT=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$ROOT/gpurun_out/prof_$TAG

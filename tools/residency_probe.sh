@@ -3,6 +3,9 @@
 # GPU-busy cycles) and SQ_WAVES, one rocprofv3 --pmc pass; prints the largest dispatches of kernels matching $1
 # usage (GPU box, repo root): bash tools/residency_probe.sh <kernel-substring> <bench args...>
 set -o pipefail
+# single-GPU tool: `bench.py --gpus N` starts its ranks as child processes, and a launcher hop behind the profiler's
+# preload (which has already initialised the GPU in the python process) is the re-exec this pool forbids
+for a in "$@"; do case "$a" in --gpus|--gpus=*) echo "$0: do not pass --gpus (profile one rank: python3 bench.py ...)" >&2; exit 2;; esac; done
 KERN=$1; shift
 ROOT=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$ROOT/gpurun_out/resid
