@@ -553,6 +553,347 @@ __global__ __launch_bounds__(64 * NW, NPB == 2 ? 1 : 8 / NW) void mlp_kernel(con
     }
 }
 
+// ------------------------------------- the whole ConvBlock in one kernel --
+// convblock_kernel = dwln_kernel's depth-wise phase + LayerNorm, then mlp_kernel's two GEMMs, per 16x16-pixel tile,
+// in ONE persistent workgroup per CU (networks/new_unet.py:74-103).  What the fusion removes:
+//   * the LayerNorm map: written (192 B/px) by one kernel and read back by the other, per block;
+//   * the depth-wise kernel's exposed LDS-DMA latency: the two chunks a tile starts with are requested BEFORE the
+//     MLP phase of the tile in front of it and land under its ~45 k cycles of MFMAs; only the third chunk of a tile is
+//     requested inside the depth-wise phase (under the FMAs of the second);
+//   * one kernel boundary per block (25 per frame-step).
+// What it cannot remove: on gfx950 the f32 MFMA executes on the SIMD's fp32 lanes, so the depth-wise FMAs (13 % of
+// the block's flops) cost their full VALU time beside the MFMAs -- they are now the ONLY thing the phase waits for.
+//
+// LDS (149.5 KiB, one workgroup of four waves per CU): fc1 | fc2 (72 KiB) | biases, layerscale, 1x1 (1.7 KiB) |
+// depth-wise taps (9.2 KiB) | dw bias, LN weight, LN bias | two 33-KiB halo chunk buffers.  The LayerNorm result
+// changes hands through the chunk buffers, which are dead by then: the depth-wise phase leaves a lane with 4 adjacent
+// pixels x 4 channels per chunk (convnext.hip dwln lane map), the GEMMs want pixel = lane & 15, channels 4 (lane >> 4)..
+// (the MFMA B-operand map).  A wave's four tile rows are its own four 16-pixel groups, so the exchange is wave-private:
+// [row 4][chunk 3][pixel 16][16 floats], the four 16-byte slots of a pixel XOR-swizzled by (pixel >> 2) ^ sigma(group)
+// with sigma = {0, 3, 1, 2}: every ds_read_b128 lane group {0-3, 12-15, 20-27}, ... then covers 16 distinct slots.
+constexpr int F_BV_FLOATS = M2_BV_FLOATS + 148;                           // fc1_b | fc2_b | layerscale | w3 [3][48] | b3 (+pad)
+constexpr int F_OFF_W2 = M_W_FLOATS;
+constexpr int F_OFF_BV = 2 * M_W_FLOATS;
+constexpr int F_OFF_DW = F_OFF_BV + F_BV_FLOATS;
+constexpr int F_OFF_PAR = F_OFF_DW + D_W_FLOATS;
+constexpr int F_OFF_T = F_OFF_PAR + E_PAR_FLOATS;
+constexpr size_t F_LDS_BYTES = (size_t)(F_OFF_T + 2 * E_BUF_FLOATS) * 4;  // 153,040 B
+static_assert(F_LDS_BYTES <= 160 * 1024 && (F_OFF_T % 4) == 0 && 4 * 3072 <= 2 * E_BUF_FLOATS, "LDS plan");
+// Vector-memory instructions EVERY wave issues in the MLP phase of a tile, i.e. after the LDS-DMA of the next tile's
+// first two chunks: per 16-pixel group 3 residual loads + 3 stores through buffer descriptors (issued whether the row
+// exists or not: a missing row has zero records).  vmcnt retires in issue order, so "all but the newest 24" covers the
+// DMA; the conditional stores of the OUT3 epilogue are not counted -- a lower bound only makes the wait conservative.
+constexpr int F_MLP_VMEM = 4 * 6;
+
+template <bool OUT3>
+__global__ __launch_bounds__(256, 1) void convblock_kernel(const float* __restrict__ x, NextBlockW wt, float* __restrict__ out,
+                                                          int B, int H, int W, int tiles_x, int tiles_y, int ntiles, Out3 o3) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* W1 = smem;
+    float* W2 = smem + F_OFF_W2;
+    float* BV = smem + F_OFF_BV;
+    float* Wl = smem + F_OFF_DW;            // [49][48]
+    float* Pl = smem + F_OFF_PAR;           // dw_b | ln_w | ln_b
+    float* Tl = smem + F_OFF_T;             // two chunk buffers; the LayerNorm exchange between the phases
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    // ---- tiles: as dwln_kernel (persistent, the workgroups of one XCD walk one contiguous band)
+    const int per_xcd = (ntiles + 7) >> 3;
+    const int band_end = min(((int)(blockIdx.x & 7) + 1) * per_xcd, ntiles);
+    const int stride = (int)(gridDim.x >> 3);
+    int tile = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+    if (tile >= band_end) return;
+    const int tiles_per_img = tiles_x * tiles_y;
+    struct TilePos { int b, y0, x0; };
+    auto locate = [&](int t) {
+        TilePos p;
+        p.b = t / tiles_per_img;
+        const int rr = t - p.b * tiles_per_img;
+        const int ty = rr / tiles_x;
+        p.y0 = ty * E_TH;
+        p.x0 = (rr - ty * tiles_x) * E_TW;
+        return p;
+    };
+
+    // ---- depth-wise phase: lane -> (row of the wave's four rows, quad of four pixels, channel group), see dwln_kernel
+    const int g = lane & 3;
+    const int idx = lane >> 2;
+    const int quad = idx & 3;
+    const int rw = ((idx >> 3) << 1) + (__builtin_popcount(idx & 7) & 1);      // row inside the wave's four
+    const int row = wave * 4 + rw;
+    int piece_yx[9];
+#pragma unroll
+    for (int n = 0; n < 9; ++n) {
+        const int k = wave + 4 * n;
+        const int R = k * 4 + (lane >> 4), sl = lane & 15;
+        const int p = 4 * R + ((sl >> 2) ^ (R & 3));
+        const int iy = p / E_PITCH, ix = p - iy * E_PITCH;
+        piece_yx[n] = (k < E_PIECES && ix < E_TW + 6) ? (iy << 8) | ix : -1;
+    }
+    auto dma_chunk = [&](const TilePos& tp, int j, int buf) {
+        __amdgpu_buffer_rsrc_t ir =
+            __builtin_amdgcn_make_buffer_rsrc((void*)(x + (size_t)tp.b * H * W * kF), 0, H * W * kF * 4, 0x00020000);
+        float* dst = Tl + buf * E_BUF_FLOATS;
+#pragma unroll
+        for (int n = 0; n < 9; ++n) {
+            const int k = wave + 4 * n;
+            if (k < E_PIECES) {
+                const int gy = tp.y0 - 3 + (piece_yx[n] >> 8), gx = tp.x0 - 3 + (piece_yx[n] & 255);
+                const bool ok = piece_yx[n] >= 0 && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+                dma16(ir, dst + k * 256, ok ? (unsigned)(((gy * W + gx) * kF + 16 * j + 4 * (lane & 3)) * 4) : 0x80000000u);
+            }
+        }
+    };
+    TilePos cur = locate(tile);
+    dma_chunk(cur, 0, 0);
+    dma_chunk(cur, 1, 1);
+    {   // weights of the block -> LDS, once per workgroup
+        __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc((void*)wt.fc1_w, 0, M_W_FLOATS * 4, 0x00020000);
+        __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc((void*)wt.fc2_w, 0, M_W_FLOATS * 4, 0x00020000);
+        for (int k = wave; k < M_W_FLOATS / 256; k += 4) {
+            dma16(r1, W1 + k * 256, (unsigned)(k * 1024 + lane * 16));
+            dma16(r2, W2 + k * 256, (unsigned)(k * 1024 + lane * 16));
+        }
+        for (int i = tid; i < M2_BV_FLOATS; i += 256) BV[i] = i < 192 ? wt.fc1_b[i] : (i < 240 ? wt.fc2_b[i - 192] : wt.ls[i - 240]);
+        if constexpr (OUT3) {
+            if (tid < 147) BV[M2_BV_FLOATS + tid] = tid < 144 ? o3.w[tid] : o3.b[tid - 144];
+        }
+        for (int q = tid; q < D_W_FLOATS / 4; q += 256)
+            reinterpret_cast<f32x4*>(Wl)[q] = reinterpret_cast<const f32x4*>(wt.dw_w)[q];
+        if (tid < E_PAR_FLOATS) Pl[tid] = tid < kF ? wt.dw_b[tid] : (tid < 2 * kF ? wt.ln_w[tid - kF] : wt.ln_b[tid - 2 * kF]);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    const int t0 = (2 * row + quad) & 3;
+    int rd0[4][4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int d = 0; d < 4; ++d) rd0[c][d] = (row * 6 + quad) * 64 + ((d ^ ((t0 + c) & 3)) * 4 + g) * 4;
+
+    // ---- MLP phase: lane -> (pixel lr of a 16-pixel group = one tile row, channel group kk), see mlp_kernel
+    const int lr = lane & 15, kk = lane >> 4;
+    lds_frag* w1p = (lds_frag*)W1 + lane;
+    lds_frag* w2p = (lds_frag*)W2 + lane;
+    lds_frag* bvp = (lds_frag*)BV + kk;
+    asm volatile("" : "+v"(w1p), "+v"(w2p), "+v"(bvp));
+    auto F1 = [&](int j, int m) { return w1p[(j * 12 + m) * 64]; };
+    auto F2 = [&](int m, int mo) { return w2p[(m * 3 + mo) * 64]; };
+    const unsigned lane_off = (unsigned)(lr * (kF * 4) + kk * 16);
+    // the exchange: this wave's [row 4][chunk 3][pixel 16][16 floats]
+    float* Xw = Tl + wave * 3072;
+    const int x_wr = rw * 768 + (4 * quad) * 16 + ((quad ^ (g == 0 ? 0 : g == 1 ? 3 : g == 2 ? 1 : 2)) * 4);     // + j * 256 + i * 16
+    const int x_rd = lr * 16 + (((lr >> 2) ^ (kk == 0 ? 0 : kk == 1 ? 3 : kk == 2 ? 1 : 2)) * 4);               // + n * 768 + j * 256
+
+#pragma unroll 1
+    for (;;) {
+        const int next_tile = tile + stride;
+        const bool more = next_tile < band_end;
+        const TilePos nxt = locate(more ? next_tile : tile);
+        // =========================================================== depth-wise 7x7 (+bias), three 16-channel chunks
+        f32x4 acc[4][3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i][j] = *reinterpret_cast<const f32x4*>(Pl + 16 * j + 4 * g);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            // chunk 0 and 1 were requested before the MLP phase of the tile in front (or in the prologue) and every
+            // wave has waited for its own pieces since; chunk 2 is requested below, once buffer 0 is free
+            if (j == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (j == 1) dma_chunk(cur, 2, 0);
+            const float* tb = Tl + (j & 1) * E_BUF_FLOATS;
+            const float* wb = Wl + 16 * j + 4 * g;
+            f32x4 win[2][10], wv[2][7];
+            auto read_row = [&](int ky, f32x4 (&wn)[10], f32x4 (&ww)[7]) {
+#pragma unroll
+                for (int dx = 0; dx < 10; ++dx)
+                    wn[dx] = *reinterpret_cast<const f32x4*>(tb + rd0[(2 * ky + (dx >> 2)) & 3][dx & 3] + ky * 6 * 64 + (dx >> 2) * 64);
+#pragma unroll
+                for (int kx = 0; kx < 7; ++kx) ww[kx] = *reinterpret_cast<const f32x4*>(wb + (ky * 7 + kx) * kF);
+            };
+            read_row(0, win[0], wv[0]);
+#pragma unroll
+            for (int ky = 0; ky < 7; ++ky) {
+                if (ky + 1 < 7) read_row(ky + 1, win[(ky + 1) & 1], wv[(ky + 1) & 1]);
+#pragma unroll
+                for (int kx = 0; kx < 7; ++kx)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc[i][j] = acc[i][j] + win[ky & 1][i + kx] * wv[ky & 1][kx];
+                asm volatile("" : "+v"(acc[0][j]), "+v"(acc[1][j]), "+v"(acc[2][j]), "+v"(acc[3][j])::"memory");
+            }
+        }
+        // =========================================================== LayerNorm over the 48 channels of each pixel
+        f32x4 lw[3], lb[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            lw[j] = *reinterpret_cast<const f32x4*>(Pl + kF + 16 * j + 4 * g);
+            lb[j] = *reinterpret_cast<const f32x4*>(Pl + 2 * kF + 16 * j + 4 * g);
+        }
+        __syncthreads();                      // every wave is done with both chunk buffers: they become the exchange
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float sm = 0.f;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) sm += (acc[i][j][0] + acc[i][j][1]) + (acc[i][j][2] + acc[i][j][3]);
+            sm += __shfl_xor(sm, 1);
+            sm += __shfl_xor(sm, 2);
+            const float u = sm / 48.f;
+            float v2 = 0.f;
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float d = acc[i][j][r] - u;
+                    v2 += d * d;
+                }
+            v2 += __shfl_xor(v2, 1);
+            v2 += __shfl_xor(v2, 2);
+            const float rden = 1.0f / sqrtf(v2 / 48.f + 1e-6f);
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                f32x4 r;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) r[k] = lw[j][k] * ((acc[i][j][k] - u) * rden) + lb[j][k];
+                *reinterpret_cast<f32x4*>(Xw + x_wr + j * 256 + i * 16) = r;
+            }
+        }
+        // the wave reads back what it wrote itself (LDS operations of a wave complete in order): pixel-per-lane rows
+        f32x4 xc[4][3];
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) xc[n][j] = *reinterpret_cast<const f32x4*>(Xw + x_rd + n * 768 + j * 256);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __syncthreads();                      // the exchange is over: the chunk buffers take the next tile's halo
+        if (more) {
+            dma_chunk(nxt, 0, 0);
+            dma_chunk(nxt, 1, 1);
+        }
+        // =========================================================== MLP on the wave's four rows (groups of 16 pixels)
+        f32x4 wq[2][2], b1n[2];
+        wq[0][0] = F1(0, 0);
+        wq[0][1] = F1(0, 1);
+        b1n[0] = bvp[0];
+        b1n[1] = bvp[4];
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            const int y = cur.y0 + wave * 4 + n;
+            // rows of `x` / `out` under this group: a descriptor over exactly its valid pixels (loads of the others
+            // return zeros, their stores are dropped); EVERY wave issues the same number of memory instructions per
+            // group, valid or not, because the waits on the next tile's chunks count them (f_mlp_vmem)
+            const int valid = y < H ? min(E_TW, W - cur.x0) : 0;
+            const size_t first = ((size_t)cur.b * H + min(y, H - 1)) * W + cur.x0;
+            __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(x + first * kF), 0, valid * (kF * 4), 0x00020000);
+            __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void*)(out + first * kF), 0, valid * (kF * 4), 0x00020000);
+            f32x4 hid[12], a2[3], vq[2][3], xr[3], lv[3];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int st = 0; st < 18; ++st) {
+                const int m = 2 * (st / 3), j = st % 3;
+                if (j == 0) {
+                    hid[m] = b1n[0];
+                    hid[m + 1] = b1n[1];
+                }
+                if (st + 1 < 18) {
+                    wq[(st + 1) & 1][0] = F1((st + 1) % 3, 2 * ((st + 1) / 3));
+                    wq[(st + 1) & 1][1] = F1((st + 1) % 3, 2 * ((st + 1) / 3) + 1);
+                    if (j == 2) {
+                        b1n[0] = bvp[4 * (m + 2)];
+                        b1n[1] = bvp[4 * (m + 3)];
+                    }
+                } else {
+#pragma unroll
+                    for (int mo = 0; mo < 3; ++mo) {
+                        vq[0][mo] = F2(0, mo);
+                        a2[mo] = bvp[48 + 4 * mo];
+                    }
+                }
+                if (j == 1 && m >= 2) {
+                    hid[m - 2] = gelu_phi4(hid[m - 2]);
+                    hid[m - 1] = gelu_phi4(hid[m - 1]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    hid[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[st & 1][0][i], xc[n][j][i], hid[m], 0, 0, 0);
+                    hid[m + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[st & 1][1][i], xc[n][j][i], hid[m + 1], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int j = 0; j < 3; ++j) xr[j] = bload(rx, lane_off + 64 * j);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int m = 0; m < 12; ++m) {
+                if (m + 1 < 12) {
+#pragma unroll
+                    for (int mo = 0; mo < 3; ++mo) vq[(m + 1) & 1][mo] = F2(m + 1, mo);
+                } else {
+                    wq[0][0] = F1(0, 0);
+                    wq[0][1] = F1(0, 1);
+                    b1n[0] = bvp[0];
+                    b1n[1] = bvp[4];
+#pragma unroll
+                    for (int mo = 0; mo < 3; ++mo) lv[mo] = bvp[60 + 4 * mo];
+                }
+                if (m == 1) {
+                    hid[10] = gelu_phi4(hid[10]);
+                    hid[11] = gelu_phi4(hid[11]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int mo = 0; mo < 3; ++mo)
+                        a2[mo] = __builtin_amdgcn_mfma_f32_16x16x4f32(vq[m & 1][mo][r], hid[m][r], a2[mo], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // ---- out = x + layerscale * r
+            float part[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+            for (int mo = 0; mo < 3; ++mo) {
+                const f32x4 v = xr[mo] + lv[mo] * a2[mo];
+                bstore(ro, lane_off + 64 * mo, v);
+                if constexpr (OUT3) {
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        const f32x4 w3 = bvp[M2_BV_FLOATS / 4 + c * 12 + 4 * mo];
+                        part[c] += (v[0] * w3[0] + v[1] * w3[1]) + (v[2] * w3[2] + v[3] * w3[3]);
+                    }
+                }
+            }
+            if constexpr (OUT3) {
+                float t[3];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    float v = part[c];
+                    v += __shfl_xor(v, 16);
+                    v += __shfl_xor(v, 32);
+                    t[c] = v + BV[M2_BV_FLOATS + 144 + c];
+                }
+                if (kk == 0 && lr < valid) {
+                    const size_t p = (size_t)y * W + cur.x0 + lr;
+                    if (o3.nchw) {
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) o3.nchw[((size_t)cur.b * 3 + c) * o3.hw + p] = t[c];
+                    }
+                    if (o3.nhwc4) reinterpret_cast<f32x4*>(o3.nhwc4)[(size_t)cur.b * o3.hw + p] = f32x4{t[0], t[1], t[2], 0.f};
+                }
+            }
+        }
+        if (!more) break;
+        // the next tile's first two chunks were requested before the vector-memory instructions of this phase: all but
+        // those may still be in flight
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(F_MLP_VMEM) : "memory");
+        tile = next_tile;
+        cur = nxt;
+    }
+}
+
 // zero_pad_features (networks/new_unet.py:56-66): src [B][h][w] -> dst [B][H][W] at (oy,ox), zeros elsewhere
 __global__ void pad_copy_kernel(const float* __restrict__ src, float* __restrict__ dst, int B, int h, int w,
                                 int H, int W, int oy, int ox) {
@@ -628,6 +969,30 @@ hipError_t launch_next_mlp_out3(const float* ln, const float* x, float* out, con
                                 hipStream_t s) {
     if (npix <= 0) return hipSuccess;
     return launch_mlp<true>(ln, x, out, w, npix, Out3{w3x48, b3, out_nchw, out_nhwc4, hw}, s);
+}
+
+template <bool OUT3>
+static hipError_t launch_block(const float* x, float* out, const NextBlockW& w, int B, int H, int W, Out3 o3, hipStream_t s) {
+    if ((size_t)H * W * kF * 4 >= 0x80000000ull) return hipErrorInvalidValue;
+    static std::atomic<uint64_t> attr{0};
+    if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(convblock_kernel<OUT3>), F_LDS_BYTES, attr); e != hipSuccess)
+        return e;
+    const int tx = (W + E_TW - 1) / E_TW, ty = (H + E_TH - 1) / E_TH;
+    const int ntiles = B * tx * ty;
+    if (ntiles <= 0) return hipSuccess;
+    // persistent: one workgroup per CU (LDS), never more workgroups than tiles; the XCD band map needs a multiple of 8
+    const int grid = ((std::min(ntiles, num_cus()) + 7) / 8) * 8;
+    hipLaunchKernelGGL(convblock_kernel<OUT3>, dim3(grid), dim3(256), F_LDS_BYTES, s, x, w, out, B, H, W, tx, ty, ntiles, o3);
+    return hipGetLastError();
+}
+
+hipError_t launch_next_block(const float* x, float* out, const NextBlockW& w, int B, int H, int W, hipStream_t s) {
+    return launch_block<false>(x, out, w, B, H, W, Out3{}, s);
+}
+
+hipError_t launch_next_block_out3(const float* x, float* out, const NextBlockW& w, int B, int H, int W, const float* w3x48,
+                                  const float* b3, float* out_nchw, float* out_nhwc4, hipStream_t s) {
+    return launch_block<true>(x, out, w, B, H, W, Out3{w3x48, b3, out_nchw, out_nhwc4, H * W}, s);
 }
 
 hipError_t launch_pad_copy(const float* src, float* dst, int B, int h, int w, int H, int W, int oy, int ox,

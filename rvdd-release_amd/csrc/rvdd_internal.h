@@ -140,6 +140,12 @@ hipError_t launch_next_mlp(const float* ln, const float* x, float* out, const Ne
 hipError_t launch_next_mlp_out3(const float* ln, const float* x, float* out, const NextBlockW& w, int64_t npix,
                                 const float* w3x48, const float* b3, float* out_nchw, float* out_nhwc4, int hw,
                                 hipStream_t s);
+// the whole ConvBlock in ONE kernel (convblock_kernel): x -> x + ls * MLP(LayerNorm(dwconv7x7(x))); x, out NHWC48
+// [B][H][W], out != x.  _out3: also the 1x1 conv 48 -> 3 on the block's output (out_nchw [B][3][H*W], out_nhwc4
+// [B][H*W][4]; either may be null)
+hipError_t launch_next_block(const float* x, float* out, const NextBlockW& w, int B, int H, int W, hipStream_t s);
+hipError_t launch_next_block_out3(const float* x, float* out, const NextBlockW& w, int B, int H, int W, const float* w3x48,
+                                  const float* b3, float* out_nchw, float* out_nhwc4, hipStream_t s);
 // 1x1 projection on MFMA: in1 NHWC[c1] (+ in2 NHWC[c2]) -> out NHWC48; (c1,c2) = (16,0) or (48,48)
 hipError_t launch_proj1x1(const float* in1, int c1, const float* in2, int c2, const float* w,
                           const float* b, float* out, int64_t npix, hipStream_t s);

@@ -34,8 +34,9 @@ constexpr int U_FLOATS = u_floats(3);
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void lds_void;
 
-__device__ __forceinline__ f32x4 bload(__amdgpu_buffer_rsrc_t r, unsigned off) {
-    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
+// voff per lane, soff wave-uniform (an SGPR or an inline constant of the instruction: costs no vector register)
+__device__ __forceinline__ f32x4 bload(__amdgpu_buffer_rsrc_t r, unsigned voff, int soff = 0) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
 }
 __device__ __forceinline__ void bstore(__amdgpu_buffer_rsrc_t r, unsigned off, f32x4 v) {
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, off, 0, 0);
@@ -134,7 +135,9 @@ __device__ __forceinline__ void wino_body(const ConvArgs& a) {
         const int uy = __builtin_amdgcn_readfirstlane(rr / a.tiles_x);
         const int ux = rr - uy * a.tiles_x;
         u.ty = uy * 4 + wave;
-        u.tx = ux * 16 + lr;
+        // the column of the unit's first tile as an opaque scalar: left to itself the optimiser strength-reduces
+        // 32 unit + 2 lr (+ constants) into a per-lane induction variable that lives in a vector register for the whole kernel
+        u.tx = __builtin_amdgcn_readfirstlane(ux * 16) + lr;
     };
     // The 16 patch pixels of a tile: 16 buffer loads of 16 B.  One buffer descriptor PER PATCH ROW (the row index
     // is wave-uniform, so this is scalar work): base = the row's first pixel, num_records = the row's bytes, or 0
@@ -169,7 +172,7 @@ __device__ __forceinline__ void wino_body(const ConvArgs& a) {
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
             const int c = min(max(u.tx - 1 + d, 0), wl - 1);
-            off[d] = (unsigned)(c * (CIN * 4) + (16 * j + 4 * g) * 4);
+            off[d] = (unsigned)(c * (CIN * 4) + 16 * g);
         }
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
@@ -179,7 +182,7 @@ __device__ __forceinline__ void wino_body(const ConvArgs& a) {
             __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
                 (void*)(img + (ptrdiff_t)yi * wl * CIN), 0, u.ty < hl ? wl * CIN * 4 : 0, 0x00020000);
 #pragma unroll
-            for (int d = 0; d < 3; ++d) lo[r * 3 + d] = bload(rs, off[d]);
+            for (int d = 0; d < 3; ++d) lo[r * 3 + d] = bload(rs, off[d], 64 * j);
         }
     };
     // Patch row pr / column pc of tile (ty, tx) is upsampled row 2 ty - 1 + pr / column 2 tx - 1 + pc:
@@ -285,6 +288,9 @@ __device__ __forceinline__ void wino_body(const ConvArgs& a) {
         }
     };
 
+    // the bias through a buffer descriptor (scalar base + one 32-bit lane offset): as a 64-bit per-lane pointer it was
+    // a loop invariant that cost a register pair for the whole kernel
+    __amdgpu_buffer_rsrc_t bias_r = __builtin_amdgcn_make_buffer_rsrc((void*)a.bias, 0, kF * 4, 0x00020000);
     int unit = blockIdx.x;
     UnitPos cur, nxt;
     locate(unit, cur);
@@ -324,7 +330,7 @@ __device__ __forceinline__ void wino_body(const ConvArgs& a) {
             }
         } else {
 #pragma unroll
-            for (int m = 0; m < 3; ++m) acc[5][m] = *reinterpret_cast<const f32x4*>(a.bias + 16 * m + 4 * g);
+            for (int m = 0; m < 3; ++m) acc[5][m] = bload(bias_r, (unsigned)(16 * g), 64 * m);
         }
         if constexpr (NJ == 3) {
             stage(I0{}, XP{}, true, cur, 1);

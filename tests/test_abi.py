@@ -72,3 +72,23 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".inc")):
                 src = open(os.path.join(dp, f)).read()
                 assert "rvdd_oracle" not in src and "oracle/" not in src, os.path.join(dp, f)
+
+
+def test_no_kernel_spills_to_scratch():
+    """Register spills of the BUILT library's kernels, read from its code objects (tools/kernel_resources.py).  No kernel
+    may spill vector registers or use scratch memory (a scratch reload is an s_waitcnt vmcnt(0) in the middle of a
+    kernel's memory pipeline: the fused-upsample Winograd kernel lost 7 % to nine of them), and the kernels of the
+    hot path (3x3 convs, ConvNeXt block, pre-stages) must not spill scalar registers either."""
+    import sys
+    sys.path.insert(0, os.path.join(REPO, "tools"))
+    import kernel_resources
+    from rvdd_release_amd import _lib
+    rows = kernel_resources.kernel_table(_lib.LIB_PATH)
+    names = {r["name"] for r in rows}
+    assert len(rows) >= 50 and any(n.startswith("wino3x3_ups_kernel") for n in names), sorted(names)
+    bad = [(r["name"], r.get("vgpr_spill_count", 0), r.get("private_segment_fixed_size", 0)) for r in rows
+           if r.get("vgpr_spill_count", 0) or r.get("private_segment_fixed_size", 0)]
+    assert not bad, bad
+    hot = ("wino3x3", "conv3x3", "mlp_kernel", "dwln_kernel", "convblock_kernel", "proj1x1", "warp48", "netin", "ha_")
+    bad = [(r["name"], r["sgpr_spill_count"]) for r in rows if r["name"].startswith(hot) and r.get("sgpr_spill_count", 0)]
+    assert not bad, bad
