@@ -586,7 +586,7 @@ static_assert(F_LDS_BYTES <= 160 * 1024 && (F_OFF_T % 4) == 0 && 4 * 3072 <= 2 *
 constexpr int F_MLP_VMEM = 4 * 6;
 
 template <bool OUT3>
-__global__ __launch_bounds__(256, 1) void convblock_kernel(const float* __restrict__ x, NextBlockW wt, float* __restrict__ out,
+__global__ __launch_bounds__(256, 2) void convblock_kernel(const float* __restrict__ x, NextBlockW wt, float* __restrict__ out,
                                                           int B, int H, int W, int tiles_x, int tiles_y, int ntiles, Out3 o3) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* W1 = smem;
@@ -665,6 +665,7 @@ __global__ __launch_bounds__(256, 1) void convblock_kernel(const float* __restri
         if (tid < E_PAR_FLOATS) Pl[tid] = tid < kF ? wt.dw_b[tid] : (tid < 2 * kF ? wt.ln_w[tid - kF] : wt.ln_b[tid - 2 * kF]);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                         // the bias is read before the first barrier of the tile loop
 
     const int t0 = (2 * row + quad) & 3;
     int rd0[4][4];
@@ -673,19 +674,12 @@ __global__ __launch_bounds__(256, 1) void convblock_kernel(const float* __restri
 #pragma unroll
         for (int d = 0; d < 4; ++d) rd0[c][d] = (row * 6 + quad) * 64 + ((d ^ ((t0 + c) & 3)) * 4 + g) * 4;
 
-    // ---- MLP phase: lane -> (pixel lr of a 16-pixel group = one tile row, channel group kk), see mlp_kernel
-    const int lr = lane & 15, kk = lane >> 4;
-    lds_frag* w1p = (lds_frag*)W1 + lane;
-    lds_frag* w2p = (lds_frag*)W2 + lane;
-    lds_frag* bvp = (lds_frag*)BV + kk;
-    asm volatile("" : "+v"(w1p), "+v"(w2p), "+v"(bvp));
-    auto F1 = [&](int j, int m) { return w1p[(j * 12 + m) * 64]; };
-    auto F2 = [&](int m, int mo) { return w2p[(m * 3 + mo) * 64]; };
-    const unsigned lane_off = (unsigned)(lr * (kF * 4) + kk * 16);
-    // the exchange: this wave's [row 4][chunk 3][pixel 16][16 floats]
-    float* Xw = Tl + wave * 3072;
-    const int x_wr = rw * 768 + (4 * quad) * 16 + ((quad ^ (g == 0 ? 0 : g == 1 ? 3 : g == 2 ? 1 : 2)) * 4);     // + j * 256 + i * 16
-    const int x_rd = lr * 16 + (((lr >> 2) ^ (kk == 0 ? 0 : kk == 1 ? 3 : kk == 2 ? 1 : 2)) * 4);               // + n * 768 + j * 256
+    // ---- MLP phase: lane -> (pixel lr of a 16-pixel group = one tile row, channel group kk), see mlp_kernel.  Its lane
+    // constants (fragment pointers, row offsets, exchange addresses) are derived INSIDE the tile loop from an opaque copy
+    // of the lane index: as loop invariants they would stay alive through the depth-wise phase, which has no register to
+    // spare (the kernel is capped at 256 registers so that the MFMA results stay in VGPRs, where the GELU reads them).
+    float* Xw = Tl + wave * 3072;           // the exchange: this wave's [row 4][chunk 3][pixel 16][16 floats]
+    auto sigma = [](int q) { return q == 0 ? 0 : q == 1 ? 3 : q == 2 ? 1 : 2; };
 
 #pragma unroll 1
     for (;;) {
@@ -734,6 +728,10 @@ __global__ __launch_bounds__(256, 1) void convblock_kernel(const float* __restri
             lb[j] = *reinterpret_cast<const f32x4*>(Pl + 2 * kF + 16 * j + 4 * g);
         }
         __syncthreads();                      // every wave is done with both chunk buffers: they become the exchange
+        int lane_o = lane;
+        asm volatile("" : "+v"(lane_o));
+        const int x_wr = (((lane_o >> 5) << 1) + (__builtin_popcount((lane_o >> 2) & 7) & 1)) * 768 + (4 * ((lane_o >> 2) & 3)) * 16 +
+                         ((((lane_o >> 2) & 3) ^ sigma(lane_o & 3)) * 4);                       // + j * 256 + i * 16
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             float sm = 0.f;
@@ -762,6 +760,15 @@ __global__ __launch_bounds__(256, 1) void convblock_kernel(const float* __restri
             }
         }
         // the wave reads back what it wrote itself (LDS operations of a wave complete in order): pixel-per-lane rows
+        const int lr = lane_o & 15, kk = lane_o >> 4;
+        const int x_rd = lr * 16 + (((lr >> 2) ^ sigma(kk)) * 4);                                   // + n * 768 + j * 256
+        lds_frag* w1p = (lds_frag*)W1 + lane_o;
+        lds_frag* w2p = (lds_frag*)W2 + lane_o;
+        lds_frag* bvp = (lds_frag*)BV + kk;
+        asm volatile("" : "+v"(w1p), "+v"(w2p), "+v"(bvp));
+        auto F1 = [&](int j, int m) { return w1p[(j * 12 + m) * 64]; };
+        auto F2 = [&](int m, int mo) { return w2p[(m * 3 + mo) * 64]; };
+        const unsigned lane_off = (unsigned)(lr * (kF * 4) + kk * 16);
         f32x4 xc[4][3];
 #pragma unroll
         for (int n = 0; n < 4; ++n)

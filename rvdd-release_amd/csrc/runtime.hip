@@ -126,6 +126,7 @@ struct rvdd_handle {
     bool use_wino = true;         // 48->48 3x3 convs: Winograd F(2x2,3x3) (RVDD_CONV=direct selects the direct kernel)
     int seq_major = 0;            // 1 = full-resolution stages one sequence at a time (see seq_major_on)
     bool fuse_upsample = true;    // UpConv's bilinear x2 inside the Winograd patch load (RVDD_FUSE_UPSAMPLE=0: separate kernel)
+    bool next_fused = true;       // ConvNeXt ConvBlock as ONE kernel (RVDD_NEXT_FUSED=0 / option "next_fused" 0: dwln + mlp kernels)
     bool serpentine = false;      // sequence order of the current frame-step (flips every step when seq_major is on)
     std::map<std::string, HostTensor> staged;
     std::vector<void*> allocs;
@@ -701,6 +702,7 @@ int rvdd_create(const rvdd_cfg* cfg, rvdd_t** out) {
     h->cfg = *cfg;
     if (const char* sm = std::getenv("RVDD_SEQ_MAJOR")) h->seq_major = std::atoi(sm) != 0;     // measurement switches
     if (const char* fu = std::getenv("RVDD_FUSE_UPSAMPLE")) h->fuse_upsample = std::atoi(fu) != 0;
+    if (const char* nf = std::getenv("RVDD_NEXT_FUSED")) h->next_fused = std::atoi(nf) != 0;
     if (const char* cv = std::getenv("RVDD_CONV")) {     // direct | winograd (forced at every size) | anything else = auto
         h->use_wino = std::strcmp(cv, "direct") != 0;
         h->force_wino = std::strcmp(cv, "winograd") == 0;
@@ -920,6 +922,11 @@ int rvdd_set_option(rvdd_t* h, const char* name, int32_t value) {
         h->fuse_upsample = value != 0;
         return RVDD_OK;
     }
+    if (std::strcmp(name, "next_fused") == 0) {
+        // 0 = ConvNeXt ConvBlock as two kernels (depth-wise + LayerNorm, then the MLP): A/B reference of convblock_kernel
+        h->next_fused = value != 0;
+        return RVDD_OK;
+    }
     if (std::strcmp(name, "seq_major") == 0) {
         // 1 = the full-resolution stages of the convunet run one sequence at a time (measured slower: see seq_major_on)
         if (value < 0 || value > 1) return fail(h, RVDD_ERR_ARG, "rvdd_set_option: seq_major must be 0 or 1");
@@ -934,7 +941,7 @@ int rvdd_set_option(rvdd_t* h, const char* name, int32_t value) {
         h->force_wino = value == 2;
         return RVDD_OK;
     }
-    return fail(h, RVDD_ERR_ARG, "rvdd_set_option: unknown option '%s' (known: no_warp, warp_raw, prev_noisy_frame, conv_kernel, seq_major, graphs, fuse_upsample)", name);
+    return fail(h, RVDD_ERR_ARG, "rvdd_set_option: unknown option '%s' (known: no_warp, warp_raw, prev_noisy_frame, conv_kernel, seq_major, graphs, fuse_upsample, next_fused)", name);
 }
 
 int rvdd_reset(rvdd_t* h) {
