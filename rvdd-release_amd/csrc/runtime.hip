@@ -126,7 +126,10 @@ struct rvdd_handle {
     bool use_wino = true;         // 48->48 3x3 convs: Winograd F(2x2,3x3) (RVDD_CONV=direct selects the direct kernel)
     int seq_major = 0;            // 1 = full-resolution stages one sequence at a time (see seq_major_on)
     bool fuse_upsample = true;    // UpConv's bilinear x2 inside the Winograd patch load (RVDD_FUSE_UPSAMPLE=0: separate kernel)
-    bool next_fused = true;       // ConvNeXt ConvBlock as ONE kernel (RVDD_NEXT_FUSED=0 / option "next_fused" 0: dwln + mlp kernels)
+    bool next_fused = false;      // ConvNeXt ConvBlock as ONE kernel (RVDD_NEXT_FUSED=1 / option "next_fused" 1); default: dwln + mlp kernels
+    bool next_streams = false;    // ConvNeXt, two-kernel blocks, B >= 2: the two halves of the batch as two chains on two streams (measured: no gain)
+    hipStream_t stream2 = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool serpentine = false;      // sequence order of the current frame-step (flips every step when seq_major is on)
     std::map<std::string, HostTensor> staged;
     std::vector<void*> allocs;
@@ -664,8 +667,22 @@ namespace {
 int run_net(rvdd_t* h, const float* netin, const float* featw, float* feat_dst, float* out_nchw,
             float* out_nhwc4, hipStream_t s, const StepInputs* prologue) {
     if (!h->is_next()) return run_convunet(h, netin, featw, feat_dst, out_nchw, out_nhwc4, s, prologue);
-    if (prologue) RC(run_prologue(h, *prologue, Sub{0, h->cfg.batch}, s));
-    return run_convnext(h, netin, featw, feat_dst, out_nchw, out_nhwc4, s);
+    const int B = h->cfg.batch;
+    if (prologue) RC(run_prologue(h, *prologue, Sub{0, B}, s));
+    if (h->next_streams && !h->next_fused && B >= 2 && h->stream2) {
+        // Two chains, one per half of the batch, on two streams.  The MLP kernel is bound by the matrix cores, the
+        // depth-wise kernel by latencies (its waves wait 58 % of their time): with one workgroup of each resident per
+        // CU the second fills the first's issue slots.  The MLP kernels of the two chains cannot share a CU (LDS), so
+        // the chains fall out of phase by themselves: A's depth-wise kernel beside B's MLP, then the reverse.
+        HIPCHK(h, hipEventRecord(h->ev_fork, s));
+        HIPCHK(h, hipStreamWaitEvent(h->stream2, h->ev_fork, 0));
+        RC(run_convnext(h, netin, featw, feat_dst, out_nchw, out_nhwc4, s, Sub{0, B / 2}, true));
+        RC(run_convnext(h, netin, featw, feat_dst, out_nchw, out_nhwc4, h->stream2, Sub{B / 2, B - B / 2}, true));
+        HIPCHK(h, hipEventRecord(h->ev_join, h->stream2));
+        HIPCHK(h, hipStreamWaitEvent(s, h->ev_join, 0));
+        return RVDD_OK;
+    }
+    return run_convnext(h, netin, featw, feat_dst, out_nchw, out_nhwc4, s, Sub{0, B}, false);
 }
 }  // namespace
 
@@ -703,6 +720,7 @@ int rvdd_create(const rvdd_cfg* cfg, rvdd_t** out) {
     if (const char* sm = std::getenv("RVDD_SEQ_MAJOR")) h->seq_major = std::atoi(sm) != 0;     // measurement switches
     if (const char* fu = std::getenv("RVDD_FUSE_UPSAMPLE")) h->fuse_upsample = std::atoi(fu) != 0;
     if (const char* nf = std::getenv("RVDD_NEXT_FUSED")) h->next_fused = std::atoi(nf) != 0;
+    if (const char* ns = std::getenv("RVDD_NEXT_STREAMS")) h->next_streams = std::atoi(ns) != 0;
     if (const char* cv = std::getenv("RVDD_CONV")) {     // direct | winograd (forced at every size) | anything else = auto
         h->use_wino = std::strcmp(cv, "direct") != 0;
         h->force_wino = std::strcmp(cv, "winograd") == 0;
@@ -741,6 +759,12 @@ int rvdd_create(const rvdd_cfg* cfg, rvdd_t** out) {
     }
     (void)hipEventCreate(&h->t0);
     (void)hipEventCreate(&h->t1);
+    if (h->is_next() && (hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking) != hipSuccess ||
+                         hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
+                         hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess)) {
+        (void)hipGetLastError();
+        h->next_streams = false;
+    }
     if (const char* gv = std::getenv("RVDD_GRAPH")) h->use_graphs = std::atoi(gv) != 0;
     if (hipStreamCreateWithFlags(&h->gstream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&h->g_in, hipEventDisableTiming) != hipSuccess ||
@@ -760,6 +784,9 @@ void rvdd_destroy(rvdd_t* h) {
     if (h->g_in) (void)hipEventDestroy(h->g_in);
     if (h->g_out) (void)hipEventDestroy(h->g_out);
     if (h->gstream) (void)hipStreamDestroy(h->gstream);
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    if (h->ev_join) (void)hipEventDestroy(h->ev_join);
+    if (h->stream2) (void)hipStreamDestroy(h->stream2);
     for (void* p : h->allocs) (void)hipFree(p);
     if (h->scratch) (void)hipFree(h->scratch);
     tvl1_free(h->tvl1);
@@ -927,6 +954,11 @@ int rvdd_set_option(rvdd_t* h, const char* name, int32_t value) {
         h->next_fused = value != 0;
         return RVDD_OK;
     }
+    if (std::strcmp(name, "next_streams") == 0) {
+        // 0 = ConvNeXt's two-kernel blocks on the caller's stream only (A/B reference of the two half-batch chains)
+        h->next_streams = value != 0 && h->stream2 != nullptr;
+        return RVDD_OK;
+    }
     if (std::strcmp(name, "seq_major") == 0) {
         // 1 = the full-resolution stages of the convunet run one sequence at a time (measured slower: see seq_major_on)
         if (value < 0 || value > 1) return fail(h, RVDD_ERR_ARG, "rvdd_set_option: seq_major must be 0 or 1");
@@ -941,7 +973,7 @@ int rvdd_set_option(rvdd_t* h, const char* name, int32_t value) {
         h->force_wino = value == 2;
         return RVDD_OK;
     }
-    return fail(h, RVDD_ERR_ARG, "rvdd_set_option: unknown option '%s' (known: no_warp, warp_raw, prev_noisy_frame, conv_kernel, seq_major, graphs, fuse_upsample, next_fused)", name);
+    return fail(h, RVDD_ERR_ARG, "rvdd_set_option: unknown option '%s' (known: no_warp, warp_raw, prev_noisy_frame, conv_kernel, seq_major, graphs, fuse_upsample, next_fused, next_streams)", name);
 }
 
 int rvdd_reset(rvdd_t* h) {
