@@ -582,10 +582,10 @@ static_assert(F_LDS_BYTES <= 160 * 1024 && (F_OFF_T % 4) == 0 && 4 * 3072 <= 2 *
 // first two chunks: per 16-pixel group 3 residual loads + 3 stores through buffer descriptors (issued whether the row
 // exists or not: a missing row has zero records).  vmcnt retires in issue order, so "all but the newest 24" covers the
 // DMA; the conditional stores of the OUT3 epilogue are not counted -- a lower bound only makes the wait conservative.
-constexpr int F_MLP_VMEM = 4 * 6;
+constexpr int F_MLP_VMEM = 2 * 6;
 
 template <bool OUT3>
-__global__ __launch_bounds__(256, 2) void convblock_kernel(const float* __restrict__ x, NextBlockW wt, float* __restrict__ out,
+__global__ __launch_bounds__(512, 2) void convblock_kernel(const float* __restrict__ x, NextBlockW wt, float* __restrict__ out,
                                                           int B, int H, int W, int tiles_x, int tiles_y, int ntiles, Out3 o3) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* W1 = smem;
@@ -621,11 +621,11 @@ __global__ __launch_bounds__(256, 2) void convblock_kernel(const float* __restri
     const int idx = lane >> 2;
     const int quad = idx & 3;
     const int rw = ((idx >> 3) << 1) + (__builtin_popcount(idx & 7) & 1);      // row inside the wave's four
-    const int row = wave * 4 + rw;
-    int piece_yx[9];
+    const int row = (wave & 3) * 4 + rw;      // waves 0-3 run the depth-wise phase; 4-7 wait at its barriers
+    int piece_yx[5];           // the 33 LDS-DMA pieces of a chunk are issued by all eight waves
 #pragma unroll
-    for (int n = 0; n < 9; ++n) {
-        const int k = wave + 4 * n;
+    for (int n = 0; n < 5; ++n) {
+        const int k = wave + 8 * n;
         const int R = k * 4 + (lane >> 4), sl = lane & 15;
         const int p = 4 * R + ((sl >> 2) ^ (R & 3));
         const int iy = p / E_PITCH, ix = p - iy * E_PITCH;
@@ -636,8 +636,8 @@ __global__ __launch_bounds__(256, 2) void convblock_kernel(const float* __restri
             __builtin_amdgcn_make_buffer_rsrc((void*)(x + (size_t)tp.b * H * W * kF), 0, H * W * kF * 4, 0x00020000);
         float* dst = Tl + buf * E_BUF_FLOATS;
 #pragma unroll
-        for (int n = 0; n < 9; ++n) {
-            const int k = wave + 4 * n;
+        for (int n = 0; n < 5; ++n) {
+            const int k = wave + 8 * n;
             if (k < E_PIECES) {
                 const int gy = tp.y0 - 3 + (piece_yx[n] >> 8), gx = tp.x0 - 3 + (piece_yx[n] & 255);
                 const bool ok = piece_yx[n] >= 0 && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
@@ -651,15 +651,15 @@ __global__ __launch_bounds__(256, 2) void convblock_kernel(const float* __restri
     {   // weights of the block -> LDS, once per workgroup
         __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc((void*)wt.fc1_w, 0, M_W_FLOATS * 4, 0x00020000);
         __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc((void*)wt.fc2_w, 0, M_W_FLOATS * 4, 0x00020000);
-        for (int k = wave; k < M_W_FLOATS / 256; k += 4) {
+        for (int k = wave; k < M_W_FLOATS / 256; k += 8) {
             dma16(r1, W1 + k * 256, (unsigned)(k * 1024 + lane * 16));
             dma16(r2, W2 + k * 256, (unsigned)(k * 1024 + lane * 16));
         }
-        for (int i = tid; i < M2_BV_FLOATS; i += 256) BV[i] = i < 192 ? wt.fc1_b[i] : (i < 240 ? wt.fc2_b[i - 192] : wt.ls[i - 240]);
+        for (int i = tid; i < M2_BV_FLOATS; i += 512) BV[i] = i < 192 ? wt.fc1_b[i] : (i < 240 ? wt.fc2_b[i - 192] : wt.ls[i - 240]);
         if constexpr (OUT3) {
             if (tid < 147) BV[M2_BV_FLOATS + tid] = tid < 144 ? o3.w[tid] : o3.b[tid - 144];
         }
-        for (int q = tid; q < D_W_FLOATS / 4; q += 256)
+        for (int q = tid; q < D_W_FLOATS / 4; q += 512)
             reinterpret_cast<f32x4*>(Wl)[q] = reinterpret_cast<const f32x4*>(wt.dw_w)[q];
         if (tid < E_PAR_FLOATS) Pl[tid] = tid < kF ? wt.dw_b[tid] : (tid < 2 * kF ? wt.ln_w[tid - kF] : wt.ln_b[tid - 2 * kF]);
     }
@@ -677,7 +677,7 @@ __global__ __launch_bounds__(256, 2) void convblock_kernel(const float* __restri
     // constants (fragment pointers, row offsets, exchange addresses) are derived INSIDE the tile loop from an opaque copy
     // of the lane index: as loop invariants they would stay alive through the depth-wise phase, which has no register to
     // spare (the kernel is capped at 256 registers so that the MFMA results stay in VGPRs, where the GELU reads them).
-    float* Xw = Tl + wave * 3072;           // the exchange: this wave's [row 4][chunk 3][pixel 16][16 floats]
+    float* Xw = Tl;                         // the exchange: [tile row 16][chunk 3][pixel 16][16 floats]
     auto sigma = [](int q) { return q == 0 ? 0 : q == 1 ? 3 : q == 2 ? 1 : 2; };
 
 #pragma unroll 1
@@ -698,6 +698,7 @@ __global__ __launch_bounds__(256, 2) void convblock_kernel(const float* __restri
             if (j == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             if (j == 1) dma_chunk(cur, 2, 0);
+            if (wave >= 4) continue;
             const float* tb = Tl + (j & 1) * E_BUF_FLOATS;
             const float* wb = Wl + 16 * j + 4 * g;
             f32x4 win[2][10], wv[2][7];
@@ -729,10 +730,10 @@ __global__ __launch_bounds__(256, 2) void convblock_kernel(const float* __restri
         __syncthreads();                      // every wave is done with both chunk buffers: they become the exchange
         int lane_o = lane;
         asm volatile("" : "+v"(lane_o));
-        const int x_wr = (((lane_o >> 5) << 1) + (__builtin_popcount((lane_o >> 2) & 7) & 1)) * 768 + (4 * ((lane_o >> 2) & 3)) * 16 +
-                         ((((lane_o >> 2) & 3) ^ sigma(lane_o & 3)) * 4);                       // + j * 256 + i * 16
+        const int x_wr = ((wave & 3) * 4 + ((lane_o >> 5) << 1) + (__builtin_popcount((lane_o >> 2) & 7) & 1)) * 768 +
+                         (4 * ((lane_o >> 2) & 3)) * 16 + ((((lane_o >> 2) & 3) ^ sigma(lane_o & 3)) * 4);   // + j * 256 + i * 16
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < 4 && wave < 4; ++i) {
             float sm = 0.f;
 #pragma unroll
             for (int j = 0; j < 3; ++j) sm += (acc[i][j][0] + acc[i][j][1]) + (acc[i][j][2] + acc[i][j][3]);
@@ -758,7 +759,8 @@ __global__ __launch_bounds__(256, 2) void convblock_kernel(const float* __restri
                 *reinterpret_cast<f32x4*>(Xw + x_wr + j * 256 + i * 16) = r;
             }
         }
-        // the wave reads back what it wrote itself (LDS operations of a wave complete in order): pixel-per-lane rows
+        __syncthreads();                      // the rows of waves 0-3 are in the exchange
+        // every wave takes two tile rows (= two groups of 16 pixels) into the MLP phase: pixel-per-lane rows
         const int lr = lane_o & 15, kk = lane_o >> 4;
         const int x_rd = lr * 16 + (((lr >> 2) ^ sigma(kk)) * 4);                                   // + n * 768 + j * 256
         lds_frag* w1p = (lds_frag*)W1 + lane_o;
@@ -768,11 +770,11 @@ __global__ __launch_bounds__(256, 2) void convblock_kernel(const float* __restri
         auto F1 = [&](int j, int m) { return w1p[(j * 12 + m) * 64]; };
         auto F2 = [&](int m, int mo) { return w2p[(m * 3 + mo) * 64]; };
         const unsigned lane_off = (unsigned)(lr * (kF * 4) + kk * 16);
-        f32x4 xc[4][3];
+        f32x4 xc[2][3];
 #pragma unroll
-        for (int n = 0; n < 4; ++n)
+        for (int n = 0; n < 2; ++n)
 #pragma unroll
-            for (int j = 0; j < 3; ++j) xc[n][j] = *reinterpret_cast<const f32x4*>(Xw + x_rd + n * 768 + j * 256);
+            for (int j = 0; j < 3; ++j) xc[n][j] = *reinterpret_cast<const f32x4*>(Xw + x_rd + (2 * wave + n) * 768 + j * 256);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __syncthreads();                      // the exchange is over: the chunk buffers take the next tile's halo
         if (more) {
@@ -786,8 +788,8 @@ __global__ __launch_bounds__(256, 2) void convblock_kernel(const float* __restri
         b1n[0] = bvp[0];
         b1n[1] = bvp[4];
 #pragma unroll
-        for (int n = 0; n < 4; ++n) {
-            const int y = cur.y0 + wave * 4 + n;
+        for (int n = 0; n < 2; ++n) {
+            const int y = cur.y0 + wave * 2 + n;
             // rows of `x` / `out` under this group: a descriptor over exactly its valid pixels (loads of the others
             // return zeros, their stores are dropped); EVERY wave issues the same number of memory instructions per
             // group, valid or not, because the waits on the next tile's chunks count them (f_mlp_vmem)
@@ -994,7 +996,7 @@ static hipError_t launch_block(const float* x, float* out, const NextBlockW& w, 
     if (ntiles <= 0) return hipSuccess;
     // persistent: one workgroup per CU (LDS), never more workgroups than tiles; the XCD band map needs a multiple of 8
     const int grid = ((std::min(ntiles, num_cus()) + 7) / 8) * 8;
-    hipLaunchKernelGGL(convblock_kernel<OUT3>, dim3(grid), dim3(256), F_LDS_BYTES, s, x, w, out, B, H, W, tx, ty, ntiles, o3);
+    hipLaunchKernelGGL(convblock_kernel<OUT3>, dim3(grid), dim3(512), F_LDS_BYTES, s, x, w, out, B, H, W, tx, ty, ntiles, o3);
     return hipGetLastError();
 }
 
