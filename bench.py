@@ -53,7 +53,7 @@ DESCR = {
 }
 FP32_PEAK_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md, chip table (vector = matrix f32)
 _CONV = "conv3x3_kernel<48, 1, false>" if os.environ.get("RVDD_CONV") == "direct" else "wino3x3_kernel<1, false>"
-_NEXT = "convblock_kernel" if os.environ.get("RVDD_NEXT_FUSED") == "1" else "mlp_kernel"
+_NEXT = "mlp_kernel" if os.environ.get("RVDD_NEXT_FUSED") == "0" else "convblock_kernel"
 DOMINANT = {"convunet": _CONV, "convunet+feat": _CONV, "next": _NEXT, "next+feat": _NEXT}
 # The launches of a kernel class inside one frame-step repeat with period 11 (plain 48->48 3x3 conv; 14 when the
 # upsample is not fused) or 25 (ConvNeXt ConvBlock) over the four resolution levels; bracketing every 3rd launch (3 is

@@ -680,6 +680,13 @@ __global__ __launch_bounds__(512, 2) void convblock_kernel(const float* __restri
     float* Xw = Tl;                         // the exchange: [tile row 16][chunk 3][pixel 16][16 floats]
     auto sigma = [](int q) { return q == 0 ? 0 : q == 1 ? 3 : q == 2 ? 1 : 2; };
 
+#ifdef RVDD_STAMPS
+    unsigned long long st_dw = 0, st_ln = 0, st_mlp = 0, st_wait = 0, st_n = 0, st_t = 0;
+#define STAMP(acc_) do { const unsigned long long now__ = __builtin_amdgcn_s_memtime(); acc_ += now__ - st_t; st_t = now__; } while (0)
+    st_t = __builtin_amdgcn_s_memtime();
+#else
+#define STAMP(acc_) do { } while (0)
+#endif
 #pragma unroll 1
     for (;;) {
         const int next_tile = tile + stride;
@@ -720,6 +727,7 @@ __global__ __launch_bounds__(512, 2) void convblock_kernel(const float* __restri
                 asm volatile("" : "+v"(acc[0][j]), "+v"(acc[1][j]), "+v"(acc[2][j]), "+v"(acc[3][j])::"memory");
             }
         }
+        STAMP(st_dw);
         // =========================================================== LayerNorm over the 48 channels of each pixel
         f32x4 lw[3], lb[3];
 #pragma unroll
@@ -781,6 +789,7 @@ __global__ __launch_bounds__(512, 2) void convblock_kernel(const float* __restri
             dma_chunk(nxt, 0, 0);
             dma_chunk(nxt, 1, 1);
         }
+        STAMP(st_ln);
         // =========================================================== MLP on the wave's four rows (groups of 16 pixels)
         f32x4 wq[2][2], b1n[2];
         wq[0][0] = F1(0, 0);
@@ -893,13 +902,26 @@ __global__ __launch_bounds__(512, 2) void convblock_kernel(const float* __restri
                 }
             }
         }
+        STAMP(st_mlp);
+#ifdef RVDD_STAMPS
+        st_n += 1;
+#endif
         if (!more) break;
         // the next tile's first two chunks were requested before the vector-memory instructions of this phase: all but
         // those may still be in flight
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(F_MLP_VMEM) : "memory");
+        STAMP(st_wait);
         tile = next_tile;
         cur = nxt;
     }
+#ifdef RVDD_STAMPS
+    // diagnostic build only: cycles of wave 0 of workgroup 0 per phase, summed over its tiles, over the first pixel of `out`
+    if (blockIdx.x == 0 && tid == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        float* o = out;
+        o[0] = (float)st_n; o[1] = (float)st_dw; o[2] = (float)st_ln; o[3] = (float)st_mlp; o[4] = (float)st_wait;
+    }
+#endif
 }
 
 // zero_pad_features (networks/new_unet.py:56-66): src [B][h][w] -> dst [B][H][W] at (oy,ox), zeros elsewhere

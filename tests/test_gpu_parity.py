@@ -805,7 +805,8 @@ def test_convblock_one_kernel_equals_two_kernels(arch, stem, fut):
 
 @pytest.mark.parametrize("name", [n for n in BUILT if ARCH[n].startswith("next")])
 def test_two_kernel_convblock_golden(name, monkeypatch):
-    """The two-kernel ConvBlock (A/B reference of the fused kernel, RVDD_NEXT_FUSED=0) on the reference's fixtures."""
+    """The two-kernel ConvBlock (A/B reference of the fused kernel that runs by default, RVDD_NEXT_FUSED=0) on the
+    reference's fixtures."""
     from rvdd_release_amd.networks import define_net_arch
     monkeypatch.setenv("RVDD_NEXT_FUSED", "0")
     stem, fut, _ = VARIANTS[name]
