@@ -689,9 +689,6 @@ __global__ __launch_bounds__(512, 2) void convblock_kernel(const float* __restri
 #endif
 #pragma unroll 1
     for (;;) {
-        const int next_tile = tile + stride;
-        const bool more = next_tile < band_end;
-        const TilePos nxt = locate(more ? next_tile : tile);
         // =========================================================== depth-wise 7x7 (+bias), three 16-channel chunks
         f32x4 acc[4][3];
 #pragma unroll
@@ -785,6 +782,11 @@ __global__ __launch_bounds__(512, 2) void convblock_kernel(const float* __restri
             for (int j = 0; j < 3; ++j) xc[n][j] = *reinterpret_cast<const f32x4*>(Xw + x_rd + (2 * wave + n) * 768 + j * 256);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __syncthreads();                      // the exchange is over: the chunk buffers take the next tile's halo
+        // (the next tile is located here, not at the top of the loop: its three scalars would live through the whole
+        // depth-wise phase, and the OUT3 instantiation has no scalar register to spare)
+        const int next_tile = tile + stride;
+        const bool more = next_tile < band_end;
+        const TilePos nxt = locate(more ? next_tile : tile);
         if (more) {
             dma_chunk(nxt, 0, 0);
             dma_chunk(nxt, 1, 1);
