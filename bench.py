@@ -81,6 +81,11 @@ def parse_args(argv=None):
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: --batch sequences per GPU; strong: --sequences in total, split over the GPUs")
     ap.add_argument("--sequences", type=int, default=64, help="total sequences with --scaling strong")
+    ap.add_argument("--online-flow", action="store_true",
+                    help="validate.py's --val_flow_from_denoised at full size (validate.py:16-38, 81-82): the flow towards the "
+                         "previous frame of every step after the first is TV-L1 (rvdd_tvl1flow_batch) from the current noisy "
+                         "frame to the re-mosaicked previous OUTPUT, inside the timed region; a mode of its own, labelled in "
+                         "the JSON line, never the headline metric")
     ap.add_argument("--collate-outputs", action="store_true",
                     help="after the timed region, all-gather the output frames of the last group (timed separately)")
     ap.add_argument("--cpu-frames", type=int, default=10, help="timed frames of the CPU-oracle sample (0 = skip)")
@@ -253,11 +258,21 @@ def main():
         del seqs
     outs = torch.empty(n_out, B, 3, H, W, dtype=torch.float32, device=dev)   # outputs of the group being advanced
 
+    def flow_from_denoised(den, raw_cur):
+        """validate.py:16-38 for B sequences: moving = channel mean of remosaick(previous output), target = channel mean of
+        the current packed raw frame, both mapped to [0,1] (library.py:67-68, :165-167) -> TV-L1 on the device."""
+        moving = ((den[:, 1, 0::2, 0::2] + den[:, 2, 0::2, 1::2]) + (den[:, 0, 1::2, 0::2] + den[:, 1, 1::2, 1::2])) * 0.125 + 0.5
+        target = raw_cur.mean(dim=1) * 0.5 + 0.5
+        return rt.tvl1flow_batch(target.contiguous(), moving.contiguous())
+
     def one_step():
         for raw, fprev, fnext in inputs:
             rt.reset()                                        # FirstOfVideo
             for t in range(1, T - fut):
-                rt.step(raw[t - 1] if t == 1 else None, raw[t], raw[t + 1] if fut else None, fprev[t],
+                fp = fprev[t]
+                if args.online_flow and t > 1:
+                    fp = flow_from_denoised(outs[t - 2], raw[t])
+                rt.step(raw[t - 1] if t == 1 else None, raw[t], raw[t + 1] if fut else None, fp,
                         fnext[t] if fut else None, out=outs[t - 1])
 
     def barrier():
@@ -416,6 +431,8 @@ def main():
     par = (f"{total_seqs} sequences sharded over {world} GPU(s), {len(groups)} group(s) of {B} in lockstep per GPU"
            if args.scaling == "strong" else f"sequences sharded over {world} GPU(s), {B} per GPU in lockstep")
     data = "synthetic"
+    if args.online_flow:
+        data += " (ONLINE FLOW: TV-L1 from the previous output inside the timed region, validate.py --val_flow_from_denoised; not the headline metric)"
     if rehearsal:
         data += " (REHEARSAL: all ranks on one GPU, not a measurement)"
     if stub:

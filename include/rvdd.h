@@ -190,6 +190,10 @@ int rvdd_srgb_metrics(rvdd_t* h, const uint8_t* a, const uint8_t* b, int32_t n, 
  *   "fuse_upsample": 0 = UpConv's bilinear x2 upsample runs as its own kernel instead of inside the Winograd patch
  *              load of the conv behind it (default 1; same bits either way).
  *   "graphs":   1 = frame-steps are captured into hipGraphs and replayed (measured slower on ROCm 7.2; off).
+ *   "next_fused": 0 = ConvNeXtUnet's ConvBlock (networks/new_unet.py:74-103) as two kernels (depth-wise + LayerNorm,
+ *               then the MLP) instead of the one fused kernel: the A/B reference; same results to a few ulp.
+ *   "next_streams": 1 = with next_fused = 0 and a batch of at least two sequences, the two halves of the batch run as
+ *               two chains on two streams (measured: no gain; off).
  * Unknown names are an error. */
 int rvdd_set_option(rvdd_t* h, const char* name, int32_t value);
 
