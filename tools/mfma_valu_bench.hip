@@ -6,7 +6,9 @@
 // instructions (v_add_f32 or v_pk_add_f32, independent registers).  One workgroup per CU (96 KiB of LDS claimed),
 // 256 threads = one wave per SIMD or 512 threads = two.  Reported: shader cycles (s_memtime) per iteration of one
 // wave, median over workgroups, and the same divided by the waves per SIMD = cycles the SIMD spends per
-// (NM MFMA + NV VALU) of work.  "split": waves 0-3 issue only the MFMAs, waves 4-7 only the vector instructions.
+// (NM MFMA + NV VALU) of work.  "split": waves 0-3 issue only the MFMAs, waves 4-7 only the vector instructions;
+// "split + prio": the same with s_setprio 3 on the vector waves (round 3: would a producer wave's vector bursts get
+// through beside a consumer wave's MFMAs at their own cost?).
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -18,7 +20,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int ITER = 2000;
 
-template <int NM, int NV, bool PK, int MODE>   // MODE 0: every wave does both; 1: split roles (needs 512 threads)
+template <int NM, int NV, bool PK, int MODE>   // MODE 0: every wave does both; 1: split roles (needs 512 threads); 2: split + s_setprio 3 on the vector waves
 __global__ __launch_bounds__(512) void bench(float* sink, long long* cycles) {
     extern __shared__ float lds[];
     const int wave = threadIdx.x >> 6;
@@ -32,6 +34,7 @@ __global__ __launch_bounds__(512) void bench(float* sink, long long* cycles) {
     const f32x2 inc = {1e-3f, 2e-3f};
     const bool do_m = MODE == 0 || wave < 4;
     const bool do_v = MODE == 0 || wave >= 4;
+    if (MODE == 2 && wave >= 4) __builtin_amdgcn_s_setprio(3);
     __syncthreads();
     const long long t0 = __builtin_amdgcn_s_memtime();
 #pragma unroll 1
@@ -85,7 +88,7 @@ void run(int threads, const char* label, float* sink, long long* dcyc) {
     std::sort(per.begin(), per.end());
     const double med = per[per.size() / 2];
     const int wps = threads / 256;
-    const double per_work = MODE == 1 ? med : med / wps;     // split: one iteration of the pair = one unit of work
+    const double per_work = MODE >= 1 ? med : med / wps;     // split: one iteration of the pair = one unit of work
     printf("%-34s NM=%2d NV=%2d %s thr=%3d  cyc/iter/wave %7.1f  SIMD cyc per (NM mfma + NV valu) %7.1f  [mfma alone %d]  wall %.3f ms\n",
            label, NM, NV, PK ? "pk " : "f32", threads, med, per_work, NM * 32, ms);
     hipEventDestroy(e0);
@@ -100,12 +103,14 @@ int main() {
 #define ROW(NV)                                                      \
     run<12, NV, false, 0>(256, "both, 1 wave/SIMD", sink, dcyc);     \
     run<12, NV, false, 0>(512, "both, 2 waves/SIMD", sink, dcyc);    \
-    run<12, NV, false, 1>(512, "split roles, 2 waves/SIMD", sink, dcyc);
+    run<12, NV, false, 1>(512, "split roles, 2 waves/SIMD", sink, dcyc);  \
+    run<12, NV, false, 2>(512, "split roles + prio", sink, dcyc);
     ROW(0) ROW(4) ROW(8) ROW(16) ROW(32) ROW(64)
 #define ROWP(NV)                                                    \
     run<12, NV, true, 0>(256, "both, 1 wave/SIMD", sink, dcyc);      \
     run<12, NV, true, 0>(512, "both, 2 waves/SIMD", sink, dcyc);     \
-    run<12, NV, true, 1>(512, "split roles, 2 waves/SIMD", sink, dcyc);
+    run<12, NV, true, 1>(512, "split roles, 2 waves/SIMD", sink, dcyc);   \
+    run<12, NV, true, 2>(512, "split roles + prio", sink, dcyc);
     ROWP(4) ROWP(8) ROWP(16) ROWP(32)
     // VALU alone
     run<0, 64, false, 0>(256, "valu only, 1 wave/SIMD", sink, dcyc);
