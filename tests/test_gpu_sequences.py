@@ -204,3 +204,37 @@ def test_rccl_collectives_run_at_world_size_one():
     col = line["collate"]
     assert col["gathered_shape"] == [1, 3, 8, 3, 720, 1280] and col["bytes_per_rank"] == 3 * 8 * 3 * 720 * 1280 * 4
     assert line["value"] > 0 and 20.0 < line["task_psnr_db"] < 60.0
+
+
+def test_c4_batch_of_four_720p():
+    """BASELINE config C4 at the batch bench.py times (B = 4, 1280x720, ConvNeXtUnet+feat+future through the fused
+    ConvBlock kernel): position in the batch never matters (the same sequence in slots 0 and 2, 1 and 3: equal bits),
+    a sequence of the batch equals the same sequence alone bit for bit (a tile's arithmetic does not depend on how many
+    tiles the launch has), and slot 0 matches the full-size oracle on the first frame."""
+    from rvdd_release_amd import synth
+    from rvdd_release_amd.runtime import RvddRuntime
+    stem = "recurrent-ConvNeXtUnet+feat-future-iso3200"
+    sd = load_weights(stem)
+    H, W, T = 720, 1280, 4
+    seqs = [synth.make_sequence(T, H, W, iso=3200, seed=3100 + b, device="cuda") for b in range(2)]
+
+    def run(which):
+        rt = RvddRuntime("next+feat", 1, len(which), H, W, 0)
+        rt.load_state_dict(sd)
+        st = lambda f: torch.stack([f(seqs[b]) for b in which], 0)
+        outs = [rt.step(st(lambda s: s.raw[t - 1]) if t == 1 else None, st(lambda s: s.raw[t]), st(lambda s: s.raw[t + 1]),
+                        st(lambda s: s.flow_prev[t]), st(lambda s: s.flow_next[t])).clone() for t in (1, 2)]
+        rt.close()
+        return outs
+
+    four = run([0, 1, 0, 1])
+    alone = run([1])
+    for t in range(2):
+        assert torch.equal(four[t][0], four[t][2]) and torch.equal(four[t][1], four[t][3])
+        assert torch.equal(four[t][1], alone[t][0])
+    torch.set_num_threads(min(16, len(os.sched_getaffinity(0))))
+    c = lambda x: x[None].cpu()
+    s0 = seqs[0]
+    want = O.RecurrentOracle(sd, future=1).step(c(s0.raw[0]), c(s0.raw[1]), c(s0.raw[2]), c(s0.flow_prev[1]), c(s0.flow_next[1]), first=True)[0]
+    got = four[0][0].cpu()
+    assert (got - want).abs().max() < 1e-4 and parity_psnr(got, want) > 120.0, float((got - want).abs().max())
