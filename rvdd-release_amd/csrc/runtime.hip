@@ -28,6 +28,7 @@ struct Conv3 {            // one 3x3 conv layer, split per 48-channel source
     int cin_pad[2] = {0, 0};
     float* w[2] = {nullptr, nullptr};
     float* wu[2] = {nullptr, nullptr};   // Winograd F(2x2,3x3) transformed bank (48-channel sources only)
+    float* w4[2] = {nullptr, nullptr};   // Winograd F(4x4,3x3) transformed banks, three cout thirds (48-channel sources only)
     float* bias = nullptr;
 };
 
@@ -124,6 +125,7 @@ struct rvdd_handle {
     bool prev_noisy = false;      // --prev_noisy_frame (rvdd_set_option): the next step's "previous frame" is the demosaiced noisy one
     bool no_warp = false;         // --no_warp (rvdd_set_option): previous output / features / next frame enter the net unwarped
     bool use_wino = true;         // 48->48 3x3 convs: Winograd F(2x2,3x3) (RVDD_CONV=direct selects the direct kernel)
+    int wino4 = 0;                // 1 = F(4x4,3x3) (wino4x4.hip) for the plain / two-pass 48->48 layers of the large levels (RVDD_WINO4)
     int seq_major = 0;            // 1 = full-resolution stages one sequence at a time (see seq_major_on)
     bool fuse_upsample = true;    // UpConv's bilinear x2 inside the Winograd patch load (RVDD_FUSE_UPSAMPLE=0: separate kernel)
     bool next_fused = true;       // ConvNeXt ConvBlock as ONE kernel (RVDD_NEXT_FUSED=0 / option "next_fused" 0: dwln + mlp kernels, the A/B reference)
@@ -278,6 +280,29 @@ std::vector<float> arrange_wino3x3(const HostTensor& t, int c0, int nj = 3) {
             const int j = c / 16, g = (c % 16) / 4, ii = c % 4, m = co / 16, lr = co % 16;
             for (int pos = 0; pos < 16; ++pos)
                 out[(((size_t)(pos * nj + j) * 3 + m) * 64 + g * 16 + lr) * 4 + ii] = (float)u[pos / 4][pos % 4];
+        }
+    return out;
+}
+
+// OIHW [48][cin_total][3][3], channels [c0, c0+48) -> U = G g G^T of F(4x4,3x3) per (cout, cin) (G 6x3, computed in double),
+// stored [third 3][pos 36][j 3][lane = 16g + (cout & 15)][i 4] with cout = 16 third + (cout & 15), channel = c0 + 16j+4g+i:
+// the A-fragment order of wino4x4.hip, one 108-KiB bank per cout third.
+std::vector<float> arrange_wino4x4(const HostTensor& t, int c0) {
+    const int cin_total = (int)t.shape[1];
+    static const double G[6][3] = {{1.0 / 4, 0, 0},        {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
+                                   {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6},  {0, 0, 1}};
+    std::vector<float> out((size_t)3 * 36 * 3 * 256, 0.f);
+    for (int co = 0; co < 48; ++co)
+        for (int c = 0; c < 48; ++c) {
+            const float* gk = &t.data[((size_t)co * cin_total + c0 + c) * 9];
+            double tmp[6][3], u[6][6];
+            for (int i = 0; i < 6; ++i)
+                for (int k = 0; k < 3; ++k) tmp[i][k] = G[i][0] * gk[k] + G[i][1] * gk[3 + k] + G[i][2] * gk[6 + k];
+            for (int i = 0; i < 6; ++i)
+                for (int k = 0; k < 6; ++k) u[i][k] = tmp[i][0] * G[k][0] + tmp[i][1] * G[k][1] + tmp[i][2] * G[k][2];
+            const int j = c / 16, g = (c % 16) / 4, ii = c % 4, third = co / 16, lr = co % 16;
+            for (int pos = 0; pos < 36; ++pos)
+                out[((((size_t)third * 36 + pos) * 3 + j) * 64 + g * 16 + lr) * 4 + ii] = (float)u[pos / 6][pos % 6];
         }
     return out;
 }
@@ -507,6 +532,15 @@ int run_conv(rvdd_t* h, const Conv3& L, const ConvCall& c, hipStream_t s, Sub su
     if (c.ups && !(cin == 48 && L.wu[c.src] && wino_applies(h, c.H, c.W)))
         return fail(h, RVDD_ERR_STATE, "run_conv: the fused upsample exists in the Winograd kernel only");
     if (c.ups) bytes -= px * 4.0 * 36.0;          // reads the quarter-size map
+    // F(4x4,3x3): plain and two-pass 48 -> 48 layers with enough 64x16-pixel units for every one of the 80 unit sequences
+    if (h->wino4 && h->use_wino && cin == 48 && !c.ups && L.w4[c.src] && (c.epi == EPI_NONE || c.epi == EPI_RELU) &&
+        (h->wino4 == 2 || (long)a.B * ((c.W + 63) / 64) * ((c.H + 15) / 16) >= 400)) {
+        a.w = L.w4[c.src];
+        Scope sc(h, s, c.acc_in ? (c.epi == EPI_RELU ? "wino4_kernel<1, true>" : "wino4_kernel<0, true>")
+                                : (c.epi == EPI_RELU ? "wino4_kernel<1, false>" : "wino4_kernel<0, false>"), flops, bytes);
+        HIPCHK(h, launch_wino4x4(a, c.epi, s));
+        return RVDD_OK;
+    }
     if ((cin == 48 || c16_ok) && L.wu[c.src] && wino_applies(h, c.H, c.W)) {
         a.w = L.wu[c.src];
         Scope sc(h, s, c.ups ? "wino3x3_ups_kernel<1>" : cin == 48 ? wino_name(c.epi, c.acc_in != nullptr)
@@ -720,6 +754,7 @@ int rvdd_create(const rvdd_cfg* cfg, rvdd_t** out) {
     if (const char* sm = std::getenv("RVDD_SEQ_MAJOR")) h->seq_major = std::atoi(sm) != 0;     // measurement switches
     if (const char* fu = std::getenv("RVDD_FUSE_UPSAMPLE")) h->fuse_upsample = std::atoi(fu) != 0;
     if (const char* nf = std::getenv("RVDD_NEXT_FUSED")) h->next_fused = std::atoi(nf) != 0;
+    if (const char* w4 = std::getenv("RVDD_WINO4")) h->wino4 = std::atoi(w4);
     if (const char* ns = std::getenv("RVDD_NEXT_STREAMS")) h->next_streams = std::atoi(ns) != 0;
     if (const char* cv = std::getenv("RVDD_CONV")) {     // direct | winograd (forced at every size) | anything else = auto
         h->use_wino = std::strcmp(cv, "direct") != 0;
@@ -842,6 +877,7 @@ int rvdd_finalize_weights(rvdd_t* h) {
                     L.cin_pad[sidx] = 48;
                     RC(upload(h, &L.w[sidx], arrange_conv3x3(wt, 48 * sidx, 48, 48)));
                     RC(upload(h, &L.wu[sidx], arrange_wino3x3(wt, 48 * sidx)));
+                    RC(upload(h, &L.w4[sidx], arrange_wino4x4(wt, 48 * sidx)));
                 }
             } else {
                 L.nsrc = 1;
@@ -849,6 +885,7 @@ int rvdd_finalize_weights(rvdd_t* h) {
                 L.cin_pad[0] = cin == 48 ? 48 : kNetInC;
                 RC(upload(h, &L.w[0], arrange_conv3x3(wt, 0, cin, L.cin_pad[0])));
                 RC(upload(h, &L.wu[0], cin == 48 ? arrange_wino3x3(wt, 0) : arrange_wino3x3(wt, 0, 1)));
+                if (cin == 48) RC(upload(h, &L.w4[0], arrange_wino4x4(wt, 0)));
             }
             RC(upload(h, &L.bias, h->staged.at(n + ".bias").data));
             for (int li = 0; li < CU_COUNT; ++li)
@@ -959,6 +996,12 @@ int rvdd_set_option(rvdd_t* h, const char* name, int32_t value) {
         h->next_streams = value != 0 && h->stream2 != nullptr;
         return RVDD_OK;
     }
+    if (std::strcmp(name, "wino4") == 0) {
+        // 0 = off, 1 = F(4x4,3x3) for the plain / two-pass 48 -> 48 layers where a launch has >= 400 units, 2 = at every size
+        if (value < 0 || value > 2) return fail(h, RVDD_ERR_ARG, "rvdd_set_option: wino4 must be 0, 1 or 2");
+        h->wino4 = value;
+        return RVDD_OK;
+    }
     if (std::strcmp(name, "seq_major") == 0) {
         // 1 = the full-resolution stages of the convunet run one sequence at a time (measured slower: see seq_major_on)
         if (value < 0 || value > 1) return fail(h, RVDD_ERR_ARG, "rvdd_set_option: seq_major must be 0 or 1");
@@ -973,7 +1016,7 @@ int rvdd_set_option(rvdd_t* h, const char* name, int32_t value) {
         h->force_wino = value == 2;
         return RVDD_OK;
     }
-    return fail(h, RVDD_ERR_ARG, "rvdd_set_option: unknown option '%s' (known: no_warp, warp_raw, prev_noisy_frame, conv_kernel, seq_major, graphs, fuse_upsample, next_fused, next_streams)", name);
+    return fail(h, RVDD_ERR_ARG, "rvdd_set_option: unknown option '%s' (known: no_warp, warp_raw, prev_noisy_frame, conv_kernel, seq_major, graphs, fuse_upsample, next_fused, next_streams, wino4)", name);
 }
 
 int rvdd_reset(rvdd_t* h) {

@@ -69,6 +69,10 @@ size_t conv3x3_weight_floats(int cin);
 // Winograd F(2x2,3x3) variant for 48 -> 48 layers; a.w = bank arranged by arrange_wino3x3 (runtime.hip)
 hipError_t launch_wino3x3(const ConvArgs& a, int cin, int epi, hipStream_t s);   // cin: 48, or 16 = the zero-padded network input
 size_t wino3x3_weight_floats();
+// Winograd F(4x4,3x3) for plain 48 -> 48 layers (EPI_NONE / EPI_RELU, with or without a.acc_in); a.w = the three cout-third
+// banks arranged by arrange_wino4x4 (runtime.hip)
+hipError_t launch_wino4x4(const ConvArgs& a, int epi, hipStream_t s);
+size_t wino4x4_weight_floats();
 void conv3x3_set_variant(int v);   // A/B switch used by rvdd_debug_conv_bench only
 
 // -------------------------------------------------------------- pre-stages --
