@@ -9,6 +9,16 @@
 // XCD's L2 and each repeats the input transform.  What makes this pay on gfx950: the matrix work falls by 1.78x, the
 // vector work (input transform 864 packed ops per wave and unit, output transform ~200) is tripled but starts small.
 //
+// STATUS (round 3): parity-green (max-abs 1-2e-6 against the F(2x2,3x3) path at every size tried, ragged ones included),
+// but SLOWER than wino3x3.hip on MI355X -- C2 408 against 505 frames/s -- and therefore OFF (rvdd_set_option "wino4" /
+// RVDD_WINO4).  The matrix work does fall by 1.78x; what the kernel then waits for is memory: a 36-element patch of four
+// channels per lane is 144 registers, so the next stage's patch can only be requested as the current one is consumed
+// (two loads per MFMA pair-step), the three cout thirds re-read the input (6.75 patch bytes per output pixel and third
+// against 4 for F(2x2)), and every workgroup stores only 64 of a pixel's 192 bytes.  Timing variants of this build
+// (profiles/r03_wino4_f4x4.json): no patch loads 529 frames/s, no epilogue 524, no input transform 410 (the transform is
+// already hidden in the memory stalls); all 36 loads at the start of a stage: 43 registers spilled, 361; 8-channel
+// chunks (half the patch registers, full prefetch, twice the load instructions): 310.
+//
 // Lane <-> data map (the MFMA B/D map, as wino3x3.hip): lane l of a wave owns output tile l & 15 of the wave's row of 16
 // tiles (64 x 4 pixels) and, per 16-channel chunk j, input channels 16j + 4g .. +3 (g = l >> 4); after the GEMMs it owns
 // output channels 16 t + 4g .. +3 (t = the workgroup's cout third) of that tile.  A workgroup = 4 waves = 4 tile rows = a
@@ -170,7 +180,6 @@ __global__ __launch_bounds__(256, 1) void wino4_kernel(ConvArgs a) {
     auto stage = [&](auto JC, f32x4 (&P)[36], f32x4 (&Q)[36], const UnitPos& ld_u, int ld_j) {
         constexpr int J = decltype(JC)::value;
         // B^T d B in place: rows first (the last row's loads are the youngest), then columns
-#ifndef W4_NO_XFORM
 #pragma unroll
         for (int y = 0; y < 6; ++y) {
             bt6(P[6 * y], P[6 * y + 1], P[6 * y + 2], P[6 * y + 3], P[6 * y + 4], P[6 * y + 5]);
@@ -179,13 +188,7 @@ __global__ __launch_bounds__(256, 1) void wino4_kernel(ConvArgs a) {
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int x = 0; x < 6; ++x) bt6(P[x], P[6 + x], P[12 + x], P[18 + x], P[24 + x], P[30 + x]);
-#endif
         __builtin_amdgcn_sched_barrier(0);
-#ifndef W4_ROLLING
-        // the whole patch of the next stage is requested now: it has this stage's 144 MFMAs to land
-        load_patch(Q, ld_u, ld_j);
-        __builtin_amdgcn_sched_barrier(0);
-#endif
         // 36 positions in 18 pairs: the two accumulator chains of a pair alternate (40-cycle dependent latency against a
         // 32-cycle issue interval); the A fragments of the next pair (of the next stage's first pair, at the end) are read
         // one pair ahead
@@ -198,10 +201,8 @@ __global__ __launch_bounds__(256, 1) void wino4_kernel(ConvArgs a) {
                 wq[0][0] = ldsA((J + 1) % 3, 0);
                 wq[0][1] = ldsA((J + 1) % 3, 1);
             }
-#ifdef W4_ROLLING
             load_elem(Q, ld_u, ld_j, 2 * s);
             load_elem(Q, ld_u, ld_j, 2 * s + 1);
-#endif
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < 4; ++i)
@@ -215,15 +216,6 @@ __global__ __launch_bounds__(256, 1) void wino4_kernel(ConvArgs a) {
         }
     };
     auto epilogue = [&]() {
-#ifdef W4_NO_EPI
-        if (a.B >= 0) {
-            f32x4 sacc = acc[0];
-#pragma unroll
-            for (int q = 1; q < 36; ++q) sacc = sacc + acc[q];
-            if (sacc[0] == 1234.5f) a.out[0] = sacc[1];
-            return;
-        }
-#endif
         // ---- output transform A^T M A (over the row index first), bias / partial sums, ReLU, stores
         const f32x4 bias = ACC_IN ? f32x4{0.f, 0.f, 0.f, 0.f}
                                   : bload(__builtin_amdgcn_make_buffer_rsrc((void*)a.bias, 0, kF * 4, 0x00020000),

@@ -819,3 +819,26 @@ def test_two_kernel_convblock_golden(name, monkeypatch):
             net.set_rec_features([fin.cuda()])
         out = net(g[f"x_{tag}"].cuda()).cpu()
         assert (out - g[f"out_{tag}"]).abs().max() < 1e-4, tag
+
+
+def test_wino4_f4x4_kernel_matches_default():
+    """The Winograd F(4x4,3x3) kernel (wino4x4.hip, option "wino4"; measured slower than F(2x2,3x3) on MI355X and
+    therefore off) forced at every size: two recurrent steps against the default path -- ragged tiles in x and y,
+    the two-pass 96 -> 48 layers, zero-padded decoder levels, batches.  F(4x4)'s transforms cost a few ulp more."""
+    from rvdd_release_amd import synth
+    from rvdd_release_amd.runtime import RvddRuntime
+    sd = load_weights("recurrent-convunet+feat-iso3200")
+    for B, H, W in ((1, 64, 96), (2, 72, 104), (1, 36, 52), (3, 22, 130), (2, 180, 320)):
+        seqs = [synth.make_sequence(3, H, W, iso=3200, seed=60 + b, device="cuda") for b in range(B)]
+        st = lambda f: torch.stack([f(s) for s in seqs], 0)
+        outs = []
+        for w4 in (0, 2):
+            rt = RvddRuntime("convunet+feat", 0, B, H, W, 0)
+            rt.set_option("conv_kernel", 2)
+            rt.set_option("wino4", w4)
+            rt.load_state_dict(sd)
+            outs.append([rt.step(st(lambda s: s.raw[0]), st(lambda s: s.raw[1]), None, st(lambda s: s.flow_prev[1]), None).clone(),
+                         rt.step(None, st(lambda s: s.raw[2]), None, st(lambda s: s.flow_prev[2]), None).clone()])
+            rt.close()
+        for a, b in zip(*outs):
+            assert (a - b).abs().max() < 2e-5 and parity_psnr(a.cpu(), b.cpu()) > 120.0, (B, H, W, float((a - b).abs().max()))
