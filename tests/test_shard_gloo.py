@@ -127,3 +127,23 @@ def test_bench_refuses_mismatched_world(tmp_path):
     out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2"], capture_output=True, text=True,
                          env=env, timeout=120)
     assert out.returncode != 0 and "WORLD_SIZE=3" in out.stderr
+
+
+def test_world_size_one_under_a_launcher_has_a_live_group(tmp_path):
+    """`torch.distributed.run --nproc-per-node 1` (the driver's N = 1 launch form): the process group IS initialised
+    and the collectives run (the GPU suite checks the same on RCCL); a plain `python` run has no group.  Through the
+    stub step of bench.py, which prints which is which."""
+    import json
+    for launcher in (True, False):
+        env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+        env.update(RVDD_BENCH_STUB="1", OMP_NUM_THREADS="2")
+        tail = [os.path.join(REPO, "bench.py"), "--gpus", "1", "--config", "C5", "--frames", "4", "--steps", "1", "--warmup", "0",
+                "--collate-outputs", "--cpu-frames", "0"]
+        cmd = ([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+                "--master-port", str(_free_port())] if launcher else [sys.executable]) + tail
+        out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+        d = line["distributed"]
+        assert d["process_group"] is launcher and d["backend"] == ("gloo" if launcher else None), d
+        assert line["n_ranks_seen"] == 1 and line["collate"]["gathered_shape"][0] == 1
