@@ -584,9 +584,13 @@ static_assert(F_LDS_BYTES <= 160 * 1024 && (F_OFF_T % 4) == 0 && 4 * 3072 <= 2 *
 // DMA; the conditional stores of the OUT3 epilogue are not counted -- a lower bound only makes the wait conservative.
 constexpr int F_MLP_VMEM = 2 * 6;
 
-template <bool OUT3>
+// POOL: the block also writes MaxPool2d(2) of its output (DownConv = MaxPool2d then ConvBlock, new_unet.py:200-204: the
+// block in front of a DownConv feeds the pool): a wave's two tile rows are one pooling row pair, horizontal neighbours
+// are lanes lr and lr ^ 1 -- one max between the two groups' outputs, one DPP max, even lanes store; no maxpool kernel.
+template <bool OUT3, bool POOL = false>
 __global__ __launch_bounds__(512, 2) void convblock_kernel(const float* __restrict__ x, NextBlockW wt, float* __restrict__ out,
-                                                          int B, int H, int W, int tiles_x, int tiles_y, int ntiles, Out3 o3) {
+                                                          int B, int H, int W, int tiles_x, int tiles_y, int ntiles, Out3 o3,
+                                                          float* __restrict__ pool) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* W1 = smem;
     float* W2 = smem + F_OFF_W2;
@@ -798,6 +802,7 @@ __global__ __launch_bounds__(512, 2) void convblock_kernel(const float* __restri
         wq[0][1] = F1(0, 1);
         b1n[0] = bvp[0];
         b1n[1] = bvp[4];
+        f32x4 vkeep[3];
 #pragma unroll
         for (int n = 0; n < 2; ++n) {
             const int y = cur.y0 + wave * 2 + n;
@@ -877,6 +882,26 @@ __global__ __launch_bounds__(512, 2) void convblock_kernel(const float* __restri
             for (int mo = 0; mo < 3; ++mo) {
                 const f32x4 v = xr[mo] + lv[mo] * a2[mo];
                 bstore(ro, lane_off + 64 * mo, v);
+                if constexpr (POOL) {
+                    if (n == 0) {
+                        vkeep[mo] = v;
+                    } else {
+                        // rows 2 wave and 2 wave + 1 of the tile, pixels lr and lr ^ 1: floor semantics of MaxPool2d(2)
+                        // fall out of the descriptor (pooled rows / columns that do not exist have no records)
+                        const int Hp = H >> 1, Wp = W >> 1;
+                        const int pr = (cur.y0 >> 1) + wave, pc0 = cur.x0 >> 1;
+                        const int nvalid = pr < Hp ? min(E_TW / 2, Wp - pc0) : 0;
+                        __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(
+                            (void*)(pool + (((size_t)cur.b * Hp + min(pr, Hp - 1)) * Wp + pc0) * kF), 0, max(nvalid, 0) * (kF * 4), 0x00020000);
+                        f32x4 m;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float a = fmaxf(vkeep[mo][e], v[e]);
+                            m[e] = fmaxf(a, __shfl_xor(a, 1));
+                        }
+                        bstore(rp, (lr & 1) ? 0x80000000u : (unsigned)((lr >> 1) * (kF * 4) + kk * 16 + 64 * mo), m);
+                    }
+                }
                 if constexpr (OUT3) {
 #pragma unroll
                     for (int c = 0; c < 3; ++c) {
@@ -1009,23 +1034,28 @@ hipError_t launch_next_mlp_out3(const float* ln, const float* x, float* out, con
     return co ? launch_mlp<true, 4>(ln, x, out, w, npix, o3, s) : launch_mlp<true, 8>(ln, x, out, w, npix, o3, s);
 }
 
-template <bool OUT3>
-static hipError_t launch_block(const float* x, float* out, const NextBlockW& w, int B, int H, int W, Out3 o3, hipStream_t s) {
+template <bool OUT3, bool POOL = false>
+static hipError_t launch_block(const float* x, float* out, const NextBlockW& w, int B, int H, int W, Out3 o3, hipStream_t s,
+                               float* pool = nullptr) {
     if ((size_t)H * W * kF * 4 >= 0x80000000ull) return hipErrorInvalidValue;
     static std::atomic<uint64_t> attr{0};
-    if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(convblock_kernel<OUT3>), F_LDS_BYTES, attr); e != hipSuccess)
+    if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(convblock_kernel<OUT3, POOL>), F_LDS_BYTES, attr); e != hipSuccess)
         return e;
     const int tx = (W + E_TW - 1) / E_TW, ty = (H + E_TH - 1) / E_TH;
     const int ntiles = B * tx * ty;
     if (ntiles <= 0) return hipSuccess;
     // persistent: one workgroup per CU (LDS), never more workgroups than tiles; the XCD band map needs a multiple of 8
     const int grid = ((std::min(ntiles, num_cus()) + 7) / 8) * 8;
-    hipLaunchKernelGGL(convblock_kernel<OUT3>, dim3(grid), dim3(512), F_LDS_BYTES, s, x, w, out, B, H, W, tx, ty, ntiles, o3);
+    hipLaunchKernelGGL((convblock_kernel<OUT3, POOL>), dim3(grid), dim3(512), F_LDS_BYTES, s, x, w, out, B, H, W, tx, ty, ntiles, o3, pool);
     return hipGetLastError();
 }
 
 hipError_t launch_next_block(const float* x, float* out, const NextBlockW& w, int B, int H, int W, hipStream_t s) {
     return launch_block<false>(x, out, w, B, H, W, Out3{}, s);
+}
+
+hipError_t launch_next_block_pool(const float* x, float* out, float* pooled, const NextBlockW& w, int B, int H, int W, hipStream_t s) {
+    return launch_block<false, true>(x, out, w, B, H, W, Out3{}, s, pooled);
 }
 
 hipError_t launch_next_block_out3(const float* x, float* out, const NextBlockW& w, int B, int H, int W, const float* w3x48,

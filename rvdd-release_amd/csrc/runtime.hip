@@ -129,6 +129,7 @@ struct rvdd_handle {
     int seq_major = 0;            // 1 = full-resolution stages one sequence at a time (see seq_major_on)
     bool fuse_upsample = true;    // UpConv's bilinear x2 inside the Winograd patch load (RVDD_FUSE_UPSAMPLE=0: separate kernel)
     bool next_fused = true;       // ConvNeXt ConvBlock as ONE kernel (RVDD_NEXT_FUSED=0 / option "next_fused" 0: dwln + mlp kernels, the A/B reference)
+    bool next_pool = true;        // ConvNeXt, fused blocks: MaxPool2d(2) from the epilogue of the block in front of a DownConv
     bool next_streams = false;    // ConvNeXt, two-kernel blocks, B >= 2: the two halves of the batch as two chains on two streams (measured: no gain)
     hipStream_t stream2 = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -755,6 +756,7 @@ int rvdd_create(const rvdd_cfg* cfg, rvdd_t** out) {
     if (const char* fu = std::getenv("RVDD_FUSE_UPSAMPLE")) h->fuse_upsample = std::atoi(fu) != 0;
     if (const char* nf = std::getenv("RVDD_NEXT_FUSED")) h->next_fused = std::atoi(nf) != 0;
     if (const char* w4 = std::getenv("RVDD_WINO4")) h->wino4 = std::atoi(w4);
+    if (const char* np = std::getenv("RVDD_NEXT_POOL")) h->next_pool = std::atoi(np) != 0;
     if (const char* ns = std::getenv("RVDD_NEXT_STREAMS")) h->next_streams = std::atoi(ns) != 0;
     if (const char* cv = std::getenv("RVDD_CONV")) {     // direct | winograd (forced at every size) | anything else = auto
         h->use_wino = std::strcmp(cv, "direct") != 0;
@@ -991,6 +993,11 @@ int rvdd_set_option(rvdd_t* h, const char* name, int32_t value) {
         h->next_fused = value != 0;
         return RVDD_OK;
     }
+    if (std::strcmp(name, "next_pool") == 0) {
+        // 0 = MaxPool2d(2) as its own kernel behind the fused block (A/B reference of the pooling epilogue; same bits)
+        h->next_pool = value != 0;
+        return RVDD_OK;
+    }
     if (std::strcmp(name, "next_streams") == 0) {
         // 0 = ConvNeXt's two-kernel blocks on the caller's stream only (A/B reference of the two half-batch chains)
         h->next_streams = value != 0 && h->stream2 != nullptr;
@@ -1016,7 +1023,7 @@ int rvdd_set_option(rvdd_t* h, const char* name, int32_t value) {
         h->force_wino = value == 2;
         return RVDD_OK;
     }
-    return fail(h, RVDD_ERR_ARG, "rvdd_set_option: unknown option '%s' (known: no_warp, warp_raw, prev_noisy_frame, conv_kernel, seq_major, graphs, fuse_upsample, next_fused, next_streams, wino4)", name);
+    return fail(h, RVDD_ERR_ARG, "rvdd_set_option: unknown option '%s' (known: no_warp, warp_raw, prev_noisy_frame, conv_kernel, seq_major, graphs, fuse_upsample, next_fused, next_pool, next_streams, wino4)", name);
 }
 
 int rvdd_reset(rvdd_t* h) {

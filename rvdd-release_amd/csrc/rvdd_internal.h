@@ -150,6 +150,8 @@ hipError_t launch_next_mlp_out3(const float* ln, const float* x, float* out, con
 // [B][H][W], out != x.  _out3: also the 1x1 conv 48 -> 3 on the block's output (out_nchw [B][3][H*W], out_nhwc4
 // [B][H*W][4]; either may be null)
 hipError_t launch_next_block(const float* x, float* out, const NextBlockW& w, int B, int H, int W, hipStream_t s);
+// the same, and MaxPool2d(2) of the block's output into pooled [B][H/2][W/2] (NHWC48) from the epilogue
+hipError_t launch_next_block_pool(const float* x, float* out, float* pooled, const NextBlockW& w, int B, int H, int W, hipStream_t s);
 hipError_t launch_next_block_out3(const float* x, float* out, const NextBlockW& w, int B, int H, int W, const float* w3x48,
                                   const float* b3, float* out_nchw, float* out_nhwc4, hipStream_t s);
 // 1x1 projection on MFMA: in1 NHWC[c1] (+ in2 NHWC[c2]) -> out NHWC48; (c1,c2) = (16,0) or (48,48)

@@ -803,6 +803,37 @@ def test_convblock_one_kernel_equals_two_kernels(arch, stem, fut):
             assert (outs[0][1] - outs[1][1]).abs().max() < 1e-5, (B, H, W)
 
 
+def test_pooling_epilogue_equals_maxpool_kernel():
+    """MaxPool2d(2) in front of each DownConv (networks/new_unet.py:200-204) written from the epilogue of the fused
+    ConvBlock ahead of it (the default) against the separate pooling kernel (option next_pool = 0): a maximum has no
+    rounding, so the outputs and the recurrent features are bit-identical -- at sizes whose levels have odd heights
+    and widths (floor semantics), ragged tiles, levels smaller than a tile, and batches."""
+    from rvdd_release_amd import synth
+    from rvdd_release_amd.runtime import RvddRuntime
+    if "next-feat-future-iso3200" not in BUILT:
+        pytest.skip("ConvNeXt path not built")
+    arch, fut = "next+feat", 1
+    sd = load_weights(VARIANTS["next-feat-future-iso3200"][0])
+    for B, H, W in ((1, 16, 16), (3, 22, 130), (2, 130, 22), (1, 50, 66), (2, 72, 104), (1, 180, 320)):
+        T = 4
+        seqs = [synth.make_sequence(T, H, W, iso=3200, seed=650 + b, device="cuda") for b in range(B)]
+        st = lambda f: torch.stack([f(s) for s in seqs], 0)
+        outs = []
+        for pool in (1, 0):
+            rt = RvddRuntime(arch, fut, B, H, W, 0)
+            rt.set_option("next_pool", pool)
+            rt.load_state_dict(sd)
+            o = []
+            for t in range(1, T - fut):
+                o.append(rt.step(st(lambda s: s.raw[t - 1]) if t == 1 else None, st(lambda s: s.raw[t]),
+                                 st(lambda s: s.raw[t + 1]), st(lambda s: s.flow_prev[t]), st(lambda s: s.flow_next[t])).clone())
+            outs.append((o, rt.get_state()[1].clone()))
+            rt.close()
+        for a, b in zip(outs[0][0], outs[1][0]):
+            assert torch.equal(a, b), (B, H, W, float((a - b).abs().max()))
+        assert torch.equal(outs[0][1], outs[1][1]), (B, H, W)
+
+
 @pytest.mark.parametrize("name", [n for n in BUILT if ARCH[n].startswith("next")])
 def test_two_kernel_convblock_golden(name, monkeypatch):
     """The two-kernel ConvBlock (A/B reference of the fused kernel that runs by default, RVDD_NEXT_FUSED=0) on the
