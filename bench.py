@@ -52,7 +52,10 @@ DESCR = {
     "C5": "recurrent convunet+feat ISO3200 1280x720 90-frame sequences, 8 per GPU (64 on 8 GPUs)",
 }
 FP32_PEAK_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md, chip table (vector = matrix f32)
-_CONV = "conv3x3_kernel<48, 1, false>" if os.environ.get("RVDD_CONV") == "direct" else "wino3x3_kernel<1, false>"
+F16_PEAK_TFLOPS = 2500.0          # same table: dense F16 / BF16 MFMA (~2.5 PF; the 5 PF figure is 2:1 sparsity)
+# the convunet's plain 48 -> 48 3x3 conv: the split-f16 kernel (default), or the f32-MFMA kernels (RVDD_CONV=f32 | winograd | direct)
+_CONV = {"direct": "conv3x3_kernel<48, 1, false>", "winograd": "wino3x3_kernel<1, false>",
+         "f32": "wino3x3_kernel<1, false>"}.get(os.environ.get("RVDD_CONV", ""), "conv3x3h_kernel<48, 1, false>")
 _NEXT = "mlp_kernel" if os.environ.get("RVDD_NEXT_FUSED") == "0" else "convblock_kernel"
 DOMINANT = {"convunet": _CONV, "convunet+feat": _CONV, "next": _NEXT, "next+feat": _NEXT}
 # The launches of a kernel class inside one frame-step repeat with period 11 (plain 48->48 3x3 conv; 14 when the
@@ -61,7 +64,9 @@ DOMINANT = {"convunet": _CONV, "convunet+feat": _CONV, "next": _NEXT, "next+feat
 EVENT_STRIDE = 3
 # MFMA flops a kernel EXECUTES per algorithmic (direct 3x3 conv) flop: Winograd F(2x2,3x3) multiplies 16 times per
 # 2x2 outputs where the direct form multiplies 36 times
-EXECUTED_PER_ALGORITHMIC = {"wino3x3": 16.0 / 36.0}
+EXECUTED_PER_ALGORITHMIC = {"wino3x3": 16.0 / 36.0,
+                            # split-f16 kernel: three F16 MFMAs (hi.hi, hi.lo, lo.hi) per product, K = 432 padded to 448
+                            "conv3x3h": 3.0 * 448.0 / 432.0}
 
 
 def _free_port():
@@ -356,11 +361,17 @@ def main():
             pass
         factor = next((f for pre, f in EXECUTED_PER_ALGORITHMIC.items() if dom.startswith(pre)), 1.0)
         executed = k["tflops"] * factor
-        roofline = {"bound": "mfma", "kernel": dom, "achieved": round(executed, 2), "peak": FP32_PEAK_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(executed / FP32_PEAK_TFLOPS, 4), "traffic": traffic,
+        split = dom.startswith("conv3x3h")
+        peak = F16_PEAK_TFLOPS if split else FP32_PEAK_TFLOPS
+        roofline = {"bound": "mfma", "kernel": dom, "achieved": round(executed, 2), "peak": peak,
+                    "unit": "TFLOP/s", "frac": round(executed / peak, 4), "traffic": traffic,
                     "traffic_source": traffic_src,
                     "algorithmic_bytes_per_launch": round(k["bytes_per_launch"]),
-                    "what_is_counted": "MFMA flops the kernel executes (Winograd F(2x2,3x3): 16/36 of the direct conv's)"
+                    "mfma_dtype": "f16 (f32 operands split hi + lo, f32 accumulation)" if split else "f32",
+                    "hbm_gbps_algorithmic": round(k["gbps"], 1),
+                    "what_is_counted": "F16 MFMA flops the kernel executes: 3 MFMAs per product (hi.hi, hi.lo, lo.hi), K 432 padded to 448"
+                                       if split else
+                                       "MFMA flops the kernel executes (Winograd F(2x2,3x3): 16/36 of the direct conv's)"
                                        if factor != 1.0 else "the kernel's algorithmic flops (all executed on MFMA)",
                     "algorithmic_equiv_tflops": round(k["tflops"], 2),
                     "launches": k["launches"], "avg_launch_us": round(k["avg_us"], 2),
@@ -442,6 +453,10 @@ def main():
         "unit": "frames/s", "n_gpus": world, "n_ranks_seen": n_ranks_seen, "distributed": distributed, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": args.scaling,
         "vs_baseline": None, "dtype": "f32", "data": data,
+        "arithmetic": ("f32 in, f32 out, f32 accumulation; the convunet's 48-channel 3x3 convs multiply on the F16 matrix pipe with "
+                       "every f32 operand split into two f16 halves (3 MFMAs per product): as close to the reference as the "
+                       "f32-MFMA kernels (tests/split_precision_study.py, DESIGN.md 4.1c); RVDD_CONV=f32 runs those instead")
+                      if (not arch.startswith("next") and _CONV.startswith("conv3x3h")) else "f32 throughout (f32 MFMA, f32 VALU)",
         "config": {"workload": f"{config}: {DESCR[config]}" + (f" (run with --frames {T})" if args.frames else ""),
                    "arch": arch, "checkpoint": stem,
                    "frame": f"{W}x{H}", "frames_per_sequence": T, "sequences_per_gpu": len(my_seqs),

@@ -184,8 +184,13 @@ int rvdd_srgb_metrics(rvdd_t* h, const uint8_t* a, const uint8_t* b, int32_t n, 
  *              Not defined with feature recurrence (the reference fails on the shapes there): error.
  *   "prev_noisy_frame" (--prev_noisy_frame, :33, :335-337): the frame handed to the next step as "previous" is the
  *              demosaiced NOISY current frame, not the denoised one (the feature recurrence is unaffected).
- *   "conv_kernel": which kernel runs the 3x3 convs: 0 = by launch size (default), 1 = the direct kernel, 2 = the
- *              Winograd kernel at every size (tests, A/B measurements).
+ *   "conv_kernel": which kernel runs the convunet's 3x3 convs.  0 (default) = the 48-channel layers on the F16 matrix
+ *              pipe with each f32 operand split into two f16 halves, three MFMAs per product, f32 accumulation
+ *              (conv3x3h.hip: as close to the reference as the f32 kernels; activations
+ *              must stay below 65504 in magnitude, beyond that the split saturates), the 16-channel first layer and
+ *              UpConv's fused upsample on an f32-MFMA kernel chosen by launch size; 1 = the direct f32 kernel
+ *              everywhere; 2 = the Winograd f32 kernel everywhere; 4 = f32 kernels chosen by launch size (1, 2, 4:
+ *              exact-f32 products, the A/B reference, about 0.8 of the default's frame rate at 720p).
  *   "seq_major": 1 = the full-resolution stages of the convunet run one sequence at a time (measured slower; off).
  *   "fuse_upsample": 0 = UpConv's bilinear x2 upsample runs as its own kernel instead of inside the Winograd patch
  *              load of the conv behind it (default 1; same bits either way).

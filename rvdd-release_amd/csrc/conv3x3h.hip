@@ -1,0 +1,452 @@
+// 3x3 convolution (padding 1, 48 output channels) as an implicit GEMM on the F16 matrix pipe with SPLIT f32 operands:
+// the same networks/unet.py layers as conv3x3.hip / wino3x3.hip (:26-76 NConvBlock, :194-208 ConvMaxPool2d, :635-669
+// bottleneck, :699-720 PostConvs), f32 in, f32 out, f32 accumulation.
+//
+// Why.  On gfx950 v_mfma_f32_16x16x4_f32 runs at 64 FLOP/clk/SIMD (the vector rate, and ON the vector lanes: VALU work
+// beside it adds to its time), v_mfma_f32_16x16x32_f16 at 16x that, and leaves the vector issue port free half of its
+// cycles (tools/f16_mfma_bench.hip; profiles/r03_f16_mfma_bench.txt).  An f32 value x is split exactly into
+//     x = hi + lo + r,   hi = f16(x) rounded toward zero,  lo = f16(x - hi),  |r| <= 2^-22 |x|  (2^-25 absolute below 2^-3:
+//                                                                                               lo is then subnormal, kept)
+// and a product of two split values is taken as hi.hi + hi.lo + lo.hi (each exact in the f32 accumulator; the dropped
+// lo.lo is 2^-22 of the product): three F16 MFMAs in place of sixteen-times-slower f32 ones.  The filters are scaled by
+// a power of two per layer before the split (so their lo halves are normal numbers) and the sums scaled back in the
+// epilogue, which is exact.  tests/split_precision_study.py runs the scheme through the oracle over the 30 / 90-frame
+// fixtures: 2.3e-6 from the reference's frames (the f32 kernels of this library: 3e-6); f16 overflows at 65504, the
+// largest activation of those runs is 8.8, and the round-toward-zero split saturates instead of producing infinities.
+//
+// Orientation as conv3x3.hip: D[cout][pixel] += W[cout][k] X[k][pixel]; lane l holds pixel l & 15 and, per MFMA, the
+// eight consecutive k of group l >> 4.  k runs (tap, channel): 8-channel group G = 4 chunk + (l >> 4) is channels
+// 8 (G % 6) .. +7 of tap G / 6 (CIN = 48: 54 groups, 14 chunks of 32, the last two groups zero filters).
+//
+// Work: a persistent workgroup of 8 waves per CU walks 16x16-pixel tiles.  The 18x18 halo tile is fetched as f32 into
+// registers one tile ahead (buffer loads, out-of-image pixels zero-filled by out-of-range offsets = padding 1), split
+// ONCE per element and written to LDS as [pixel][hi 48 f16 | lo 48 f16 | 32 B pad] (224 B per pixel, an odd multiple of
+// 32: every B fragment read of the kernel is bank-conflict free, tools/lds_b128_bench.hip).  The split filter bank (14 chunks x 3 cout blocks x {hi, lo} x 1 KiB
+// lane-linear A fragments = 84 KiB) is DMA'd to LDS once per workgroup.  Wave w owns tile rows 2w, 2w+1 (two B
+// fragments per chunk) and all 48 couts (three A fragments): per chunk 6 + 4 ds_read_b128 (hi and lo) feed 18 MFMAs on
+// six accumulators, the fragments of the next chunk being read while the current one is multiplied.
+#include "rvdd_internal.h"
+
+#include <type_traits>
+
+namespace {
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+typedef __fp16 fp16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) void lds_void;
+
+constexpr int TH = 16, TW = 16, IH = TH + 2, IW = TW + 2;
+constexpr int NTHREADS = 512;
+
+template <int CIN>
+struct HGeo {
+    static constexpr int GPT = CIN / 8;                      // 8-channel groups per tap
+    static constexpr int NG = 9 * GPT;                       // groups of the whole filter
+    static constexpr int NCH = (NG + 3) / 4;                 // K chunks of 32 (one MFMA deep)
+    static constexpr int HI = CIN * 2;                       // bytes of one pixel's hi half
+    static constexpr int S = 2 * HI + 32;                    // LDS bytes per pixel: an odd multiple of 32 (tools/lds_b128_bench.hip:
+                                                             // every fragment pattern of the kernel conflict-free; 208 = 13 x 16 is 2-way)
+    static constexpr int W_BYTES = NCH * 3 * 2 * 1024;
+    static constexpr int I_BYTES = IH * IW * S;
+    static constexpr int P_FLOATS = 48 + 3 * 48 + 4;         // bias, PostConvs[1] weights and bias
+    static constexpr int LDS_BYTES = W_BYTES + I_BYTES + P_FLOATS * 4;
+    static constexpr int SEG = CIN / 4;                      // 16-B pieces of one f32 pixel
+    static constexpr int ROWSEG = IW * SEG;                  // ... of one halo row
+    static constexpr int RPR = NTHREADS / ROWSEG;            // halo rows fetched per round of one load per thread
+    static constexpr int NR = (IH + RPR - 1) / RPR;          // rounds per tile
+    static constexpr int A_SPLIT = 7;                        // chunks reached from the first A base pointer (< 64 KiB of offsets)
+};
+
+__device__ __forceinline__ f32x4 bload(__amdgpu_buffer_rsrc_t r, unsigned voff, int soff = 0) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+__device__ __forceinline__ void bstore(__amdgpu_buffer_rsrc_t r, unsigned off, f32x4 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, off, 0, 0);
+}
+
+// x (four f32) -> hi, lo (four f16 each, as two dwords): hi toward zero (never an infinity), lo = x - hi to nearest
+__device__ __forceinline__ void split4(f32x4 x, u32x2& hi, u32x2& lo) {
+    const fp16x2 h01 = __builtin_amdgcn_cvt_pkrtz(x[0], x[1]);
+    const fp16x2 h23 = __builtin_amdgcn_cvt_pkrtz(x[2], x[3]);
+    const h2 l01 = {(_Float16)(x[0] - (float)h01[0]), (_Float16)(x[1] - (float)h01[1])};
+    const h2 l23 = {(_Float16)(x[2] - (float)h23[0]), (_Float16)(x[3] - (float)h23[1])};
+    hi = u32x2{__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23)};
+    lo = u32x2{__builtin_bit_cast(unsigned, l01), __builtin_bit_cast(unsigned, l23)};
+}
+
+struct TilePos {
+    int b, y0, x0;
+};
+
+// Diagnostic build (-DRVDD_STAMPS, tools/conv3x3h_bench.hip): every wave adds the shader cycles it spends
+// in each phase of the tile loop to g_stamps (s_memtime; the reads cost a few per cent themselves).
+#ifdef RVDD_STAMPS
+__device__ unsigned long long g_stamps[8 * 8];      // [wave][phase 0..6, tiles]
+#define STAMP_DECL unsigned long long st_acc[7] = {0, 0, 0, 0, 0, 0, 0}, st_t = __builtin_amdgcn_s_memtime(), st_n = 0
+#define STAMP(i)                                                       \
+    do {                                                               \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime();  \
+        st_acc[i] += now_ - st_t;                                      \
+        st_t = now_;                                                   \
+    } while (0)
+#define STAMP_FLUSH                                                                        \
+    do {                                                                                   \
+        if ((threadIdx.x & 63) == 0) {                                                     \
+            const int w_ = threadIdx.x >> 6;                                               \
+            for (int i_ = 0; i_ < 7; ++i_) atomicAdd(&g_stamps[w_ * 8 + i_], st_acc[i_]);   \
+            atomicAdd(&g_stamps[w_ * 8 + 7], st_n);                                        \
+        }                                                                                  \
+    } while (0)
+#else
+#define STAMP_DECL
+#define STAMP(i)
+#define STAMP_FLUSH
+#endif
+
+template <int CIN, int EPI, bool ACC_IN>
+__global__ __launch_bounds__(NTHREADS) void conv3x3h_kernel(ConvArgs a) {
+    using G = HGeo<CIN>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    typedef __attribute__((address_space(3))) unsigned char lds_u8;
+    typedef __attribute__((address_space(3))) f32x4 lds_f4;
+    typedef __attribute__((address_space(3))) u32x2 lds_u2;
+    lds_u8* L = (lds_u8*)smem;
+    float* Pl = reinterpret_cast<float*>(smem + G::W_BYTES + G::I_BYTES);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 15;
+    const int g = lane >> 4;
+
+    {   // split filter bank -> LDS (linear copy of the host arrangement), every workgroup starting at another piece
+        __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, G::W_BYTES, 0x00020000);
+        constexpr int NP = G::W_BYTES / 1024;
+        const int rot = (int)((blockIdx.x * 37u) % (unsigned)NP);
+        for (int i = wave; i < NP; i += NTHREADS / 64) {
+            int k = i + rot;
+            if (k >= NP) k -= NP;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lds_void*)(smem + k * 1024), 16, (unsigned)(k * 1024 + lane * 16), 0, 0, 0);
+        }
+    }
+    if (tid < kF) Pl[tid] = a.bias[tid];
+    if constexpr (EPI == EPI_RELU_OUT3) {
+        if (tid >= 64 && tid < 64 + 3 * kF) Pl[kF + tid - 64] = a.w3[tid - 64];
+        else if (tid >= 256 && tid < 259) Pl[4 * kF + tid - 256] = a.b3[tid - 256];
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    // ---- tiles of this workgroup: the workgroups of one XCD (blockIdx & 7) share a contiguous eighth of the tile list,
+    // walked side by side, so that the halo columns two neighbours both read meet in that XCD's L2
+    int t, t_end, t_step;
+    if ((gridDim.x & 7) == 0) {
+        const int xcd = blockIdx.x & 7;
+        t = (int)(((long long)a.ntiles * xcd) >> 3) + (int)(blockIdx.x >> 3);
+        t_end = (int)(((long long)a.ntiles * (xcd + 1)) >> 3);
+        t_step = gridDim.x >> 3;
+    } else {
+        t = blockIdx.x;
+        t_end = a.ntiles;
+        t_step = gridDim.x;
+    }
+    const int tiles_per_img = a.tiles_x * a.tiles_y;
+    auto locate = [&](int tile, TilePos& p) {
+        p.b = __builtin_amdgcn_readfirstlane(tile / tiles_per_img);
+        const int rr = tile - p.b * tiles_per_img;
+        const int ty = __builtin_amdgcn_readfirstlane(rr / a.tiles_x);
+        p.y0 = ty * TH;
+        p.x0 = (rr - ty * a.tiles_x) * TW;
+    };
+
+    // ---- halo fetch: thread -> (row rp of the round, halo column hx, 16-B piece `part`), the same for every tile
+    const int rp = tid / G::ROWSEG;
+    const int rem = tid - rp * G::ROWSEG;
+    const int hx = rem / G::SEG;
+    const int part = rem - hx * G::SEG;
+    const bool ld_thread = rp < G::RPR;
+    const int g_lane = (rp * a.W + hx) * (CIN * 4) + part * 16;           // byte offset inside the image, relative to the halo origin
+    const unsigned l_lane = (unsigned)(G::W_BYTES + (rp * IW + hx) * G::S + part * 8);
+    const unsigned img_bytes = (unsigned)(a.H * a.W * CIN * 4);
+    // One round = one 16-B load per thread (RPR halo rows).  The rounds of the NEXT tile are issued one per chunk inside
+    // this tile's MFMA loop (a CU's texture path moves 64 B per clock: the 72 KiB of a halo tile are 1100 cycles of it, and
+    // issued in one burst they stood in front of the MFMAs), split in registers under the last chunks, and written to LDS
+    // between the two barriers at the end of the tile.
+    f32x4 pre[G::NR];
+    u32x2 shi[G::NR], slo[G::NR];
+    struct Src {
+        __amdgpu_buffer_rsrc_t r;
+        int org;
+        bool xok;
+        int y0;
+    };
+    auto source = [&](const TilePos& p, bool live) {
+        Src q;
+        q.r = __builtin_amdgcn_make_buffer_rsrc((void*)(a.in + (size_t)(live ? p.b : 0) * a.H * a.W * CIN), 0, live ? img_bytes : 0,
+                                                0x00020000);
+        q.org = ((p.y0 - 1) * a.W + (p.x0 - 1)) * (CIN * 4);
+        q.xok = ld_thread && (unsigned)(p.x0 - 1 + hx) < (unsigned)a.W;
+        q.y0 = p.y0;
+        return q;
+    };
+    auto fetch_round = [&](const Src& q, int r0) {
+        const int hy = G::RPR * r0 + rp;
+        const bool ok = q.xok && hy < IH && (unsigned)(q.y0 - 1 + hy) < (unsigned)a.H;
+        const int off = g_lane + q.org + r0 * G::RPR * a.W * (CIN * 4);
+        pre[r0] = bload(q.r, ok ? (unsigned)off : 0x80000000u);
+    };
+    auto write_tile = [&]() {       // split halves -> LDS
+#pragma unroll
+        for (int r0 = 0; r0 < G::NR; ++r0)
+            if (ld_thread && G::RPR * r0 + rp < IH) {
+                *(lds_u2*)(L + l_lane + r0 * G::RPR * IW * G::S) = shi[r0];
+                *(lds_u2*)(L + l_lane + r0 * G::RPR * IW * G::S + G::HI) = slo[r0];
+            }
+    };
+
+    // ---- fragment addresses
+    unsigned boff[G::NCH];           // B: this lane's pixel of tile row 2 wave, at the tap and channel group of chunk j
+#pragma unroll
+    for (int j = 0; j < G::NCH; ++j) {
+        int Gi = 4 * j + g;
+        if (Gi >= G::NG) Gi = G::NG - 1;          // the zero-filter groups of the last chunk: any valid address
+        const int tap = Gi / G::GPT;
+        const int c0 = (Gi - tap * G::GPT) * 8;
+        const int ky = tap / 3, kx = tap - 3 * ky;
+        boff[j] = (unsigned)(G::W_BYTES + ((2 * wave + ky) * IW + n + kx) * G::S + c0 * 2);
+    }
+    unsigned abase[2] = {(unsigned)(lane * 16), (unsigned)(lane * 16 + G::A_SPLIT * 6 * 1024)};
+    asm volatile("" : "+v"(abase[0]), "+v"(abase[1]));
+    h8 Af[2][3][2], Bf[2][2][2];
+    auto read_frags = [&](int buf, int j) {
+#pragma unroll
+        for (int mt = 0; mt < 3; ++mt)
+#pragma unroll
+            for (int hl = 0; hl < 2; ++hl) {
+                const int jj = j < G::A_SPLIT ? j : j - G::A_SPLIT;
+                Af[buf][mt][hl] = __builtin_bit_cast(h8, *(lds_f4*)(L + abase[j < G::A_SPLIT ? 0 : 1] + ((jj * 3 + mt) * 2 + hl) * 1024));
+            }
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int hl = 0; hl < 2; ++hl)
+                Bf[buf][nt][hl] = __builtin_bit_cast(h8, *(lds_f4*)(L + boff[j] + nt * IW * G::S + hl * G::HI));
+    };
+
+    const unsigned map_bytes = (unsigned)(a.H * a.W * kF * 4);
+    const unsigned out_bytes = (unsigned)(a.Hout * a.Wout * kF * 4);
+    const float ws = a.wscale;
+
+    TilePos cur, nxt;
+    locate(t, cur);
+    {   // the first tile: fetched, split and staged before the loop
+        const Src q = source(cur, t < t_end);
+#pragma unroll
+        for (int r0 = 0; r0 < G::NR; ++r0) fetch_round(q, r0);
+#pragma unroll
+        for (int r0 = 0; r0 < G::NR; ++r0) split4(pre[r0], shi[r0], slo[r0]);
+        write_tile();
+    }
+    // results of the tile before, stored one 16-B piece per chunk inside the current tile's MFMA loop (before the first
+    // tile: out-of-range offsets, the stores are dropped)
+    constexpr int NOUT = EPI == EPI_POOL ? 3 : 6;
+    f32x4 outv[NOUT];
+    unsigned so_prev[2] = {0x80000000u, 0x80000000u};
+    __amdgpu_buffer_rsrc_t orr_prev = __builtin_amdgcn_make_buffer_rsrc((void*)a.out, 0, 0, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < NOUT; ++i) outv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    STAMP_DECL;
+#pragma unroll 1
+    while (t < t_end) {
+        STAMP(0);
+        __syncthreads();       // tile t is staged
+        STAMP(1);
+        locate(t + t_step, nxt);
+        const Src qn = source(nxt, t + t_step < t_end);
+        const int yy0 = cur.y0 + 2 * wave, xx = cur.x0 + n;
+        unsigned po[2], so[2];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const bool ok = yy0 + nt < a.H && xx < a.W;
+            po[nt] = ok ? (unsigned)((((yy0 + nt) * a.W + xx) * kF + 4 * g) * 4) : 0x80000000u;
+            so[nt] = ok ? (unsigned)((((yy0 + nt + a.oy) * a.Wout + xx + a.ox) * kF + 4 * g) * 4) : 0x80000000u;
+        }
+        if constexpr (EPI == EPI_POOL) {
+            const int pr_ = (cur.y0 >> 1) + wave, pc = xx >> 1;
+            const bool ok = !(n & 1) && pr_ < a.Hout && pc < a.Wout;
+            so[0] = ok ? (unsigned)(((pr_ * a.Wout + pc) * kF + 4 * g) * 4) : 0x80000000u;
+        }
+        f32x4 side[2][3];
+        __amdgpu_buffer_rsrc_t pr = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)((ACC_IN ? a.acc_in : a.out) + (size_t)cur.b * a.H * a.W * kF), 0, map_bytes, 0x00020000);
+        STAMP(2);
+
+        // ---- 14 chunks x 18 MFMAs, and between the chunks: a store of the last tile, a side load of this one, a halo
+        // load of the next one (chunks 0..8), the split of what those loads brought (the last three chunks)
+        f32x4 acc[2][3];
+        read_frags(0, 0);
+#pragma unroll
+        for (int j = 0; j < G::NCH; ++j) {
+            const int cb = j & 1;
+            if (j + 1 < G::NCH) read_frags(cb ^ 1, j + 1);
+            if (j < NOUT) bstore(orr_prev, so_prev[EPI == EPI_POOL ? 0 : j / 3] + 64 * (j % 3), outv[j]);
+            if constexpr (ACC_IN) {
+                if (j < 6) side[j / 3][j % 3] = bload(pr, po[j / 3], 64 * (j % 3));
+            }
+            if (j < G::NR) fetch_round(qn, j);
+#pragma unroll
+            for (int r0 = 0; r0 < G::NR; ++r0)
+                if (j == G::NCH - 1 - (G::NR - 1 - r0) / 3) {
+                    split4(pre[r0], shi[r0], slo[r0]);
+                    asm volatile("" : "+v"(shi[r0]), "+v"(slo[r0]));      // here, not sunk behind the barrier next to its use
+                }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                const int ha = p == 1 ? 1 : 0, hb = p == 0 ? 1 : 0;      // hi.lo, lo.hi, then hi.hi
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int mt = 0; mt < 3; ++mt) {
+                        const f32x4 c = (j == 0 && p == 0) ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[nt][mt];
+                        acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Af[cb][mt][ha], Bf[cb][nt][hb], c, 0, 0, 0);
+                    }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        STAMP(3);
+
+        // ---- epilogue: scale back, bias / partial sums, activation; the 48-channel results wait in registers for the
+        // next tile's chunks
+        f32x4 v[2][3];
+#pragma unroll
+        for (int mt = 0; mt < 3; ++mt) {
+            const f32x4 bias = *reinterpret_cast<const f32x4*>(Pl + 16 * mt + 4 * g);
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                const f32x4 base = ACC_IN ? side[nt][mt] : bias;
+                v[nt][mt] = __builtin_elementwise_fma(acc[nt][mt], f32x4{ws, ws, ws, ws}, base);
+            }
+        }
+        if constexpr (EPI == EPI_POOL) {
+            // MaxPool2d(2) of the un-activated conv output: the wave's two rows are one pooling row pair, columns n, n ^ 1
+#pragma unroll
+            for (int mt = 0; mt < 3; ++mt)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float q = fmaxf(v[0][mt][e], v[1][mt][e]);
+                    outv[mt][e] = fmaxf(q, __shfl_xor(q, 1));
+                }
+        } else {
+            float o3[2][3];
+            if constexpr (EPI == EPI_RELU_OUT3) {
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) o3[nt][0] = o3[nt][1] = o3[nt][2] = 0.f;
+            }
+            __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(
+                (void*)((EPI == EPI_RELU_ADD2 ? a.res1 : a.out) + (size_t)cur.b * a.H * a.W * kF), 0, map_bytes, 0x00020000);
+            __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc(
+                (void*)((EPI == EPI_RELU_ADD2 ? a.res2 : a.out) + (size_t)cur.b * a.H * a.W * kF), 0, map_bytes, 0x00020000);
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < 3; ++mt) {
+                    f32x4 x = v[nt][mt];
+                    if constexpr (EPI == EPI_RELU || EPI == EPI_RELU_ADD2 || EPI == EPI_RELU_OUT3) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) x[e] = fmaxf(x[e], 0.f);
+                    }
+                    if constexpr (EPI == EPI_RELU_ADD2) x = (bload(r1, po[nt], 64 * mt) + bload(r2, po[nt], 64 * mt)) + x;   // e3 + d1 + d2 (unet.py:563-566)
+                    outv[nt * 3 + mt] = x;
+                    if constexpr (EPI == EPI_RELU_OUT3) {
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) {
+                            const f32x4 w = *reinterpret_cast<const f32x4*>(Pl + kF + c * kF + 16 * mt + 4 * g);
+                            o3[nt][c] += (x[0] * w[0] + x[1] * w[1]) + (x[2] * w[2] + x[3] * w[3]);
+                        }
+                    }
+                }
+            if constexpr (EPI == EPI_RELU_OUT3) {
+                const size_t hw = (size_t)a.H * a.W;
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    float tq[3];
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        float q = o3[nt][c];
+                        q += __shfl_xor(q, 16);
+                        q += __shfl_xor(q, 32);
+                        tq[c] = q + Pl[4 * kF + c];
+                    }
+                    if (g == 0 && yy0 + nt < a.H && xx < a.W) {
+                        const size_t pidx = (size_t)(yy0 + nt) * a.W + xx;
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) a.out3_nchw[((size_t)cur.b * 3 + c) * hw + pidx] = tq[c];
+                        if (a.out3_nhwc4)
+                            reinterpret_cast<f32x4*>(a.out3_nhwc4)[(size_t)cur.b * hw + pidx] = f32x4{tq[0], tq[1], tq[2], 0.f};
+                    }
+                }
+            }
+        }
+        so_prev[0] = so[0];
+        so_prev[1] = so[1];
+        orr_prev = __builtin_amdgcn_make_buffer_rsrc((void*)(a.out + (size_t)cur.b * a.Hout * a.Wout * kF), 0, out_bytes, 0x00020000);
+        STAMP(4);
+        __syncthreads();       // every wave has read its last fragment of this tile: the next one may be staged
+        STAMP(5);
+        write_tile();
+        STAMP(6);
+#ifdef RVDD_STAMPS
+        ++st_n;
+#endif
+        t += t_step;
+        cur = nxt;
+    }
+    // the last tile's results
+#pragma unroll
+    for (int j = 0; j < NOUT; ++j) bstore(orr_prev, so_prev[EPI == EPI_POOL ? 0 : j / 3] + 64 * (j % 3), outv[j]);
+    STAMP_FLUSH;
+}
+
+template <int CIN, int EPI, bool ACC_IN>
+hipError_t launch_h(const ConvArgs& a0, hipStream_t s) {
+    static std::atomic<uint64_t> attr_done{0};
+    using G = HGeo<CIN>;
+    void (*kern)(ConvArgs) = conv3x3h_kernel<CIN, EPI, ACC_IN>;
+    if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(kern), G::LDS_BYTES, attr_done); e != hipSuccess) return e;
+    ConvArgs a = a0;
+    a.tiles_x = (a.W + TW - 1) / TW;
+    a.tiles_y = (a.H + TH - 1) / TH;
+    a.ntiles = a.B * a.tiles_x * a.tiles_y;
+    const int cus = current_device_cus();
+    const int grid = a.ntiles < cus ? a.ntiles : cus;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHREADS), G::LDS_BYTES, s, a);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+size_t conv3x3h_weight_bytes(int cin) { return cin == 48 ? HGeo<48>::W_BYTES : HGeo<16>::W_BYTES; }
+
+hipError_t launch_conv3x3h(const ConvArgs& a, int cin, int epi, hipStream_t s) {
+    if (a.B <= 0 || a.H <= 0 || a.W <= 0) return hipSuccess;
+    if (cin != 48 || a.ups) return hipErrorInvalidValue;
+    // every map is addressed with one 32-bit byte offset per image whose out-of-image sentinel is 2^31
+    if ((size_t)a.H * a.W * kF * 4 >= 0x80000000ull || (size_t)a.Hout * a.Wout * kF * 4 >= 0x80000000ull) return hipErrorInvalidValue;
+    const bool acc = a.acc_in != nullptr;
+    switch (epi) {
+        case EPI_NONE:
+            return acc ? launch_h<48, EPI_NONE, true>(a, s) : launch_h<48, EPI_NONE, false>(a, s);
+        case EPI_RELU:
+            return acc ? launch_h<48, EPI_RELU, true>(a, s) : launch_h<48, EPI_RELU, false>(a, s);
+        case EPI_POOL:
+            return acc ? hipErrorInvalidValue : launch_h<48, EPI_POOL, false>(a, s);
+        case EPI_RELU_ADD2:
+            return acc ? hipErrorInvalidValue : launch_h<48, EPI_RELU_ADD2, false>(a, s);
+        case EPI_RELU_OUT3:
+            return acc ? hipErrorInvalidValue : launch_h<48, EPI_RELU_OUT3, false>(a, s);
+    }
+    return hipErrorInvalidValue;
+}

@@ -29,6 +29,8 @@ struct Conv3 {            // one 3x3 conv layer, split per 48-channel source
     float* w[2] = {nullptr, nullptr};
     float* wu[2] = {nullptr, nullptr};   // Winograd F(2x2,3x3) transformed bank (48-channel sources only)
     float* w4[2] = {nullptr, nullptr};   // Winograd F(4x4,3x3) transformed banks, three cout thirds (48-channel sources only)
+    float* wh[2] = {nullptr, nullptr};   // split-f16 banks of conv3x3h.hip (hi / lo halves of 2^s w; 48-channel sources only)
+    float wh_inv[2] = {1.f, 1.f};        // 2^-s of each
     float* bias = nullptr;
 };
 
@@ -125,6 +127,8 @@ struct rvdd_handle {
     bool prev_noisy = false;      // --prev_noisy_frame (rvdd_set_option): the next step's "previous frame" is the demosaiced noisy one
     bool no_warp = false;         // --no_warp (rvdd_set_option): previous output / features / next frame enter the net unwarped
     bool use_wino = true;         // 48->48 3x3 convs: Winograd F(2x2,3x3) (RVDD_CONV=direct selects the direct kernel)
+    bool split16 = true;          // 48->48 3x3 convs on the F16 matrix pipe with split f32 operands (conv3x3h.hip); RVDD_CONV=f32 | direct |
+                                  // winograd / "conv_kernel" 1, 2, 4 select the f32-MFMA kernels (the A/B reference)
     int wino4 = 0;                // 1 = F(4x4,3x3) (wino4x4.hip) for the plain / two-pass 48->48 layers of the large levels (RVDD_WINO4)
     int seq_major = 0;            // 1 = full-resolution stages one sequence at a time (see seq_major_on)
     bool fuse_upsample = true;    // UpConv's bilinear x2 inside the Winograd patch load (RVDD_FUSE_UPSAMPLE=0: separate kernel)
@@ -282,6 +286,57 @@ std::vector<float> arrange_wino3x3(const HostTensor& t, int c0, int nj = 3) {
             for (int pos = 0; pos < 16; ++pos)
                 out[(((size_t)(pos * nj + j) * 3 + m) * 64 + g * 16 + lr) * 4 + ii] = (float)u[pos / 4][pos % 4];
         }
+    return out;
+}
+
+// f32 -> f16 bits, toward zero (saturating) or to nearest even; f16 bits -> f32.  Host-side twins of v_cvt_pkrtz_f16_f32 /
+// v_cvt_f16_f32 for the split filter banks.
+uint16_t f16_bits(float x, bool toward_zero) {
+    _Float16 hv = (_Float16)x;                   // to nearest even
+    uint16_t u;
+    std::memcpy(&u, &hv, 2);
+    if (toward_zero) {
+        if ((u & 0x7fffu) == 0x7c00u) u = (uint16_t)((u & 0x8000u) | 0x7bffu);      // an overflow saturates
+        else if (std::fabs((float)hv) > std::fabs(x)) u = (uint16_t)(u - 1);        // magnitude one step down
+    }
+    return u;
+}
+float f16_value(uint16_t u) {
+    _Float16 hv;
+    std::memcpy(&hv, &u, 2);
+    return (float)hv;
+}
+
+// OIHW [48][cin_total][3][3], channels [c0, c0+48) -> the split bank of conv3x3h.hip: w' = 2^s w (s = the largest power
+// keeping |w'| <= 1024, returned as 2^-s), hi = f16(w') toward zero, lo = f16(w' - hi); stored
+// [chunk 14][cout block 3][hi, lo][lane = 16g + (cout & 15)][e 8] as f16 with 8-channel group G = 4 chunk + g = channels
+// 8 (G % 6) + e of tap G / 6 (groups 54, 55 zero): lane-linear 16-B A fragments of v_mfma_f32_16x16x32_f16.
+std::vector<float> arrange_conv3x3h(const HostTensor& t, int c0, float* inv_scale) {
+    const int cin_total = (int)t.shape[1];
+    float mx = 0.f;
+    for (int co = 0; co < 48; ++co)
+        for (int c = 0; c < 48; ++c)
+            for (int k = 0; k < 9; ++k) mx = std::max(mx, std::fabs(t.data[((size_t)co * cin_total + c0 + c) * 9 + k]));
+    int sft = 0;
+    if (mx > 0.f && std::isfinite(mx)) sft = std::min(40, std::max(-40, (int)std::floor(std::log2(1024.0 / mx))));
+    const float sc = std::ldexp(1.0f, sft);
+    *inv_scale = std::ldexp(1.0f, -sft);
+    const size_t halves = conv3x3h_weight_bytes(48) / 2;
+    std::vector<uint16_t> bank(halves, 0);
+    for (int G = 0; G < 54; ++G) {
+        const int j = G / 4, g = G % 4, tap = G / 6, cg = (G % 6) * 8;
+        for (int co = 0; co < 48; ++co)
+            for (int e = 0; e < 8; ++e) {
+                const float w = t.data[((size_t)co * cin_total + c0 + cg + e) * 9 + tap] * sc;      // exact: a power of two
+                const uint16_t hi = f16_bits(w, true);
+                const uint16_t lo = f16_bits(w - f16_value(hi), false);
+                const size_t frag = ((size_t)(j * 3 + co / 16) * 2) * 512 + (size_t)(g * 16 + co % 16) * 8 + e;
+                bank[frag] = hi;
+                bank[frag + 512] = lo;
+            }
+    }
+    std::vector<float> out(halves / 2);
+    std::memcpy(out.data(), bank.data(), halves * 2);
     return out;
 }
 
@@ -454,6 +509,15 @@ const char* wino_name(int epi, bool acc) {
     return names[epi][acc];
 }
 
+const char* conv_name_h(int epi, bool acc) {
+    static const char* names[5][2] = {{"conv3x3h_kernel<48, 0, false>", "conv3x3h_kernel<48, 0, true>"},
+                                      {"conv3x3h_kernel<48, 1, false>", "conv3x3h_kernel<48, 1, true>"},
+                                      {"conv3x3h_kernel<48, 2, false>", "conv3x3h_kernel<48, 2, true>"},
+                                      {"conv3x3h_kernel<48, 3, false>", "conv3x3h_kernel<48, 3, true>"},
+                                      {"conv3x3h_kernel<48, 4, false>", "conv3x3h_kernel<48, 4, true>"}};
+    return names[epi][acc];
+}
+
 struct ConvCall {
     const float* in = nullptr;
     int src = 0;             // which weight slice of the layer
@@ -533,6 +597,14 @@ int run_conv(rvdd_t* h, const Conv3& L, const ConvCall& c, hipStream_t s, Sub su
     if (c.ups && !(cin == 48 && L.wu[c.src] && wino_applies(h, c.H, c.W)))
         return fail(h, RVDD_ERR_STATE, "run_conv: the fused upsample exists in the Winograd kernel only");
     if (c.ups) bytes -= px * 4.0 * 36.0;          // reads the quarter-size map
+    // the F16 matrix pipe with split operands: every 48-channel layer but UpConv's fused upsample
+    if (h->split16 && cin == 48 && !c.ups && L.wh[c.src]) {
+        a.w = L.wh[c.src];
+        a.wscale = L.wh_inv[c.src];
+        Scope sc(h, s, conv_name_h(c.epi, c.acc_in != nullptr), flops, bytes);
+        HIPCHK(h, launch_conv3x3h(a, 48, c.epi, s));
+        return RVDD_OK;
+    }
     // F(4x4,3x3): plain and two-pass 48 -> 48 layers with enough 64x16-pixel units for every one of the 80 unit sequences
     if (h->wino4 && h->use_wino && cin == 48 && !c.ups && L.w4[c.src] && (c.epi == EPI_NONE || c.epi == EPI_RELU) &&
         (h->wino4 == 2 || (long)a.B * ((c.W + 63) / 64) * ((c.H + 15) / 16) >= 400)) {
@@ -758,9 +830,12 @@ int rvdd_create(const rvdd_cfg* cfg, rvdd_t** out) {
     if (const char* w4 = std::getenv("RVDD_WINO4")) h->wino4 = std::atoi(w4);
     if (const char* np = std::getenv("RVDD_NEXT_POOL")) h->next_pool = std::atoi(np) != 0;
     if (const char* ns = std::getenv("RVDD_NEXT_STREAMS")) h->next_streams = std::atoi(ns) != 0;
-    if (const char* cv = std::getenv("RVDD_CONV")) {     // direct | winograd (forced at every size) | anything else = auto
+    if (const char* cv = std::getenv("RVDD_CONV")) {
+        // f32 (the f32-MFMA kernels, direct or Winograd by launch size) | direct | winograd (that f32 kernel at every size) |
+        // anything else = the default: split-f16 kernel for the 48-channel layers, f32 kernels by size for the rest
         h->use_wino = std::strcmp(cv, "direct") != 0;
         h->force_wino = std::strcmp(cv, "winograd") == 0;
+        h->split16 = std::strcmp(cv, "direct") != 0 && std::strcmp(cv, "winograd") != 0 && std::strcmp(cv, "f32") != 0;
     }
     const int B = cfg->batch, H = cfg->height, W = cfg->width;
     int rc = RVDD_OK;
@@ -880,6 +955,7 @@ int rvdd_finalize_weights(rvdd_t* h) {
                     RC(upload(h, &L.w[sidx], arrange_conv3x3(wt, 48 * sidx, 48, 48)));
                     RC(upload(h, &L.wu[sidx], arrange_wino3x3(wt, 48 * sidx)));
                     RC(upload(h, &L.w4[sidx], arrange_wino4x4(wt, 48 * sidx)));
+                    RC(upload(h, &L.wh[sidx], arrange_conv3x3h(wt, 48 * sidx, &L.wh_inv[sidx])));
                 }
             } else {
                 L.nsrc = 1;
@@ -888,6 +964,7 @@ int rvdd_finalize_weights(rvdd_t* h) {
                 RC(upload(h, &L.w[0], arrange_conv3x3(wt, 0, cin, L.cin_pad[0])));
                 RC(upload(h, &L.wu[0], cin == 48 ? arrange_wino3x3(wt, 0) : arrange_wino3x3(wt, 0, 1)));
                 if (cin == 48) RC(upload(h, &L.w4[0], arrange_wino4x4(wt, 0)));
+                if (cin == 48) RC(upload(h, &L.wh[0], arrange_conv3x3h(wt, 0, &L.wh_inv[0])));
             }
             RC(upload(h, &L.bias, h->staged.at(n + ".bias").data));
             for (int li = 0; li < CU_COUNT; ++li)
@@ -1016,11 +1093,13 @@ int rvdd_set_option(rvdd_t* h, const char* name, int32_t value) {
         return RVDD_OK;
     }
     if (std::strcmp(name, "conv_kernel") == 0) {
-        // which kernel runs the 3x3 convs: 0 = by launch size (default), 1 = the direct kernel everywhere,
-        // 2 = the Winograd kernel everywhere (also where it is the slower choice: tests and A/B measurements)
-        if (value < 0 || value > 2) return fail(h, RVDD_ERR_ARG, "rvdd_set_option: conv_kernel must be 0 (auto), 1 (direct) or 2 (winograd)");
+        // which kernel runs the 3x3 convs: 0 = the default (48-channel layers on the split-f16 kernel, the others on an f32
+        // kernel chosen by launch size), 1 = the direct f32 kernel everywhere, 2 = the Winograd f32 kernel everywhere (also
+        // where it is the slower choice: tests and A/B measurements), 4 = f32 kernels chosen by launch size
+        if (value < 0 || value > 4 || value == 3) return fail(h, RVDD_ERR_ARG, "rvdd_set_option: conv_kernel must be 0 (default), 1 (direct f32), 2 (winograd f32) or 4 (f32 by size)");
         h->use_wino = value != 1;
         h->force_wino = value == 2;
+        h->split16 = value == 0;
         return RVDD_OK;
     }
     return fail(h, RVDD_ERR_ARG, "rvdd_set_option: unknown option '%s' (known: no_warp, warp_raw, prev_noisy_frame, conv_kernel, seq_major, graphs, fuse_upsample, next_fused, next_pool, next_streams, wino4)", name);
@@ -1415,10 +1494,11 @@ int rvdd_debug_conv_bench(rvdd_t* h, int32_t variant, int32_t level, int32_t ite
     ENTER(h);
     if (!h->finalized || h->is_next()) return fail(h, RVDD_ERR_STATE, "rvdd_debug_conv_bench: needs a finalized convunet handle");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const bool was = h->prof_on, was_wino = h->use_wino;
+    const bool was = h->prof_on, was_wino = h->use_wino, was_split = h->split16;
     h->prof_on = false;
-    h->use_wino = h->force_wino = variant == 3;   // variant 3 = Winograd kernel, 0..2 = direct kernel variants
-    conv3x3_set_variant(variant == 3 ? 0 : variant);
+    h->use_wino = h->force_wino = variant == 3;   // variant 3 = Winograd kernel, 4 = split-f16 kernel, 0..2 = direct kernel variants
+    h->split16 = variant == 4;
+    conv3x3_set_variant(variant >= 3 ? 0 : variant);
     ConvCall c;
     c.in = h->lv[level].t[0]; c.out = h->lv[level].t[1]; c.H = h->lv[level].H; c.W = h->lv[level].W; c.epi = EPI_RELU;
     const Conv3& L = h->cu[CU_ENC1_1];
@@ -1436,6 +1516,7 @@ int rvdd_debug_conv_bench(rvdd_t* h, int32_t variant, int32_t level, int32_t ite
     h->prof_on = was;
     h->use_wino = was_wino;
     h->force_wino = false;
+    h->split16 = was_split;
     return rc;
 }
 

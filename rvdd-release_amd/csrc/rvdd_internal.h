@@ -61,6 +61,7 @@ struct ConvArgs {
     const float* b3;      // [3]
     float* out3_nchw;     // [B][3][H][W]
     float* out3_nhwc4;    // [B][H][W][4] copy for the next frame's warp, or nullptr
+    float wscale;         // conv3x3h.hip: 2^-s, the filters having been scaled by 2^s before the f16 split
 };
 
 // cin = 16 or 48.  Returns hipGetLastError().
@@ -73,6 +74,10 @@ size_t wino3x3_weight_floats();
 // banks arranged by arrange_wino4x4 (runtime.hip)
 hipError_t launch_wino4x4(const ConvArgs& a, int epi, hipStream_t s);
 size_t wino4x4_weight_floats();
+// the same layers on the F16 matrix pipe with split f32 operands (conv3x3h.hip); a.w = the split bank arranged by
+// arrange_conv3x3h (runtime.hip), a.wscale its scale; cin 48, every epilogue, with or without a.acc_in; no a.ups
+hipError_t launch_conv3x3h(const ConvArgs& a, int cin, int epi, hipStream_t s);
+size_t conv3x3h_weight_bytes(int cin);
 void conv3x3_set_variant(int v);   // A/B switch used by rvdd_debug_conv_bench only
 
 // -------------------------------------------------------------- pre-stages --

@@ -36,14 +36,16 @@ def parity_psnr(a, b):
     return 200.0 if mse == 0 else 10 * math.log10(4.0 / mse)
 
 
-@pytest.fixture(params=["auto", "winograd"])
+@pytest.fixture(params=["auto", "winograd", "f32"])
 def conv_kernel(request, monkeypatch):
-    """Which kernel runs the 3x3 convs.  "auto" picks by launch size, so small frames run the direct kernel;
-    "winograd" forces the production (720p) Winograd kernel at every size: ragged tiles in x and y, the
-    zero_pad_features output placement, the 16-channel first layer and the fused 1x1 epilogue all run at the
-    fixture sizes the reference pinned.  Read by rvdd_create (RVDD_CONV)."""
-    if request.param == "winograd":
-        monkeypatch.setenv("RVDD_CONV", "winograd")
+    """Which kernel runs the 3x3 convs.  "auto" is the default: every 48-channel layer on the F16 matrix pipe with
+    split f32 operands (conv3x3h.hip) at every size, the first layer and UpConv's fused upsample on an f32 kernel
+    picked by launch size; "f32" picks among the f32-MFMA kernels by launch size, so small frames run the direct
+    kernel; "winograd" forces the Winograd f32 kernel at every size: ragged tiles in x and y, the zero_pad_features
+    output placement, the 16-channel first layer and the fused 1x1 epilogue all run at the fixture sizes the
+    reference pinned.  Read by rvdd_create (RVDD_CONV)."""
+    if request.param in ("winograd", "f32"):
+        monkeypatch.setenv("RVDD_CONV", request.param)
     else:
         monkeypatch.delenv("RVDD_CONV", raising=False)
     return request.param
@@ -211,7 +213,7 @@ def test_odd_shapes_vs_oracle(arch, stem, fut, conv_kernel):
     (tools/shape_sweep.py runs the long form of this: 11 shapes x B in {1, 3}.)"""
     from rvdd_release_amd import synth
     from rvdd_release_amd.runtime import RvddRuntime
-    if arch.startswith("next") and conv_kernel == "winograd":
+    if arch.startswith("next") and conv_kernel != "auto":
         pytest.skip("the conv kernel choice does not enter ConvNeXtUnet")
     sd = load_weights(stem)
     T, B = 3 + fut, 3
