@@ -197,6 +197,8 @@ int rvdd_srgb_metrics(rvdd_t* h, const uint8_t* a, const uint8_t* b, int32_t n, 
  *   "graphs":   1 = frame-steps are captured into hipGraphs and replayed (measured slower on ROCm 7.2; off).
  *   "next_fused": 0 = ConvNeXtUnet's ConvBlock (networks/new_unet.py:74-103) as two kernels (depth-wise + LayerNorm,
  *               then the MLP) instead of the one fused kernel: the A/B reference; same results to a few ulp.
+ *   "next_split": 0 = the fused ConvBlock multiplies its two 1x1 convs on the f32 matrix pipe (exact-f32 products) instead
+ *               of the F16 pipe with split f32 operands (the default, as "conv_kernel" 0; the A/B reference).
  *   "next_pool": 0 = with next_fused, MaxPool2d(2) in front of a DownConv (new_unet.py:200-204) as its own kernel instead
  *               of the fused block's epilogue (default 1; same bits either way).
  *   "wino4":    1 / 2 = the plain and two-pass 48 -> 48 3x3 convs on the Winograd F(4x4,3x3) kernel where a launch has

@@ -578,6 +578,40 @@ constexpr int F_OFF_PAR = F_OFF_DW + D_W_FLOATS;
 constexpr int F_OFF_T = F_OFF_PAR + E_PAR_FLOATS;
 constexpr size_t F_LDS_BYTES = (size_t)(F_OFF_T + 2 * E_BUF_FLOATS) * 4;  // 153,040 B
 static_assert(F_LDS_BYTES <= 160 * 1024 && (F_OFF_T % 4) == 0 && 4 * 3072 <= 2 * E_BUF_FLOATS, "LDS plan");
+// SPLIT (the default): the two 1x1 convs on the F16 matrix pipe with split f32 operands, as conv3x3h.hip (x = hi + lo in
+// f16, a product = hi.hi + hi.lo + lo.hi, f32 accumulation; filters scaled by a power of two before the split).  The lane
+// map of the f32 form stays: a lane's 4-channel blocks ARE halves of an F16 MFMA's 8-deep k group, so the operands are
+// register pairs side by side and the k order is whatever the host arranged the filter fragments for:
+//   fc1, per 16 hidden units m, lane blocks x0 x1 x2 (channels 16j + 4kk ..+3):
+//        [wh0 wh1].[xh0 xh1] + [wh0 wh1].[xl0 xl1] + [wl0 wl1].[xh0 xh1] + [wh2 wl2].[xh2 xh2] + [wh2 wl2].[xl2 xl2]
+//        = 5 MFMAs on fragments Fa Fb Fc (1 KiB each): 3 KiB per m, 36 KiB.  (The last one carries wl2.xl2 along, a
+//        lo.lo term: it fills the half k group that wh2.xl2 leaves, with the fragment the fourth already holds.  A
+//        half-deep v_mfma_f32_16x16x16_f16 in its place gave NaNs: hipcc 7.2 schedules the 16x16x32 that reads its
+//        result as accumulator two instructions behind it, which the hardware does not interlock.)
+//   fc2, per pair of hidden blocks (2p, 2p+1) and 16 outputs mo:
+//        [wh wh'].[hh hh'] + [wh wh'].[hl hl'] + [wl wl'].[hh hh'] = 3 MFMAs, fragments Gh Gl: 36 KiB
+// 114 F16 MFMAs of 16 cycles per 16 pixels in place of 288 f32 ones of 32, and they leave the vector port free half of
+// their time: the phase is bound by its GELU, no longer by the matrix pipe.
+constexpr int F_W1H_BYTES = 12 * 3072, F_W2H_BYTES = 6 * 3 * 2 * 1024;
+constexpr int F_SPLIT_SHIFT = (F_W1H_BYTES + F_W2H_BYTES) / 4 - 2 * M_W_FLOATS;      // floats the regions behind the filters move by
+constexpr size_t F_LDS_BYTES_SPLIT = F_LDS_BYTES + (size_t)F_SPLIT_SHIFT * 4;           // the same 153,040 B
+static_assert(F_LDS_BYTES_SPLIT <= 160 * 1024 && (F_SPLIT_SHIFT % 4) == 0 && F_SPLIT_SHIFT >= 0, "LDS plan (split)");
+typedef _Float16 h8v __attribute__((ext_vector_type(8)));
+typedef _Float16 h4v __attribute__((ext_vector_type(4)));
+typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+typedef __fp16 fp16x2v __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x2v __attribute__((ext_vector_type(2)));
+// x (four f32) -> hi, lo (four f16 each): hi toward zero (saturating, never an infinity), lo = x - hi to nearest
+__device__ __forceinline__ void split4h(f32x4 x, u32x2v& hi, u32x2v& lo) {
+    const fp16x2v h01 = __builtin_amdgcn_cvt_pkrtz(x[0], x[1]);
+    const fp16x2v h23 = __builtin_amdgcn_cvt_pkrtz(x[2], x[3]);
+    const h2v l01 = {(_Float16)(x[0] - (float)h01[0]), (_Float16)(x[1] - (float)h01[1])};
+    const h2v l23 = {(_Float16)(x[2] - (float)h23[0]), (_Float16)(x[3] - (float)h23[1])};
+    hi = u32x2v{__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23)};
+    lo = u32x2v{__builtin_bit_cast(unsigned, l01), __builtin_bit_cast(unsigned, l23)};
+}
+__device__ __forceinline__ h8v cat8(u32x2v a, u32x2v b) { return __builtin_bit_cast(h8v, u32x4{a[0], a[1], b[0], b[1]}); }
+
 // Vector-memory instructions EVERY wave issues in the MLP phase of a tile, i.e. after the LDS-DMA of the next tile's
 // first two chunks: per 16-pixel group 3 residual loads + 3 stores through buffer descriptors (issued whether the row
 // exists or not: a missing row has zero records).  vmcnt retires in issue order, so "all but the newest 24" covers the
@@ -587,17 +621,18 @@ constexpr int F_MLP_VMEM = 2 * 6;
 // POOL: the block also writes MaxPool2d(2) of its output (DownConv = MaxPool2d then ConvBlock, new_unet.py:200-204: the
 // block in front of a DownConv feeds the pool): a wave's two tile rows are one pooling row pair, horizontal neighbours
 // are lanes lr and lr ^ 1 -- one max between the two groups' outputs, one DPP max, even lanes store; no maxpool kernel.
-template <bool OUT3, bool POOL = false>
+template <bool OUT3, bool POOL = false, bool SPLIT = true>
 __global__ __launch_bounds__(512, 2) void convblock_kernel(const float* __restrict__ x, NextBlockW wt, float* __restrict__ out,
                                                           int B, int H, int W, int tiles_x, int tiles_y, int ntiles, Out3 o3,
                                                           float* __restrict__ pool) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int SH = SPLIT ? F_SPLIT_SHIFT : 0;
     float* W1 = smem;
-    float* W2 = smem + F_OFF_W2;
-    float* BV = smem + F_OFF_BV;
-    float* Wl = smem + F_OFF_DW;            // [49][48]
-    float* Pl = smem + F_OFF_PAR;           // dw_b | ln_w | ln_b
-    float* Tl = smem + F_OFF_T;             // two chunk buffers; the LayerNorm exchange between the phases
+    float* W2 = smem + (SPLIT ? F_W1H_BYTES / 4 : F_OFF_W2);
+    float* BV = smem + F_OFF_BV + SH;
+    float* Wl = smem + F_OFF_DW + SH;       // [49][48]
+    float* Pl = smem + F_OFF_PAR + SH;      // dw_b | ln_w | ln_b
+    float* Tl = smem + F_OFF_T + SH;        // two chunk buffers; the LayerNorm exchange between the phases
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -653,13 +688,23 @@ __global__ __launch_bounds__(512, 2) void convblock_kernel(const float* __restri
     dma_chunk(cur, 0, 0);
     dma_chunk(cur, 1, 1);
     {   // weights of the block -> LDS, once per workgroup
-        __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc((void*)wt.fc1_w, 0, M_W_FLOATS * 4, 0x00020000);
-        __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc((void*)wt.fc2_w, 0, M_W_FLOATS * 4, 0x00020000);
-        for (int k = wave; k < M_W_FLOATS / 256; k += 8) {
-            dma16(r1, W1 + k * 256, (unsigned)(k * 1024 + lane * 16));
-            dma16(r2, W2 + k * 256, (unsigned)(k * 1024 + lane * 16));
+        if constexpr (SPLIT) {
+            __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc((void*)wt.fc1_h, 0, F_W1H_BYTES, 0x00020000);
+            __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc((void*)wt.fc2_h, 0, F_W2H_BYTES, 0x00020000);
+            for (int k = wave; k < F_W1H_BYTES / 1024; k += 8) dma16(r1, W1 + k * 256, (unsigned)(k * 1024 + lane * 16));
+            for (int k = wave; k < F_W2H_BYTES / 1024; k += 8) dma16(r2, W2 + k * 256, (unsigned)(k * 1024 + lane * 16));
+            // biases in the filters' scale (they seed the accumulators), the layerscale in fc2's inverse scale: all exact
+            for (int i = tid; i < M2_BV_FLOATS; i += 512)
+                BV[i] = i < 192 ? wt.fc1_b[i] * wt.fc1_scale : (i < 240 ? wt.fc2_b[i - 192] * wt.fc2_scale : wt.ls[i - 240] * wt.fc2_inv);
+        } else {
+            __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc((void*)wt.fc1_w, 0, M_W_FLOATS * 4, 0x00020000);
+            __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc((void*)wt.fc2_w, 0, M_W_FLOATS * 4, 0x00020000);
+            for (int k = wave; k < M_W_FLOATS / 256; k += 8) {
+                dma16(r1, W1 + k * 256, (unsigned)(k * 1024 + lane * 16));
+                dma16(r2, W2 + k * 256, (unsigned)(k * 1024 + lane * 16));
+            }
+            for (int i = tid; i < M2_BV_FLOATS; i += 512) BV[i] = i < 192 ? wt.fc1_b[i] : (i < 240 ? wt.fc2_b[i - 192] : wt.ls[i - 240]);
         }
-        for (int i = tid; i < M2_BV_FLOATS; i += 512) BV[i] = i < 192 ? wt.fc1_b[i] : (i < 240 ? wt.fc2_b[i - 192] : wt.ls[i - 240]);
         if constexpr (OUT3) {
             if (tid < 147) BV[M2_BV_FLOATS + tid] = tid < 144 ? o3.w[tid] : o3.b[tid - 144];
         }
@@ -798,10 +843,12 @@ __global__ __launch_bounds__(512, 2) void convblock_kernel(const float* __restri
         STAMP(st_ln);
         // =========================================================== MLP on the wave's four rows (groups of 16 pixels)
         f32x4 wq[2][2], b1n[2];
-        wq[0][0] = F1(0, 0);
-        wq[0][1] = F1(0, 1);
-        b1n[0] = bvp[0];
-        b1n[1] = bvp[4];
+        if constexpr (!SPLIT) {
+            wq[0][0] = F1(0, 0);
+            wq[0][1] = F1(0, 1);
+            b1n[0] = bvp[0];
+            b1n[1] = bvp[4];
+        }
         f32x4 vkeep[3];
 #pragma unroll
         for (int n = 0; n < 2; ++n) {
@@ -813,7 +860,65 @@ __global__ __launch_bounds__(512, 2) void convblock_kernel(const float* __restri
             const size_t first = ((size_t)cur.b * H + min(y, H - 1)) * W + cur.x0;
             __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(x + first * kF), 0, valid * (kF * 4), 0x00020000);
             __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void*)(out + first * kF), 0, valid * (kF * 4), 0x00020000);
-            f32x4 hid[12], a2[3], vq[2][3], xr[3], lv[3];
+            f32x4 a2[3], xr[3], lv[3];
+            if constexpr (SPLIT) {
+                const char* w1b = reinterpret_cast<const char*>(W1) + lane_o * 16;
+                const char* w2b = reinterpret_cast<const char*>(W2) + lane_o * 16;
+                auto FA = [&](int m, int f) { return __builtin_bit_cast(h8v, *reinterpret_cast<const f32x4*>(w1b + m * 3072 + f * 1024)); };
+                auto FG = [&](int p, int mo, int hl) { return __builtin_bit_cast(h8v, *reinterpret_cast<const f32x4*>(w2b + ((p * 3 + mo) * 2 + hl) * 1024)); };
+                u32x2v xh[3], xl[3];
+#pragma unroll
+                for (int j = 0; j < 3; ++j) split4h(xc[n][j], xh[j], xl[j]);
+                const h8v B1 = cat8(xh[0], xh[1]), B2 = cat8(xl[0], xl[1]), B3 = cat8(xh[2], xh[2]);
+                const h8v B4 = cat8(xl[2], xl[2]);
+#pragma unroll
+                for (int mo = 0; mo < 3; ++mo) a2[mo] = bvp[48 + 4 * mo];
+#pragma unroll
+                for (int mo = 0; mo < 3; ++mo) xr[mo] = bload(rx, lane_off + 64 * mo);
+                const float s1i = wt.fc1_inv;
+#pragma unroll
+                for (int p = 0; p < 6; ++p) {
+                    // fc1 for hidden blocks 2p, 2p+1 (two accumulator chains side by side), small terms first
+                    f32x4 hq[2];
+                    h8v fa[2], fb[2], fc[2];
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        hq[k] = bvp[4 * (2 * p + k)];
+                        fa[k] = FA(2 * p + k, 0);
+                        fb[k] = FA(2 * p + k, 1);
+                        fc[k] = FA(2 * p + k, 2);
+                    }
+                    h8v gh[3], gl[3];
+#pragma unroll
+                    for (int mo = 0; mo < 3; ++mo) {
+                        gh[mo] = FG(p, mo, 0);
+                        gl[mo] = FG(p, mo, 1);
+                    }
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) hq[k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[k], B2, hq[k], 0, 0, 0);
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) hq[k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[k], B1, hq[k], 0, 0, 0);
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) hq[k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fc[k], B4, hq[k], 0, 0, 0);
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) hq[k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fc[k], B3, hq[k], 0, 0, 0);
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) hq[k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[k], B1, hq[k], 0, 0, 0);
+                    u32x2v hh[2], hl[2];
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) split4h(gelu_phi4(hq[k] * s1i), hh[k], hl[k]);
+                    const h8v Bhh = cat8(hh[0], hh[1]), Bhl = cat8(hl[0], hl[1]);
+#pragma unroll
+                    for (int mo = 0; mo < 3; ++mo) a2[mo] = __builtin_amdgcn_mfma_f32_16x16x32_f16(gh[mo], Bhl, a2[mo], 0, 0, 0);
+#pragma unroll
+                    for (int mo = 0; mo < 3; ++mo) a2[mo] = __builtin_amdgcn_mfma_f32_16x16x32_f16(gl[mo], Bhh, a2[mo], 0, 0, 0);
+#pragma unroll
+                    for (int mo = 0; mo < 3; ++mo) a2[mo] = __builtin_amdgcn_mfma_f32_16x16x32_f16(gh[mo], Bhh, a2[mo], 0, 0, 0);
+                }
+#pragma unroll
+                for (int mo = 0; mo < 3; ++mo) lv[mo] = bvp[60 + 4 * mo];
+            } else {
+            f32x4 hid[12], vq[2][3];
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int st = 0; st < 18; ++st) {
@@ -875,6 +980,7 @@ __global__ __launch_bounds__(512, 2) void convblock_kernel(const float* __restri
                     for (int mo = 0; mo < 3; ++mo)
                         a2[mo] = __builtin_amdgcn_mfma_f32_16x16x4f32(vq[m & 1][mo][r], hid[m][r], a2[mo], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
+            }
             }
             // ---- out = x + layerscale * r
             float part[3] = {0.f, 0.f, 0.f};
@@ -1034,20 +1140,28 @@ hipError_t launch_next_mlp_out3(const float* ln, const float* x, float* out, con
     return co ? launch_mlp<true, 4>(ln, x, out, w, npix, o3, s) : launch_mlp<true, 8>(ln, x, out, w, npix, o3, s);
 }
 
-template <bool OUT3, bool POOL = false>
-static hipError_t launch_block(const float* x, float* out, const NextBlockW& w, int B, int H, int W, Out3 o3, hipStream_t s,
-                               float* pool = nullptr) {
+template <bool OUT3, bool POOL, bool SPLIT>
+static hipError_t launch_block_t(const float* x, float* out, const NextBlockW& w, int B, int H, int W, Out3 o3, hipStream_t s,
+                                 float* pool) {
     if ((size_t)H * W * kF * 4 >= 0x80000000ull) return hipErrorInvalidValue;
     static std::atomic<uint64_t> attr{0};
-    if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(convblock_kernel<OUT3, POOL>), F_LDS_BYTES, attr); e != hipSuccess)
+    constexpr size_t LDS = SPLIT ? F_LDS_BYTES_SPLIT : F_LDS_BYTES;
+    if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(convblock_kernel<OUT3, POOL, SPLIT>), LDS, attr); e != hipSuccess)
         return e;
     const int tx = (W + E_TW - 1) / E_TW, ty = (H + E_TH - 1) / E_TH;
     const int ntiles = B * tx * ty;
     if (ntiles <= 0) return hipSuccess;
     // persistent: one workgroup per CU (LDS), never more workgroups than tiles; the XCD band map needs a multiple of 8
     const int grid = ((std::min(ntiles, num_cus()) + 7) / 8) * 8;
-    hipLaunchKernelGGL((convblock_kernel<OUT3, POOL>), dim3(grid), dim3(512), F_LDS_BYTES, s, x, w, out, B, H, W, tx, ty, ntiles, o3, pool);
+    hipLaunchKernelGGL((convblock_kernel<OUT3, POOL, SPLIT>), dim3(grid), dim3(512), LDS, s, x, w, out, B, H, W, tx, ty, ntiles, o3, pool);
     return hipGetLastError();
+}
+// w.fc1_h set = the split-f16 MLP (the default); null = the f32-MFMA form (option next_split 0: the A/B reference)
+template <bool OUT3, bool POOL = false>
+static hipError_t launch_block(const float* x, float* out, const NextBlockW& w, int B, int H, int W, Out3 o3, hipStream_t s,
+                               float* pool = nullptr) {
+    return w.fc1_h ? launch_block_t<OUT3, POOL, true>(x, out, w, B, H, W, o3, s, pool)
+                   : launch_block_t<OUT3, POOL, false>(x, out, w, B, H, W, o3, s, pool);
 }
 
 hipError_t launch_next_block(const float* x, float* out, const NextBlockW& w, int B, int H, int W, hipStream_t s) {

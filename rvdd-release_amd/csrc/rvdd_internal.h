@@ -138,6 +138,11 @@ struct NextBlockW {          // device pointers, one ConvBlock (networks/new_une
     const float* fc2_w;
     const float* fc2_b;      // [48]
     const float* ls;         // [48]
+    // the fused kernel's split-f16 MLP (convnext.hip SPLIT): filter fragments of 2^s fc1 / 2^s' fc2 as f16 hi, lo halves
+    // (arranged in runtime_next.inc), the scales and their inverses; fc1_h null = the f32-MFMA form
+    const float* fc1_h;
+    const float* fc2_h;
+    float fc1_scale, fc1_inv, fc2_scale, fc2_inv;
 };
 // one ConvBlock = dwln (x -> LayerNorm(dwconv7x7(x))) then mlp (ln, x -> x + ls * MLP(ln)); x NHWC48
 // co = the launch shares the CUs with a kernel of the other half-batch chain (runtime_next.inc): dwln one workgroup per
