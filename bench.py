@@ -55,7 +55,7 @@ FP32_PEAK_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md, chip
 F16_PEAK_TFLOPS = 2500.0          # same table: dense F16 / BF16 MFMA (~2.5 PF; the 5 PF figure is 2:1 sparsity)
 # the convunet's plain 48 -> 48 3x3 conv: the split-f16 kernel (default), or the f32-MFMA kernels (RVDD_CONV=f32 | winograd | direct)
 _CONV = {"direct": "conv3x3_kernel<48, 1, false>", "winograd": "wino3x3_kernel<1, false>",
-         "f32": "wino3x3_kernel<1, false>"}.get(os.environ.get("RVDD_CONV", ""), "conv3x3h_kernel<48, 1, false>")
+         "f32": "wino3x3_kernel<1, false>"}.get(os.environ.get("RVDD_CONV", ""), "conv3x3h_kernel<48, 1, false, false>")
 _NEXT = "mlp_kernel" if os.environ.get("RVDD_NEXT_FUSED") == "0" else "convblock_kernel"
 DOMINANT = {"convunet": _CONV, "convunet+feat": _CONV, "next": _NEXT, "next+feat": _NEXT}
 # The launches of a kernel class inside one frame-step repeat with period 11 (plain 48->48 3x3 conv; 14 when the

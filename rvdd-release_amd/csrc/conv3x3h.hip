@@ -106,7 +106,10 @@ __device__ unsigned long long g_stamps[8 * 8];      // [wave][phase 0..6, tiles]
 #define STAMP_FLUSH
 #endif
 
-template <int CIN, int EPI, bool ACC_IN>
+// UPS (UpConv, networks/unet.py:88-147): `a.in` is the half-resolution map [B][H/2][W/2][48] and the conv input is its
+// bilinear x2 upsample (align_corners=False), interpolated in the halo fetch with the expressions of upsample2x_kernel
+// (prestage.hip) in the same order: the same bits as "upsample, then conv", the upsampled map is never written.
+template <int CIN, int EPI, bool ACC_IN, bool UPS = false>
 __global__ __launch_bounds__(NTHREADS) void conv3x3h_kernel(ConvArgs a) {
     using G = HGeo<CIN>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -169,33 +172,70 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3h_kernel(ConvArgs a) {
     const bool ld_thread = rp < G::RPR;
     const int g_lane = (rp * a.W + hx) * (CIN * 4) + part * 16;           // byte offset inside the image, relative to the halo origin
     const unsigned l_lane = (unsigned)(G::W_BYTES + (rp * IW + hx) * G::S + part * 8);
-    const unsigned img_bytes = (unsigned)(a.H * a.W * CIN * 4);
     // One round = one 16-B load per thread (RPR halo rows).  The rounds of the NEXT tile are issued one per chunk inside
     // this tile's MFMA loop (a CU's texture path moves 64 B per clock: the 72 KiB of a halo tile are 1100 cycles of it, and
     // issued in one burst they stood in front of the MFMAs), split in registers under the last chunks, and written to LDS
     // between the two barriers at the end of the tile.
     f32x4 pre[G::NR];
     u32x2 shi[G::NR], slo[G::NR];
+    f32x4 lo4[UPS ? 3 : 1][4];       // UPS: the 2x2 half-resolution pixels behind a halo piece, three rounds in flight
+    float up_ly[UPS ? 3 : 1];        // ... and their vertical weight (< 0: outside the upsampled map, the piece is zero)
     struct Src {
         __amdgpu_buffer_rsrc_t r;
         int org;
         bool xok;
         int y0;
+        unsigned xo0, xo1;           // UPS: byte offsets of the two source columns (with this thread's channel piece)
+        float lx1;
     };
     auto source = [&](const TilePos& p, bool live) {
         Src q;
-        q.r = __builtin_amdgcn_make_buffer_rsrc((void*)(a.in + (size_t)(live ? p.b : 0) * a.H * a.W * CIN), 0, live ? img_bytes : 0,
-                                                0x00020000);
+        const int ih = UPS ? a.H >> 1 : a.H, iw = UPS ? a.W >> 1 : a.W;
+        q.r = __builtin_amdgcn_make_buffer_rsrc((void*)(a.in + (size_t)(live ? p.b : 0) * ih * iw * CIN), 0,
+                                                live ? (unsigned)(ih * iw * CIN * 4) : 0, 0x00020000);
         q.org = ((p.y0 - 1) * a.W + (p.x0 - 1)) * (CIN * 4);
         q.xok = ld_thread && (unsigned)(p.x0 - 1 + hx) < (unsigned)a.W;
         q.y0 = p.y0;
+        q.xo0 = q.xo1 = 0;
+        q.lx1 = 0.f;
+        if constexpr (UPS) {
+            const int X = p.x0 - 1 + hx;
+            const float px = fmaxf(0.5f * ((float)X + 0.5f) - 0.5f, 0.f);
+            const int x0 = (int)px;
+            const int x1 = x0 + (x0 < iw - 1 ? 1 : 0);
+            q.lx1 = px - (float)x0;
+            q.xo0 = (unsigned)(x0 * (CIN * 4) + part * 16);
+            q.xo1 = (unsigned)(x1 * (CIN * 4) + part * 16);
+        }
         return q;
     };
     auto fetch_round = [&](const Src& q, int r0) {
         const int hy = G::RPR * r0 + rp;
         const bool ok = q.xok && hy < IH && (unsigned)(q.y0 - 1 + hy) < (unsigned)a.H;
-        const int off = g_lane + q.org + r0 * G::RPR * a.W * (CIN * 4);
-        pre[r0] = bload(q.r, ok ? (unsigned)off : 0x80000000u);
+        if constexpr (UPS) {
+            const int Y = q.y0 - 1 + hy, ih = a.H >> 1, iw = a.W >> 1;
+            const float py = fmaxf(0.5f * ((float)Y + 0.5f) - 0.5f, 0.f);
+            const int y0 = (int)py;
+            const int y1 = y0 + (y0 < ih - 1 ? 1 : 0);
+            up_ly[r0 % 3] = ok ? py - (float)y0 : -1.f;
+            const unsigned r0o = ok ? (unsigned)(y0 * iw * (CIN * 4)) : 0x80000000u, r1o = ok ? (unsigned)(y1 * iw * (CIN * 4)) : 0x80000000u;
+            lo4[r0 % 3][0] = bload(q.r, r0o + q.xo0);
+            lo4[r0 % 3][1] = bload(q.r, r0o + q.xo1);
+            lo4[r0 % 3][2] = bload(q.r, r1o + q.xo0);
+            lo4[r0 % 3][3] = bload(q.r, r1o + q.xo1);
+        } else {
+            const int off = g_lane + q.org + r0 * G::RPR * a.W * (CIN * 4);
+            pre[r0] = bload(q.r, ok ? (unsigned)off : 0x80000000u);
+        }
+    };
+    // UPS: round r0's four pixels -> its halo piece (vertical pass, then horizontal, each "a * wa, then one fused
+    // multiply-add", as upsample2x_kernel)
+    auto interp_round = [&](const Src& q, int r0) {
+        auto fma4 = [](f32x4 x, float sc, f32x4 c) { return __builtin_elementwise_fma(x, f32x4{sc, sc, sc, sc}, c); };
+        const float ly1 = up_ly[r0 % 3], ly0 = 1.f - ly1, lx1 = q.lx1, lx0 = 1.f - lx1;
+        const f32x4 c0 = fma4(lo4[r0 % 3][2], ly1, lo4[r0 % 3][0] * ly0), c1 = fma4(lo4[r0 % 3][3], ly1, lo4[r0 % 3][1] * ly0);
+        const f32x4 v = fma4(c1, lx1, c0 * lx0);
+        pre[r0] = ly1 < 0.f ? f32x4{0.f, 0.f, 0.f, 0.f} : v;
     };
     auto write_tile = [&]() {       // split halves -> LDS
 #pragma unroll
@@ -244,7 +284,10 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3h_kernel(ConvArgs a) {
     {   // the first tile: fetched, split and staged before the loop
         const Src q = source(cur, t < t_end);
 #pragma unroll
-        for (int r0 = 0; r0 < G::NR; ++r0) fetch_round(q, r0);
+        for (int r0 = 0; r0 < G::NR; ++r0) {
+            fetch_round(q, r0);
+            if constexpr (UPS) interp_round(q, r0);
+        }
 #pragma unroll
         for (int r0 = 0; r0 < G::NR; ++r0) split4(pre[r0], shi[r0], slo[r0]);
         write_tile();
@@ -296,6 +339,9 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3h_kernel(ConvArgs a) {
                 if (j < 6) side[j / 3][j % 3] = bload(pr, po[j / 3], 64 * (j % 3));
             }
             if (j < G::NR) fetch_round(qn, j);
+            if constexpr (UPS) {
+                if (j >= 2 && j - 2 < G::NR) interp_round(qn, j - 2);      // two chunks after its loads were issued
+            }
 #pragma unroll
             for (int r0 = 0; r0 < G::NR; ++r0)
                 if (j == G::NCH - 1 - (G::NR - 1 - r0) / 3) {
@@ -316,6 +362,8 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3h_kernel(ConvArgs a) {
             }
             __builtin_amdgcn_sched_barrier(0);
         }
+#pragma unroll
+        for (int j = G::NCH; j < NOUT; ++j) bstore(orr_prev, so_prev[EPI == EPI_POOL ? 0 : j / 3] + 64 * (j % 3), outv[j]);      // CIN 16: five chunks
         STAMP(3);
 
         // ---- epilogue: scale back, bias / partial sums, activation; the 48-channel results wait in registers for the
@@ -410,11 +458,11 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3h_kernel(ConvArgs a) {
     STAMP_FLUSH;
 }
 
-template <int CIN, int EPI, bool ACC_IN>
+template <int CIN, int EPI, bool ACC_IN, bool UPS = false>
 hipError_t launch_h(const ConvArgs& a0, hipStream_t s) {
     static std::atomic<uint64_t> attr_done{0};
     using G = HGeo<CIN>;
-    void (*kern)(ConvArgs) = conv3x3h_kernel<CIN, EPI, ACC_IN>;
+    void (*kern)(ConvArgs) = conv3x3h_kernel<CIN, EPI, ACC_IN, UPS>;
     if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(kern), G::LDS_BYTES, attr_done); e != hipSuccess) return e;
     ConvArgs a = a0;
     a.tiles_x = (a.W + TW - 1) / TW;
@@ -432,10 +480,20 @@ size_t conv3x3h_weight_bytes(int cin) { return cin == 48 ? HGeo<48>::W_BYTES : H
 
 hipError_t launch_conv3x3h(const ConvArgs& a, int cin, int epi, hipStream_t s) {
     if (a.B <= 0 || a.H <= 0 || a.W <= 0) return hipSuccess;
-    if (cin != 48 || a.ups) return hipErrorInvalidValue;
     // every map is addressed with one 32-bit byte offset per image whose out-of-image sentinel is 2^31
     if ((size_t)a.H * a.W * kF * 4 >= 0x80000000ull || (size_t)a.Hout * a.Wout * kF * 4 >= 0x80000000ull) return hipErrorInvalidValue;
     const bool acc = a.acc_in != nullptr;
+    if (cin == 16) {      // the zero-padded network input (6 or 9 real channels)
+        if (acc || a.ups) return hipErrorInvalidValue;
+        if (epi == EPI_NONE) return launch_h<16, EPI_NONE, false>(a, s);
+        if (epi == EPI_RELU) return launch_h<16, EPI_RELU, false>(a, s);
+        return hipErrorInvalidValue;
+    }
+    if (cin != 48) return hipErrorInvalidValue;
+    if (a.ups) {          // a.in = the map to upsample, [B][H/2][W/2][48]
+        if (acc || epi != EPI_RELU || (a.H & 1) || (a.W & 1)) return hipErrorInvalidValue;
+        return launch_h<48, EPI_RELU, false, true>(a, s);
+    }
     switch (epi) {
         case EPI_NONE:
             return acc ? launch_h<48, EPI_NONE, true>(a, s) : launch_h<48, EPI_NONE, false>(a, s);

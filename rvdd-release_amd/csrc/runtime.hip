@@ -312,22 +312,26 @@ float f16_value(uint16_t u) {
 // keeping |w'| <= 1024, returned as 2^-s), hi = f16(w') toward zero, lo = f16(w' - hi); stored
 // [chunk 14][cout block 3][hi, lo][lane = 16g + (cout & 15)][e 8] as f16 with 8-channel group G = 4 chunk + g = channels
 // 8 (G % 6) + e of tap G / 6 (groups 54, 55 zero): lane-linear 16-B A fragments of v_mfma_f32_16x16x32_f16.
-std::vector<float> arrange_conv3x3h(const HostTensor& t, int c0, float* inv_scale) {
+std::vector<float> arrange_conv3x3h(const HostTensor& t, int c0, float* inv_scale, int cin_pad = 48) {
     const int cin_total = (int)t.shape[1];
+    const int nc = cin_pad == 48 ? 48 : std::min(cin_total, 16);      // 16: the first layer, 6 or 9 real channels, zero filters beyond
+    const int gpt = cin_pad / 8, ng = 9 * gpt, nch = (ng + 3) / 4;
     float mx = 0.f;
     for (int co = 0; co < 48; ++co)
-        for (int c = 0; c < 48; ++c)
+        for (int c = 0; c < nc; ++c)
             for (int k = 0; k < 9; ++k) mx = std::max(mx, std::fabs(t.data[((size_t)co * cin_total + c0 + c) * 9 + k]));
     int sft = 0;
     if (mx > 0.f && std::isfinite(mx)) sft = std::min(40, std::max(-40, (int)std::floor(std::log2(1024.0 / mx))));
     const float sc = std::ldexp(1.0f, sft);
     *inv_scale = std::ldexp(1.0f, -sft);
-    const size_t halves = conv3x3h_weight_bytes(48) / 2;
+    const size_t halves = (size_t)nch * 3 * 2 * 512;
+    if (halves * 2 != conv3x3h_weight_bytes(cin_pad)) return {};
     std::vector<uint16_t> bank(halves, 0);
-    for (int G = 0; G < 54; ++G) {
-        const int j = G / 4, g = G % 4, tap = G / 6, cg = (G % 6) * 8;
+    for (int G = 0; G < ng; ++G) {
+        const int j = G / 4, g = G % 4, tap = G / gpt, cg = (G % gpt) * 8;
         for (int co = 0; co < 48; ++co)
             for (int e = 0; e < 8; ++e) {
+                if (cg + e >= nc) continue;
                 const float w = t.data[((size_t)co * cin_total + c0 + cg + e) * 9 + tap] * sc;      // exact: a power of two
                 const uint16_t hi = f16_bits(w, true);
                 const uint16_t lo = f16_bits(w - f16_value(hi), false);
@@ -511,11 +515,11 @@ const char* wino_name(int epi, bool acc) {
 }
 
 const char* conv_name_h(int epi, bool acc) {
-    static const char* names[5][2] = {{"conv3x3h_kernel<48, 0, false>", "conv3x3h_kernel<48, 0, true>"},
-                                      {"conv3x3h_kernel<48, 1, false>", "conv3x3h_kernel<48, 1, true>"},
-                                      {"conv3x3h_kernel<48, 2, false>", "conv3x3h_kernel<48, 2, true>"},
-                                      {"conv3x3h_kernel<48, 3, false>", "conv3x3h_kernel<48, 3, true>"},
-                                      {"conv3x3h_kernel<48, 4, false>", "conv3x3h_kernel<48, 4, true>"}};
+    static const char* names[5][2] = {{"conv3x3h_kernel<48, 0, false, false>", "conv3x3h_kernel<48, 0, true, false>"},
+                                      {"conv3x3h_kernel<48, 1, false, false>", "conv3x3h_kernel<48, 1, true, false>"},
+                                      {"conv3x3h_kernel<48, 2, false, false>", "conv3x3h_kernel<48, 2, true, false>"},
+                                      {"conv3x3h_kernel<48, 3, false, false>", "conv3x3h_kernel<48, 3, true, false>"},
+                                      {"conv3x3h_kernel<48, 4, false, false>", "conv3x3h_kernel<48, 4, true, false>"}};
     return names[epi][acc];
 }
 
@@ -595,15 +599,16 @@ int run_conv(rvdd_t* h, const Conv3& L, const ConvCall& c, hipStream_t s, Sub su
     a.out3_nchw = c.out3_nchw ? c.out3_nchw + px_in * 3 : nullptr;
     a.out3_nhwc4 = c.out3_nhwc4 ? c.out3_nhwc4 + px_in * 4 : nullptr;
     const bool c16_ok = cin != 48 && !c.acc_in && (c.epi == EPI_NONE || c.epi == EPI_RELU);
-    if (c.ups && !(cin == 48 && L.wu[c.src] && wino_applies(h, c.H, c.W)))
-        return fail(h, RVDD_ERR_STATE, "run_conv: the fused upsample exists in the Winograd kernel only");
+    if (c.ups && !(cin == 48 && ((h->split16 && L.wh[c.src]) || (L.wu[c.src] && wino_applies(h, c.H, c.W)))))
+        return fail(h, RVDD_ERR_STATE, "run_conv: the fused upsample exists in the split-f16 and the Winograd kernels only");
     if (c.ups) bytes -= px * 4.0 * 36.0;          // reads the quarter-size map
-    // the F16 matrix pipe with split operands: every 48-channel layer but UpConv's fused upsample
-    if (h->split16 && cin == 48 && !c.ups && L.wh[c.src]) {
+    // the F16 matrix pipe with split operands: every layer of the convunet
+    if (h->split16 && L.wh[c.src] && (cin == 48 || c16_ok)) {
         a.w = L.wh[c.src];
         a.wscale = L.wh_inv[c.src];
-        Scope sc(h, s, conv_name_h(c.epi, c.acc_in != nullptr), flops, bytes);
-        HIPCHK(h, launch_conv3x3h(a, 48, c.epi, s));
+        Scope sc(h, s, c.ups ? "conv3x3h_kernel<48, 1, false, true>" : cin == 48 ? conv_name_h(c.epi, c.acc_in != nullptr)
+                           : (c.epi == EPI_NONE ? "conv3x3h_kernel<16, 0, false, false>" : "conv3x3h_kernel<16, 1, false, false>"), flops, bytes);
+        HIPCHK(h, launch_conv3x3h(a, cin == 48 ? 48 : 16, c.epi, s));
         return RVDD_OK;
     }
     // F(4x4,3x3): plain and two-pass 48 -> 48 layers with enough 64x16-pixel units for every one of the 80 unit sequences
@@ -710,7 +715,7 @@ int run_convunet(rvdd_t* h, const float* netin, const float* featw, float* feat_
             const size_t lo_px = (size_t)sb.b0 * lv[lo].H * lv[lo].W, hi_px = (size_t)sb.b0 * lv[hi].H * lv[hi].W;
             // UpConv: bilinear x2, conv, ReLU (:137-142).  Where the Winograd kernel runs the conv, the interpolation
             // happens in its patch load and the upsampled map is never written; elsewhere it is made first.
-            const bool fused = h->fuse_upsample && wino_applies(h, uh, uw);
+            const bool fused = h->fuse_upsample && (h->split16 || wino_applies(h, uh, uw));
             if (!fused) {
                 Scope sc(h, s, "upsample2x_kernel", 0.0, (double)sb.nb * uh * uw * 192.0 * 1.25);
                 HIPCHK(h, launch_upsample2x(d + lo_px * kF, lv[hi].t[0] + (size_t)sb.b0 * uh * uw * kF, sb.nb, lv[lo].H, lv[lo].W, uh,
@@ -966,7 +971,7 @@ int rvdd_finalize_weights(rvdd_t* h) {
                 RC(upload(h, &L.w[0], arrange_conv3x3(wt, 0, cin, L.cin_pad[0])));
                 RC(upload(h, &L.wu[0], cin == 48 ? arrange_wino3x3(wt, 0) : arrange_wino3x3(wt, 0, 1)));
                 if (cin == 48) RC(upload(h, &L.w4[0], arrange_wino4x4(wt, 0)));
-                if (cin == 48) RC(upload(h, &L.wh[0], arrange_conv3x3h(wt, 0, &L.wh_inv[0])));
+                RC(upload(h, &L.wh[0], arrange_conv3x3h(wt, 0, &L.wh_inv[0], cin == 48 ? 48 : 16)));
             }
             RC(upload(h, &L.bias, h->staged.at(n + ".bias").data));
             for (int li = 0; li < CU_COUNT; ++li)

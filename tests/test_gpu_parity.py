@@ -256,11 +256,13 @@ def test_state_roundtrip_and_reset():
     assert torch.equal(o1, o1b)
 
 
+@pytest.mark.parametrize("conv", [0, 2])
 @pytest.mark.parametrize("B,H,W", [(1, 36, 52), (2, 72, 104), (1, 256, 256)])
-def test_fused_upsample_equals_upsample_then_conv(B, H, W):
-    """UpConv (networks/unet.py:88-147): the bilinear x2 upsample interpolated inside the Winograd patch load gives
-    the same bits as the upsample kernel followed by the conv (same operations in the same order), at sizes with
-    ragged tiles, clamped borders and the zero_pad_features placement."""
+def test_fused_upsample_equals_upsample_then_conv(B, H, W, conv):
+    """UpConv (networks/unet.py:88-147): the bilinear x2 upsample interpolated inside the conv kernel's input fetch
+    (the split-f16 kernel's halo fetch, conv = 0; the Winograd f32 kernel's patch load, conv = 2) gives the same bits
+    as the upsample kernel followed by the same conv kernel (same operations in the same order), at sizes with ragged
+    tiles, clamped borders and the zero_pad_features placement."""
     from rvdd_release_amd import synth
     from rvdd_release_amd.runtime import RvddRuntime
     sd = load_weights("recurrent-convunet+feat-iso3200")
@@ -268,7 +270,7 @@ def test_fused_upsample_equals_upsample_then_conv(B, H, W):
     outs = []
     for fused in (1, 0):
         rt = RvddRuntime("convunet+feat", 0, B, H, W, 0)
-        rt.set_option("conv_kernel", 2)
+        rt.set_option("conv_kernel", conv)
         rt.set_option("fuse_upsample", fused)
         rt.load_state_dict(sd)
         st = lambda f: torch.stack([f(s) for s in seqs], 0)
