@@ -66,7 +66,10 @@ EVENT_STRIDE = 3
 # 2x2 outputs where the direct form multiplies 36 times
 EXECUTED_PER_ALGORITHMIC = {"wino3x3": 16.0 / 36.0,
                             # split-f16 kernel: three F16 MFMAs (hi.hi, hi.lo, lo.hi) per product, K = 432 padded to 448
-                            "conv3x3h": 3.0 * 448.0 / 432.0}
+                            "conv3x3h": 3.0 * 448.0 / 432.0,
+                            # fused ConvBlock, split-f16 MLP: 114 F16 MFMAs (16x16x32) per 16 pixels = 116,736 flop per pixel
+                            # against 41,568 algorithmic (depth-wise 4,704 on the vector ALU + 36,864 in the two 1x1 convs)
+                            "convblock_kernel": 116736.0 / 41568.0}
 
 
 def _free_port():
@@ -97,6 +100,8 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-frames-8", type=int, default=4, help="timed frames of the second CPU sample at 8 threads (0 = skip)")
     ap.add_argument("--cpu-frames-wide", type=int, default=3,
                     help="timed frames of a third CPU sample at min(affinity, cgroup quota, 64) threads, when that exceeds 16 (0 = skip)")
+    ap.add_argument("--no-exact-ab", action="store_true",
+                    help="skip the second, untimed-region-external run on the exact-f32-product kernels (one GPU only)")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--all-kernel-events", action="store_true",
                     help="diagnostic: bracket EVERY launch of every kernel (costs ~6 %% of the frame rate); "
@@ -263,20 +268,20 @@ def main():
         del seqs
     outs = torch.empty(n_out, B, 3, H, W, dtype=torch.float32, device=dev)   # outputs of the group being advanced
 
-    def flow_from_denoised(den, raw_cur):
+    def flow_from_denoised(den, raw_cur, rt=rt):
         """validate.py:16-38 for B sequences: moving = channel mean of remosaick(previous output), target = channel mean of
         the current packed raw frame, both mapped to [0,1] (library.py:67-68, :165-167) -> TV-L1 on the device."""
         moving = ((den[:, 1, 0::2, 0::2] + den[:, 2, 0::2, 1::2]) + (den[:, 0, 1::2, 0::2] + den[:, 1, 1::2, 1::2])) * 0.125 + 0.5
         target = raw_cur.mean(dim=1) * 0.5 + 0.5
         return rt.tvl1flow_batch(target.contiguous(), moving.contiguous())
 
-    def one_step():
+    def one_step(rt=rt, outs=outs):
         for raw, fprev, fnext in inputs:
             rt.reset()                                        # FirstOfVideo
             for t in range(1, T - fut):
                 fp = fprev[t]
                 if args.online_flow and t > 1:
-                    fp = flow_from_denoised(outs[t - 2], raw[t])
+                    fp = flow_from_denoised(outs[t - 2], raw[t], rt)
                 rt.step(raw[t - 1] if t == 1 else None, raw[t], raw[t + 1] if fut else None, fp,
                         fnext[t] if fut else None, out=outs[t - 1])
 
@@ -361,7 +366,9 @@ def main():
             pass
         factor = next((f for pre, f in EXECUTED_PER_ALGORITHMIC.items() if dom.startswith(pre)), 1.0)
         executed = k["tflops"] * factor
-        split = dom.startswith("conv3x3h")
+        split = dom.startswith("conv3x3h") or (dom == "convblock_kernel" and os.environ.get("RVDD_NEXT_SPLIT") != "0")
+        if dom == "convblock_kernel" and not split:
+            factor, executed = 1.0, k["tflops"]
         peak = F16_PEAK_TFLOPS if split else FP32_PEAK_TFLOPS
         roofline = {"bound": "mfma", "kernel": dom, "achieved": round(executed, 2), "peak": peak,
                     "unit": "TFLOP/s", "frac": round(executed / peak, 4), "traffic": traffic,
@@ -369,7 +376,10 @@ def main():
                     "algorithmic_bytes_per_launch": round(k["bytes_per_launch"]),
                     "mfma_dtype": "f16 (f32 operands split hi + lo, f32 accumulation)" if split else "f32",
                     "hbm_gbps_algorithmic": round(k["gbps"], 1),
-                    "what_is_counted": "F16 MFMA flops the kernel executes: 3 MFMAs per product (hi.hi, hi.lo, lo.hi), K 432 padded to 448"
+                    "what_is_counted": ("F16 MFMA flops the kernel executes in its two 1x1 convs (114 MFMAs per 16 pixels; the depth-wise 7x7, "
+                                        "LayerNorm and GELU run on the vector ALU and bound the kernel: DESIGN.md 4.3c)")
+                                       if split and dom == "convblock_kernel" else
+                                       "F16 MFMA flops the kernel executes: 3 MFMAs per product (hi.hi, hi.lo, lo.hi), K 432 padded to 448"
                                        if split else
                                        "MFMA flops the kernel executes (Winograd F(2x2,3x3): 16/36 of the direct conv's)"
                                        if factor != 1.0 else "the kernel's algorithmic flops (all executed on MFMA)",
@@ -377,6 +387,28 @@ def main():
                     "launches": k["launches"], "avg_launch_us": round(k["avg_us"], 2),
                     "events": "every launch" if args.all_kernel_events else
                               f"every {EVENT_STRIDE}rd launch (uniform over the launches of a frame-step)"}
+
+    # ---- the same workload on the kernels that multiply f32 operands directly (f32 MFMA): what the split-f16 matrix path
+    # buys, and how far apart the two paths' frames are.  One GPU only, outside the timed region.
+    exact = None
+    if world == 1 and not stub and not args.no_exact_ab and not args.online_flow:
+        rt2 = RvddRuntime(arch, fut, B, H, W, dev_index)
+        rt2.set_option("next_split" if arch.startswith("next") else "conv_kernel", 0 if arch.startswith("next") else 4)
+        rt2.load_state_dict(sd)
+        outs2 = torch.empty_like(outs)
+        one_step(rt2, outs2)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        one_step(rt2, outs2)
+        torch.cuda.synchronize()
+        el2 = time.perf_counter() - t2
+        d = (outs2 - outs).abs()
+        exact = {"value": round(n_out * len(my_seqs) / el2, 3), "unit": "frames/s", "steps": 1,
+                 "kernels": "RVDD_NEXT_SPLIT=0 (f32-MFMA 1x1 convs)" if arch.startswith("next") else "RVDD_CONV=f32 (f32-MFMA Winograd / direct 3x3 convs)",
+                 "max_abs_diff_vs_default": float(d.max()), "mean_abs_diff_vs_default": float(d.mean()),
+                 "what": "every output frame of the last group of sequences, default (split-f16 matrix path) against exact-f32 products"}
+        rt2.close()
+        del outs2, d
 
     # ---- CPU baseline: the oracle on this host's cores, bounded sample, sequence 0
     cpu = None
@@ -456,7 +488,11 @@ def main():
         "arithmetic": ("f32 in, f32 out, f32 accumulation; the convunet's 48-channel 3x3 convs multiply on the F16 matrix pipe with "
                        "every f32 operand split into two f16 halves (3 MFMAs per product): as close to the reference as the "
                        "f32-MFMA kernels (tests/split_precision_study.py, DESIGN.md 4.1c); RVDD_CONV=f32 runs those instead")
-                      if (not arch.startswith("next") and _CONV.startswith("conv3x3h")) else "f32 throughout (f32 MFMA, f32 VALU)",
+                      if (not arch.startswith("next") and _CONV.startswith("conv3x3h")) else
+                      ("f32 in, f32 out, f32 accumulation; the ConvBlock's two 1x1 convs multiply on the F16 matrix pipe with every f32 "
+                       "operand split into two f16 halves (DESIGN.md 4.3c); RVDD_NEXT_SPLIT=0 runs the f32-MFMA form")
+                      if (arch.startswith("next") and os.environ.get("RVDD_NEXT_SPLIT") != "0" and os.environ.get("RVDD_NEXT_FUSED") != "0")
+                      else "f32 throughout (f32 MFMA, f32 VALU)",
         "config": {"workload": f"{config}: {DESCR[config]}" + (f" (run with --frames {T})" if args.frames else ""),
                    "arch": arch, "checkpoint": stem,
                    "frame": f"{W}x{H}", "frames_per_sequence": T, "sequences_per_gpu": len(my_seqs),
@@ -467,7 +503,7 @@ def main():
         "algorithmic_gflop_per_frame": gflop_frame,
         "whole_path_algorithmic_tflops": round(fps / world * gflop_frame / 1e3, 2),
         "task_psnr_db": round(psnr_mean, 3),
-        "roofline": roofline, "cpu_baseline": cpu, "collate": collate, "kernels": kernels,
+        "roofline": roofline, "cpu_baseline": cpu, "exact_f32_kernels": exact, "collate": collate, "kernels": kernels,
     }
     if cpu:
         line["gpu_over_cpu"] = round(fps / cpu["value"], 1)

@@ -261,6 +261,17 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3h_kernel(ConvArgs a) {
     asm volatile("" : "+v"(abase[0]), "+v"(abase[1]));
     h8 Af[2][3][2], Bf[2][2][2];
     auto read_frags = [&](int buf, int j) {
+#ifdef RVDD_EXP_NO_B
+        if (j < 2)       // experiment: pixel fragments read for the first two chunks only
+#endif
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int hl = 0; hl < 2; ++hl)
+                Bf[buf][nt][hl] = __builtin_bit_cast(h8, *(lds_f4*)(L + boff[j] + nt * IW * G::S + hl * G::HI));
+#ifdef RVDD_EXP_NO_A
+        if (j < 2)       // experiment (tools/conv3x3h_bench.hip): filter fragments read for the first two chunks only
+#endif
 #pragma unroll
         for (int mt = 0; mt < 3; ++mt)
 #pragma unroll
@@ -268,11 +279,6 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3h_kernel(ConvArgs a) {
                 const int jj = j < G::A_SPLIT ? j : j - G::A_SPLIT;
                 Af[buf][mt][hl] = __builtin_bit_cast(h8, *(lds_f4*)(L + abase[j < G::A_SPLIT ? 0 : 1] + ((jj * 3 + mt) * 2 + hl) * 1024));
             }
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-            for (int hl = 0; hl < 2; ++hl)
-                Bf[buf][nt][hl] = __builtin_bit_cast(h8, *(lds_f4*)(L + boff[j] + nt * IW * G::S + hl * G::HI));
     };
 
     const unsigned map_bytes = (unsigned)(a.H * a.W * kF * 4);

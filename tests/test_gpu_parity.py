@@ -807,6 +807,42 @@ def test_convblock_one_kernel_equals_two_kernels(arch, stem, fut):
             assert (outs[0][1] - outs[1][1]).abs().max() < 1e-5, (B, H, W)
 
 
+@pytest.mark.parametrize("arch,stem,fut,opt", [
+    ("convunet+feat", "recurrent-convunet+feat-iso3200", 0, ("conv_kernel", 4)),
+    ("convunet", "recurrent-convunet-future-iso3200", 1, ("conv_kernel", 2)),
+    ("next+feat", "recurrent-ConvNeXtUnet+feat-future-iso3200", 1, ("next_split", 0)),
+])
+def test_split_f16_matrix_path_matches_f32_kernels(arch, stem, fut, opt):
+    """The default path multiplies its dense convs on the F16 matrix pipe with every f32 operand split into two f16
+    halves (three MFMAs per product, f32 accumulation: conv3x3h.hip, convnext.hip SPLIT); the option selects the
+    kernels that multiply f32 operands on the f32 matrix pipe.  Same frames to fp32 rounding noise -- max-abs < 2e-5,
+    parity PSNR > 120 dB -- over four recurrent steps at sizes with ragged tiles and zero-padded levels, batches."""
+    from rvdd_release_amd import synth
+    from rvdd_release_amd.runtime import RvddRuntime
+    if arch.startswith("next") and "next-iso3200" not in BUILT:
+        pytest.skip("ConvNeXt path not built")
+    sd = load_weights(stem)
+    for B, H, W in ((2, 72, 104), (1, 180, 320), (3, 50, 66)):
+        T = 5 + fut
+        seqs = [synth.make_sequence(T, H, W, iso=3200, seed=700 + b, device="cuda") for b in range(B)]
+        st = lambda f: torch.stack([f(s) for s in seqs], 0)
+        outs = []
+        for exact in (0, 1):
+            rt = RvddRuntime(arch, fut, B, H, W, 0)
+            if exact:
+                rt.set_option(*opt)
+            rt.load_state_dict(sd)
+            o = []
+            for t in range(1, T - fut):
+                o.append(rt.step(st(lambda s: s.raw[t - 1]) if t == 1 else None, st(lambda s: s.raw[t]),
+                                 st(lambda s: s.raw[t + 1]) if fut else None, st(lambda s: s.flow_prev[t]),
+                                 st(lambda s: s.flow_next[t]) if fut else None).clone())
+            outs.append(o)
+            rt.close()
+        for a, b in zip(*outs):
+            assert (a - b).abs().max() < 2e-5 and parity_psnr(a.cpu(), b.cpu()) > 120.0, (B, H, W, float((a - b).abs().max()))
+
+
 def test_pooling_epilogue_equals_maxpool_kernel():
     """MaxPool2d(2) in front of each DownConv (networks/new_unet.py:200-204) written from the epilogue of the fused
     ConvBlock ahead of it (the default) against the separate pooling kernel (option next_pool = 0): a maximum has no

@@ -29,8 +29,8 @@ for k in sorted(f):
     name = name.split("(")[0].replace(", 0>", ">") if "conv3x3" in name else name.split("(")[0]
     if name.startswith("mlp_kernel"):
         name = "mlp_kernel"                      # one instantiation; bench.py looks it up by its plain name
-    if name == "convblock_kernel<false>":
-        name = "convblock_kernel"                # the 24 plain blocks of a frame-step (<true> = the last one, with the 1x1 conv)
+    if name.startswith("convblock_kernel<false, false"):
+        name = "convblock_kernel"                # the plain blocks of a frame-step (<false, true, .> also pool, <true, ..> = the last one, with the 1x1 conv)
     fm = sum(f[k]) / len(f[k])
     wm = sum(w[k]) / len(w[k]) if k in w else 0.0
     out[name] = {"launches": len(f[k]), "FETCH_SIZE_KiB_avg": round(fm, 1), "WRITE_SIZE_KiB_avg": round(wm, 1),
