@@ -312,41 +312,49 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3h_kernel(ConvArgs a) {
         STAMP(0);
         __syncthreads();       // tile t is staged
         STAMP(1);
-        locate(t + t_step, nxt);
-        const Src qn = source(nxt, t + t_step < t_end);
+        // The first chunk's MFMAs go out at once; the tile's address work (next tile's position, this tile's store and
+        // side-load offsets) follows them and runs under them, and everything that needs it starts at chunk SH.
+        constexpr int SH = G::NCH >= 12 ? 1 : 0;
+        Src qn;
         const int yy0 = cur.y0 + 2 * wave, xx = cur.x0 + n;
         unsigned po[2], so[2];
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
-            const bool ok = yy0 + nt < a.H && xx < a.W;
-            po[nt] = ok ? (unsigned)((((yy0 + nt) * a.W + xx) * kF + 4 * g) * 4) : 0x80000000u;
-            so[nt] = ok ? (unsigned)((((yy0 + nt + a.oy) * a.Wout + xx + a.ox) * kF + 4 * g) * 4) : 0x80000000u;
-        }
-        if constexpr (EPI == EPI_POOL) {
-            const int pr_ = (cur.y0 >> 1) + wave, pc = xx >> 1;
-            const bool ok = !(n & 1) && pr_ < a.Hout && pc < a.Wout;
-            so[0] = ok ? (unsigned)(((pr_ * a.Wout + pc) * kF + 4 * g) * 4) : 0x80000000u;
-        }
         f32x4 side[2][3];
-        __amdgpu_buffer_rsrc_t pr = __builtin_amdgcn_make_buffer_rsrc(
-            (void*)((ACC_IN ? a.acc_in : a.out) + (size_t)cur.b * a.H * a.W * kF), 0, map_bytes, 0x00020000);
+        __amdgpu_buffer_rsrc_t pr;
+        auto addresses = [&]() {
+            locate(t + t_step, nxt);
+            qn = source(nxt, t + t_step < t_end);
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                const bool ok = yy0 + nt < a.H && xx < a.W;
+                po[nt] = ok ? (unsigned)((((yy0 + nt) * a.W + xx) * kF + 4 * g) * 4) : 0x80000000u;
+                so[nt] = ok ? (unsigned)((((yy0 + nt + a.oy) * a.Wout + xx + a.ox) * kF + 4 * g) * 4) : 0x80000000u;
+            }
+            if constexpr (EPI == EPI_POOL) {
+                const int pr_ = (cur.y0 >> 1) + wave, pc = xx >> 1;
+                const bool ok = !(n & 1) && pr_ < a.Hout && pc < a.Wout;
+                so[0] = ok ? (unsigned)(((pr_ * a.Wout + pc) * kF + 4 * g) * 4) : 0x80000000u;
+            }
+            pr = __builtin_amdgcn_make_buffer_rsrc((void*)((ACC_IN ? a.acc_in : a.out) + (size_t)cur.b * a.H * a.W * kF), 0, map_bytes,
+                                                   0x00020000);
+        };
         STAMP(2);
 
         // ---- 14 chunks x 18 MFMAs, and between the chunks: a store of the last tile, a side load of this one, a halo
-        // load of the next one (chunks 0..8), the split of what those loads brought (the last three chunks)
+        // load of the next one (nine chunks from SH on), the split of what those loads brought (the last three chunks)
         f32x4 acc[2][3];
         read_frags(0, 0);
 #pragma unroll
         for (int j = 0; j < G::NCH; ++j) {
             const int cb = j & 1;
             if (j + 1 < G::NCH) read_frags(cb ^ 1, j + 1);
-            if (j < NOUT) bstore(orr_prev, so_prev[EPI == EPI_POOL ? 0 : j / 3] + 64 * (j % 3), outv[j]);
+            if (j == SH) addresses();
+            if (j >= SH && j - SH < NOUT) bstore(orr_prev, so_prev[EPI == EPI_POOL ? 0 : (j - SH) / 3] + 64 * ((j - SH) % 3), outv[j - SH]);
             if constexpr (ACC_IN) {
-                if (j < 6) side[j / 3][j % 3] = bload(pr, po[j / 3], 64 * (j % 3));
+                if (j >= SH && j - SH < 6) side[(j - SH) / 3][(j - SH) % 3] = bload(pr, po[(j - SH) / 3], 64 * ((j - SH) % 3));
             }
-            if (j < G::NR) fetch_round(qn, j);
+            if (j >= SH && j - SH < G::NR) fetch_round(qn, j - SH);
             if constexpr (UPS) {
-                if (j >= 2 && j - 2 < G::NR) interp_round(qn, j - 2);      // two chunks after its loads were issued
+                if (j >= SH + 2 && j - SH - 2 < G::NR) interp_round(qn, j - SH - 2);      // two chunks after its loads were issued
             }
 #pragma unroll
             for (int r0 = 0; r0 < G::NR; ++r0)
@@ -369,7 +377,7 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3h_kernel(ConvArgs a) {
             __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
-        for (int j = G::NCH; j < NOUT; ++j) bstore(orr_prev, so_prev[EPI == EPI_POOL ? 0 : j / 3] + 64 * (j % 3), outv[j]);      // CIN 16: five chunks
+        for (int j = G::NCH - SH; j < NOUT; ++j) bstore(orr_prev, so_prev[EPI == EPI_POOL ? 0 : j / 3] + 64 * (j % 3), outv[j]);      // CIN 16: five chunks
         STAMP(3);
 
         // ---- epilogue: scale back, bias / partial sums, activation; the 48-channel results wait in registers for the

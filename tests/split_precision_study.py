@@ -15,6 +15,8 @@ against the REFERENCE's stored frames and per-frame PSNR.  Schemes:
     bf16x3p6   x = h + m + l in bf16, products of order <= 2 (hh hm mh mm hl lh)
     bf16x3p3   hh hm mh only (16 bits)
     bf16x2p3   x = h + l in bf16, hh hl lh
+    wino-...   the 3x3 convs as Winograd F(2x2,3x3) with the element-wise products on split operands (the transformed
+               patches and filters are what is split)
 
 Also prints the largest |operand| any dense conv saw (f16 overflows at 65504).
 """
@@ -68,14 +70,44 @@ SCHEMES = {
 }
 
 
+def winograd_split_conv(x, w, b, split, terms):
+    """3x3 conv, padding 1, as Winograd F(2x2,3x3) whose element-wise products run on split operands: V = B^T d B and
+    U = G g G^T in f32 (as a kernel would form them), both split, the channel sums of the kept partial products in
+    float64, Y = A^T M A in f32."""
+    Bn, C, H, W = x.shape
+    Hp, Wp = H + (H & 1), W + (W & 1)
+    xp = F.pad(x, (1, 1 + Wp - W, 1, 1 + Hp - H))
+    pt = xp.unfold(2, 4, 2).unfold(3, 4, 2)                       # [B, C, th, tw, 4, 4]
+    BT = torch.tensor([[1, 0, -1, 0], [0, 1, 1, 0], [0, -1, 1, 0], [0, 1, 0, -1]], dtype=torch.float32)
+    G = torch.tensor([[1, 0, 0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0, 0, 1]], dtype=torch.float64)
+    AT = torch.tensor([[1, 1, 1, 0], [0, 1, -1, -1]], dtype=torch.float32)
+    V = torch.einsum("ij,bctujk,lk->bctuil", BT, pt, BT)          # f32 adds only: exact order does not matter much here
+    U = torch.einsum("ij,ocjk,lk->ocil", G, w.double(), G).float()
+    Vs, Us = split(V), split(U)
+    M = None
+    for i, j in terms:
+        t = torch.einsum("bctuil,ocil->botuil", Vs[i], Us[j])
+        M = t if M is None else M + t
+    M = M.float()
+    Y = torch.einsum("ij,botujk,lk->botuil", AT, M, AT)           # [B, O, th, tw, 2, 2]
+    th, tw = Y.shape[2], Y.shape[3]
+    y = Y.permute(0, 1, 2, 4, 3, 5).reshape(Bn, w.shape[0], 2 * th, 2 * tw)[:, :, :H, :W]
+    if b is not None:
+        y = y + b.view(1, -1, 1, 1)
+    return y.contiguous()
+
+
 def make_conv(scheme, only=None):
-    split, terms = SCHEMES[scheme]
+    wino = scheme.startswith("wino-")
+    split, terms = SCHEMES[scheme[5:] if wino else scheme]
 
     def conv(x, w, b=None, stride=1, padding=0, dilation=1, groups=1):
         if groups != 1 or (only == "3x3" and w.shape[-1] != 3) or (only == "1x1" and w.shape[-1] != 1):
             return REAL(x, w, b, stride, padding, dilation, groups)
         STATS["max_x"] = max(STATS["max_x"], float(x.abs().max()))
         STATS["max_w"] = max(STATS["max_w"], float(w.abs().max()))
+        if wino and w.shape[-1] == 3 and padding == 1 and w.shape[1] >= 16:
+            return winograd_split_conv(x, w, b, split, terms)
         xs, ws = split(x), split(w)
         acc = None
         for i, j in terms:
@@ -108,7 +140,7 @@ def main():
     torch.set_num_threads(8)
     print(f"{'fixture':34s} {'scheme':9s} {'max|out-ref|':>13s} {'max dPSNR dB':>13s} {'max|feat-ref|':>14s}")
     for name in names:
-        for scheme in ["f32"] + sorted(SCHEMES):
+        for scheme in ["f32"] + sorted(SCHEMES) + ["wino-f16x2p3", "wino-f16x2p4"]:
             worst, dps, feat = run(name, scheme)
             print(f"{name:34s} {scheme:9s} {worst:13.3e} {dps:13.2e} {feat:14.3e}", flush=True)
     print(f"largest |activation| into a dense conv {STATS['max_x']:.3f}, largest |weight| {STATS['max_w']:.3f}")
