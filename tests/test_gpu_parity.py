@@ -843,6 +843,33 @@ def test_split_f16_matrix_path_matches_f32_kernels(arch, stem, fut, opt):
             assert (a - b).abs().max() < 2e-5 and parity_psnr(a.cpu(), b.cpu()) > 120.0, (B, H, W, float((a - b).abs().max()))
 
 
+def test_split_path_outside_its_domain_stays_finite():
+    """The split-f16 matrix path needs |activation| < 65504 (include/rvdd.h, "conv_kernel").  Frames a hundred thousand
+    times brighter than the [-1, 1] the reference feeds push the first layers past that: the round-toward-zero split
+    saturates, so the default path returns finite (wrong) frames, never NaN or infinity, and the f32-MFMA kernels
+    (conv_kernel 4) return the exact products' frames, as the header says."""
+    from rvdd_release_amd import synth
+    from rvdd_release_amd.runtime import RvddRuntime
+    sd = load_weights("recurrent-convunet+feat-iso3200")
+    s = synth.make_sequence(3, 64, 96, iso=3200, seed=5, device="cuda")
+    big = 1.0e5
+    outs = {}
+    for conv in (0, 4):
+        rt = RvddRuntime("convunet+feat", 0, 1, 64, 96, 0)
+        rt.set_option("conv_kernel", conv)
+        rt.load_state_dict(sd)
+        o = rt.step((s.raw[0] * big)[None], (s.raw[1] * big)[None], None, s.flow_prev[1][None], None).clone()
+        outs[conv] = o
+        rt.close()
+        assert torch.isfinite(o).all(), conv
+    want = O.RecurrentOracle(sd, future=0).step((s.raw[0] * big).cpu()[None], (s.raw[1] * big).cpu()[None], None,
+                                                 s.flow_prev[1].cpu()[None], None, first=True)
+    scale = float(want.abs().max())
+    assert (outs[4].cpu() - want).abs().max() < 1e-4 * scale          # exact products: right at any magnitude
+    # ... and the case IS outside the split path's domain (activations of ~1e6 inside the net): its frames are off
+    assert (outs[0].cpu() - want).abs().max() > 1e-3 * scale
+
+
 def test_pooling_epilogue_equals_maxpool_kernel():
     """MaxPool2d(2) in front of each DownConv (networks/new_unet.py:200-204) written from the epilogue of the fused
     ConvBlock ahead of it (the default) against the separate pooling kernel (option next_pool = 0): a maximum has no
