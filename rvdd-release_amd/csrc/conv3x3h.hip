@@ -139,8 +139,8 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3h_kernel(ConvArgs a) {
         if (tid >= 64 && tid < 64 + 3 * kF) Pl[kF + tid - 64] = a.w3[tid - 64];
         else if (tid >= 256 && tid < 259) Pl[4 * kF + tid - 256] = a.b3[tid - 256];
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    // (no wait here: the bank's DMA runs beside the first tile's halo fetch; both are awaited in front of the tile loop,
+    // whose first barrier publishes bank, parameters and tile together)
 
     // ---- tiles of this workgroup: the workgroups of one XCD (blockIdx & 7) share a contiguous eighth of the tile list,
     // walked side by side, so that the halo columns two neighbours both read meet in that XCD's L2
@@ -297,6 +297,7 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3h_kernel(ConvArgs a) {
 #pragma unroll
         for (int r0 = 0; r0 < G::NR; ++r0) split4(pre[r0], shi[r0], slo[r0]);
         write_tile();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's pieces of the filter bank have landed
     }
     // results of the tile before, stored one 16-B piece per chunk inside the current tile's MFMA loop (before the first
     // tile: out-of-range offsets, the stores are dropped)
