@@ -20,8 +20,10 @@
 //
 // Work: a persistent workgroup of 8 waves per CU walks 16x16-pixel tiles.  The 18x18 halo tile is fetched as f32 into
 // registers one tile ahead (buffer loads, out-of-image pixels zero-filled by out-of-range offsets = padding 1), split
-// ONCE per element and written to LDS as [pixel][hi 48 f16 | lo 48 f16 | 32 B pad] (224 B per pixel, an odd multiple of
-// 32: every B fragment read of the kernel is bank-conflict free, tools/lds_b128_bench.hip).  The split filter bank (14 chunks x 3 cout blocks x {hi, lo} x 1 KiB
+// ONCE per element and written to LDS as two planes, [pixel][hi 48 f16] and [pixel][lo 48 f16] (96 B per pixel, an odd
+// multiple of 32: every B fragment read of the kernel is bank-conflict free, tools/lds_b128_bench.hip).  The staging
+// stores between a tile's two barriers run at the LDS write port's ~60 B per clock whatever their width or pattern
+// (8-byte, 16-byte after a lane exchange, conflict-free or not: 0.75-1.3 k cycles per tile).  The split filter bank (14 chunks x 3 cout blocks x {hi, lo} x 1 KiB
 // lane-linear A fragments = 84 KiB) is DMA'd to LDS once per workgroup.  Wave w owns tile rows 2w, 2w+1 (two B
 // fragments per chunk) and all 48 couts (three A fragments): per chunk 6 + 4 ds_read_b128 (hi and lo) feed 18 MFMAs on
 // six accumulators, the fragments of the next chunk being read while the current one is multiplied.
@@ -47,10 +49,13 @@ struct HGeo {
     static constexpr int NG = 9 * GPT;                       // groups of the whole filter
     static constexpr int NCH = (NG + 3) / 4;                 // K chunks of 32 (one MFMA deep)
     static constexpr int HI = CIN * 2;                       // bytes of one pixel's hi half
-    static constexpr int S = 2 * HI + 32;                    // LDS bytes per pixel: an odd multiple of 32 (tools/lds_b128_bench.hip:
-                                                             // every fragment pattern of the kernel conflict-free; 208 = 13 x 16 is 2-way)
+    static constexpr int S = HI;                             // LDS bytes per pixel in EACH of the two planes (hi, lo): 96 / 32, an odd multiple of
+                                                             // 32 -- every fragment pattern of the kernel is conflict-free
+                                                             // (tools/lds_b128_bench.hip; 192 or 208 are 2-way), and 10 KiB less than one
+                                                             // interleaved [hi | lo | pad] image of 224 B per pixel
+    static constexpr int PLANE = IH * IW * HI;
     static constexpr int W_BYTES = NCH * 3 * 2 * 1024;
-    static constexpr int I_BYTES = IH * IW * S;
+    static constexpr int I_BYTES = 2 * PLANE;
     static constexpr int P_FLOATS = 48 + 3 * 48 + 4;         // bias, PostConvs[1] weights and bias
     static constexpr int LDS_BYTES = W_BYTES + I_BYTES + P_FLOATS * 4;
     static constexpr int SEG = CIN / 4;                      // 16-B pieces of one f32 pixel
@@ -242,7 +247,7 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3h_kernel(ConvArgs a) {
         for (int r0 = 0; r0 < G::NR; ++r0)
             if (ld_thread && G::RPR * r0 + rp < IH) {
                 *(lds_u2*)(L + l_lane + r0 * G::RPR * IW * G::S) = shi[r0];
-                *(lds_u2*)(L + l_lane + r0 * G::RPR * IW * G::S + G::HI) = slo[r0];
+                *(lds_u2*)(L + l_lane + r0 * G::RPR * IW * G::S + G::PLANE) = slo[r0];
             }
     };
 
@@ -268,7 +273,7 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3h_kernel(ConvArgs a) {
         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
             for (int hl = 0; hl < 2; ++hl)
-                Bf[buf][nt][hl] = __builtin_bit_cast(h8, *(lds_f4*)(L + boff[j] + nt * IW * G::S + hl * G::HI));
+                Bf[buf][nt][hl] = __builtin_bit_cast(h8, *(lds_f4*)(L + boff[j] + nt * IW * G::S + hl * G::PLANE));
 #ifdef RVDD_EXP_NO_A
         if (j < 2)       // experiment (tools/conv3x3h_bench.hip): filter fragments read for the first two chunks only
 #endif

@@ -46,7 +46,7 @@ int main() {
     hipFuncSetAttribute(reinterpret_cast<const void*>(bench), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     struct P { int sn, o[4]; const char* what; };
     std::vector<P> pats = {{16, {0, 256, 512, 768}, "lane-linear (A fragments)"}};
-    for (int S : {192, 208, 224, 240, 256, 272, 288}) {
+    for (int S : {96, 160, 192, 208, 224, 240, 256, 272, 288}) {
         pats.push_back({S, {0, 16, 32, 48}, "groups 0-3 of one tap"});
         pats.push_back({S, {32, 48, 64, 80}, "groups 2-5 of one tap"});
         pats.push_back({S, {64, 80, S, S + 16}, "groups 4,5 of a tap and 0,1 of the next pixel"});
