@@ -199,6 +199,10 @@ int rvdd_srgb_metrics(rvdd_t* h, const uint8_t* a, const uint8_t* b, int32_t n, 
  *               then the MLP) instead of the one fused kernel: the A/B reference; same results to a few ulp.
  *   "next_split": 0 = the fused ConvBlock multiplies its two 1x1 convs on the f32 matrix pipe (exact-f32 products) instead
  *               of the F16 pipe with split f32 operands (the default, as "conv_kernel" 0; the A/B reference).
+ *   "next_pipe": 0 = the fused ConvBlock runs its three phases one after the other in all eight waves of a workgroup
+ *               (convblock_kernel) instead of as a pipeline over tiles -- depth-wise conv and LayerNorm of the next tile on
+ *               four waves beside the MLP of the current one on the other four (convblock_pipe_kernel, the default with
+ *               next_split; same bits either way).
  *   "next_pool": 0 = with next_fused, MaxPool2d(2) in front of a DownConv (new_unet.py:200-204) as its own kernel instead
  *               of the fused block's epilogue (default 1; same bits either way).
  *   "wino4":    1 / 2 = the plain and two-pass 48 -> 48 3x3 convs on the Winograd F(4x4,3x3) kernel where a launch has

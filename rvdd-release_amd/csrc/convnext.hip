@@ -1057,6 +1057,426 @@ __global__ __launch_bounds__(512, 2) void convblock_kernel(const float* __restri
 #endif
 }
 
+// convblock_pipe_kernel: convblock_kernel<.., SPLIT = true> as a two-stage pipeline over tiles (option next_pipe).
+// Per-wave stamps of convblock_kernel: waves 4-7 idle through the depth-wise phase and the
+// LayerNorm, then both waves of a SIMD share its vector port through the MLP phase.  Here waves 0-3 ("front", one per
+// SIMD) run the depth-wise taps and the LayerNorm of tile t+1 while waves 4-7 ("back", one per SIMD) run the MLP of tile
+// t -- all 16 rows, four 16-pixel groups per wave.  Same LDS plan, same arithmetic in the same order per pixel, same bits.
+//   * hand-over: the front writes the LayerNorm result into the exchange (the halo buffers, dead by then), workgroup
+//     barrier A; the back reads its 12 fragments into registers, workgroup barrier B; the buffers are free again and the
+//     front requests the first two halo chunks of the next tile.  Two s_barrier per tile for every wave.
+//   * the halo chunks are requested and awaited by the front waves alone; "all four front waves are past this point" is
+//     an LDS counter each of them adds one to and polls (fsync), since s_barrier counts all eight.
+template <bool OUT3, bool POOL>
+__global__ __launch_bounds__(512, 2) void convblock_pipe_kernel(const float* __restrict__ x, NextBlockW wt, float* __restrict__ out,
+                                                               int B, int H, int W, int tiles_x, int tiles_y, int ntiles, Out3 o3,
+                                                               float* __restrict__ pool) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int SH = F_SPLIT_SHIFT;
+    float* W1 = smem;
+    float* W2 = smem + F_W1H_BYTES / 4;
+    float* BV = smem + F_OFF_BV + SH;
+    float* Wl = smem + F_OFF_DW + SH;       // [49][48]
+    float* Pl = smem + F_OFF_PAR + SH;      // dw_b | ln_w | ln_b
+    float* Tl = smem + F_OFF_T + SH;        // two chunk buffers; the LayerNorm exchange between the stages
+    unsigned* Fs = reinterpret_cast<unsigned*>(smem + F_OFF_T + SH + 2 * E_BUF_FLOATS);       // the front's counter
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool front = wave < 4;
+
+    const int per_xcd = (ntiles + 7) >> 3;
+    const int band_end = min(((int)(blockIdx.x & 7) + 1) * per_xcd, ntiles);
+    const int stride = (int)(gridDim.x >> 3);
+    int tile = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+    if (tile >= band_end) return;
+    const int tiles_per_img = tiles_x * tiles_y;
+    struct TilePos { int b, y0, x0; };
+    auto locate = [&](int t) {
+        TilePos p;
+        p.b = t / tiles_per_img;
+        const int rr = t - p.b * tiles_per_img;
+        const int ty = rr / tiles_x;
+        p.y0 = ty * E_TH;
+        p.x0 = (rr - ty * tiles_x) * E_TW;
+        return p;
+    };
+
+    {   // weights of the block -> LDS, once per workgroup (all eight waves)
+        __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc((void*)wt.fc1_h, 0, F_W1H_BYTES, 0x00020000);
+        __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc((void*)wt.fc2_h, 0, F_W2H_BYTES, 0x00020000);
+        for (int k = wave; k < F_W1H_BYTES / 1024; k += 8) dma16(r1, W1 + k * 256, (unsigned)(k * 1024 + lane * 16));
+        for (int k = wave; k < F_W2H_BYTES / 1024; k += 8) dma16(r2, W2 + k * 256, (unsigned)(k * 1024 + lane * 16));
+        for (int i = tid; i < M2_BV_FLOATS; i += 512)
+            BV[i] = i < 192 ? wt.fc1_b[i] * wt.fc1_scale : (i < 240 ? wt.fc2_b[i - 192] * wt.fc2_scale : wt.ls[i - 240] * wt.fc2_inv);
+        if constexpr (OUT3) {
+            if (tid < 147) BV[M2_BV_FLOATS + tid] = tid < 144 ? o3.w[tid] : o3.b[tid - 144];
+        }
+        for (int q = tid; q < D_W_FLOATS / 4; q += 512)
+            reinterpret_cast<f32x4*>(Wl)[q] = reinterpret_cast<const f32x4*>(wt.dw_w)[q];
+        if (tid < E_PAR_FLOATS) Pl[tid] = tid < kF ? wt.dw_b[tid] : (tid < 2 * kF ? wt.ln_w[tid - kF] : wt.ln_b[tid - 2 * kF]);
+        if (tid == 0) Fs[0] = 0;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    float* Xw = Tl;                         // the exchange: [tile row 16][chunk 3][pixel 16][16 floats]
+    auto sigma = [](int q) { return q == 0 ? 0 : q == 1 ? 3 : q == 2 ? 1 : 2; };
+#ifdef RVDD_STAMPS
+    unsigned long long ps[6] = {0, 0, 0, 0, 0, 0}, ps_t = __builtin_amdgcn_s_memtime(), ps_n = 0;
+#define PSTAMP(i) do { const unsigned long long now__ = __builtin_amdgcn_s_memtime(); ps[i] += now__ - ps_t; ps_t = now__; } while (0)
+#else
+#define PSTAMP(i) do { } while (0)
+#endif
+
+    if (front) {
+        // ================================================================================================ front
+        const int g = lane & 3;
+        const int idx = lane >> 2;
+        const int quad = idx & 3;
+        const int rw = ((idx >> 3) << 1) + (__builtin_popcount(idx & 7) & 1);      // row inside the wave's four
+        const int row = wave * 4 + rw;
+        int piece_yx[9];           // the 33 LDS-DMA pieces of a chunk over the four front waves
+#pragma unroll
+        for (int n = 0; n < 9; ++n) {
+            const int k = wave + 4 * n;
+            const int R = k * 4 + (lane >> 4), sl = lane & 15;
+            const int p = 4 * R + ((sl >> 2) ^ (R & 3));
+            const int iy = p / E_PITCH, ix = p - iy * E_PITCH;
+            piece_yx[n] = (k < E_PIECES && ix < E_TW + 6) ? (iy << 8) | ix : -1;
+        }
+        auto dma_chunk = [&](const TilePos& tp, int j, int buf) {
+            __amdgpu_buffer_rsrc_t ir =
+                __builtin_amdgcn_make_buffer_rsrc((void*)(x + (size_t)tp.b * H * W * kF), 0, H * W * kF * 4, 0x00020000);
+            float* dst = Tl + buf * E_BUF_FLOATS;
+#pragma unroll
+            for (int n = 0; n < 9; ++n) {
+                const int k = wave + 4 * n;
+                if (k < E_PIECES) {
+                    const int gy = tp.y0 - 3 + (piece_yx[n] >> 8), gx = tp.x0 - 3 + (piece_yx[n] & 255);
+                    const bool ok = piece_yx[n] >= 0 && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+                    dma16(ir, dst + k * 256, ok ? (unsigned)(((gy * W + gx) * kF + 16 * j + 4 * (lane & 3)) * 4) : 0x80000000u);
+                }
+            }
+        };
+        // all four front waves are past this point (and what they wrote to LDS, or had DMA'd, before it is visible)
+        unsigned fs_target = 0;
+        auto fsync = [&]() {
+            fs_target += 4;
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            if (lane == 0) __hip_atomic_fetch_add(Fs, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            while ((int)(__hip_atomic_load(Fs, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) - fs_target) < 0) __builtin_amdgcn_s_sleep(1);
+        };
+        const int t0 = (2 * row + quad) & 3;
+        int rd0[4][4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int d = 0; d < 4; ++d) rd0[c][d] = (row * 6 + quad) * 64 + ((d ^ ((t0 + c) & 3)) * 4 + g) * 4;
+
+        TilePos cur = locate(tile);
+        dma_chunk(cur, 0, 0);
+        dma_chunk(cur, 1, 1);
+#pragma unroll 1
+        for (;;) {
+            f32x4 acc[4][3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[i][j] = *reinterpret_cast<const f32x4*>(Pl + 16 * j + 4 * g);
+#pragma unroll
+            PSTAMP(0);
+            for (int j = 0; j < 3; ++j) {
+                // j = 0: chunks 0 and 1 have landed (requested together, a tile ago); j = 2: so has chunk 2, requested below
+                // when every front wave was done with chunk 0 (the wait inside fsync covers every request of this wave)
+                if (j != 1) fsync();
+                PSTAMP(1);
+                const float* tb = Tl + (j & 1) * E_BUF_FLOATS;
+                const float* wb = Wl + 16 * j + 4 * g;
+                f32x4 win[2][10], wv[2][7];
+                auto read_row = [&](int ky, f32x4 (&wn)[10], f32x4 (&ww)[7]) {
+#pragma unroll
+                    for (int dx = 0; dx < 10; ++dx)
+                        wn[dx] = *reinterpret_cast<const f32x4*>(tb + rd0[(2 * ky + (dx >> 2)) & 3][dx & 3] + ky * 6 * 64 + (dx >> 2) * 64);
+#pragma unroll
+                    for (int kx = 0; kx < 7; ++kx) ww[kx] = *reinterpret_cast<const f32x4*>(wb + (ky * 7 + kx) * kF);
+                };
+                read_row(0, win[0], wv[0]);
+#pragma unroll
+                for (int ky = 0; ky < 7; ++ky) {
+                    if (ky + 1 < 7) read_row(ky + 1, win[(ky + 1) & 1], wv[(ky + 1) & 1]);
+#pragma unroll
+                    for (int kx = 0; kx < 7; ++kx)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) acc[i][j] = acc[i][j] + win[ky & 1][i + kx] * wv[ky & 1][kx];
+                    asm volatile("" : "+v"(acc[0][j]), "+v"(acc[1][j]), "+v"(acc[2][j]), "+v"(acc[3][j])::"memory");
+                }
+                PSTAMP(2);
+                if (j == 0) {
+                    fsync();                         // every front wave is done with buffer 0
+                    dma_chunk(cur, 2, 0);
+                }
+            }
+            // ---- LayerNorm over the 48 channels of each pixel
+            f32x4 lw[3], lb[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                lw[j] = *reinterpret_cast<const f32x4*>(Pl + kF + 16 * j + 4 * g);
+                lb[j] = *reinterpret_cast<const f32x4*>(Pl + 2 * kF + 16 * j + 4 * g);
+            }
+            fsync();                                 // every front wave is done with both buffers: they become the exchange
+            int lane_o = lane;
+            asm volatile("" : "+v"(lane_o));
+            const int x_wr = (wave * 4 + ((lane_o >> 5) << 1) + (__builtin_popcount((lane_o >> 2) & 7) & 1)) * 768 +
+                             (4 * ((lane_o >> 2) & 3)) * 16 + ((((lane_o >> 2) & 3) ^ sigma(lane_o & 3)) * 4);   // + j * 256 + i * 16
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float sm = 0.f;
+#pragma unroll
+                for (int j = 0; j < 3; ++j) sm += (acc[i][j][0] + acc[i][j][1]) + (acc[i][j][2] + acc[i][j][3]);
+                sm += __shfl_xor(sm, 1);
+                sm += __shfl_xor(sm, 2);
+                const float u = sm / 48.f;
+                float v2 = 0.f;
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float d = acc[i][j][r] - u;
+                        v2 += d * d;
+                    }
+                v2 += __shfl_xor(v2, 1);
+                v2 += __shfl_xor(v2, 2);
+                const float rden = 1.0f / sqrtf(v2 / 48.f + 1e-6f);
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    f32x4 r;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) r[k] = lw[j][k] * ((acc[i][j][k] - u) * rden) + lb[j][k];
+                    *reinterpret_cast<f32x4*>(Xw + x_wr + j * 256 + i * 16) = r;
+                }
+            }
+            PSTAMP(3);
+            __syncthreads();                         // A: the exchange holds this tile's LayerNorm result
+            __syncthreads();                         // B: the back has it in registers; the buffers are free
+            PSTAMP(4);
+#ifdef RVDD_STAMPS
+            ++ps_n;
+#endif
+            const int next_tile = tile + stride;
+            if (next_tile >= band_end) break;
+            tile = next_tile;
+            cur = locate(tile);
+            dma_chunk(cur, 0, 0);
+            dma_chunk(cur, 1, 1);
+        }
+    } else {
+        // ================================================================================================= back
+        const int bw = wave - 4;                // rows 4 bw .. 4 bw + 3 of every tile
+#pragma unroll 1
+        for (;;) {
+            const TilePos cur = locate(tile);
+            int lane_o = lane;
+            asm volatile("" : "+v"(lane_o));
+            const int lr = lane_o & 15, kk = lane_o >> 4;
+            const int x_rd = lr * 16 + (((lr >> 2) ^ sigma(kk)) * 4);                                   // + row * 768 + j * 256
+            typedef __attribute__((address_space(3))) f32x4 lds_frag_t;
+            lds_frag_t* bvp = (lds_frag_t*)BV + kk;
+            asm volatile("" : "+v"(bvp));
+            const unsigned lane_off = (unsigned)(lr * (kF * 4) + kk * 16);
+            PSTAMP(0);
+            __syncthreads();                         // A
+            PSTAMP(1);
+            f32x4 xc[4][3];
+#pragma unroll
+            for (int n = 0; n < 4; ++n)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) xc[n][j] = *reinterpret_cast<const f32x4*>(Xw + x_rd + (4 * bw + n) * 768 + j * 256);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __syncthreads();                         // B
+            PSTAMP(2);
+            // two 16-pixel groups (= two tile rows) at a time: they share every filter fragment, and their MFMA chains and GELUs
+            // are independent, which is what hides each other's latencies now that the SIMD partner is in another phase
+#pragma unroll
+            for (int n2 = 0; n2 < 4; n2 += 2) {
+                __amdgpu_buffer_rsrc_t rx[2], ro[2];
+                int yrow[2], valid[2];
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    yrow[q] = cur.y0 + bw * 4 + n2 + q;
+                    valid[q] = yrow[q] < H ? min(E_TW, W - cur.x0) : 0;
+                    const size_t first = ((size_t)cur.b * H + min(yrow[q], H - 1)) * W + cur.x0;
+                    rx[q] = __builtin_amdgcn_make_buffer_rsrc((void*)(x + first * kF), 0, valid[q] * (kF * 4), 0x00020000);
+                    ro[q] = __builtin_amdgcn_make_buffer_rsrc((void*)(out + first * kF), 0, valid[q] * (kF * 4), 0x00020000);
+                }
+                f32x4 a2[2][3], xr[2][3], lv[3];
+                const char* w1b = reinterpret_cast<const char*>(W1) + lane_o * 16;
+                const char* w2b = reinterpret_cast<const char*>(W2) + lane_o * 16;
+                auto FA = [&](int m, int f) { return __builtin_bit_cast(h8v, *reinterpret_cast<const f32x4*>(w1b + m * 3072 + f * 1024)); };
+                auto FG = [&](int p, int mo, int hl) { return __builtin_bit_cast(h8v, *reinterpret_cast<const f32x4*>(w2b + ((p * 3 + mo) * 2 + hl) * 1024)); };
+                h8v B1[2], B2[2], B3[2], B4[2];
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    u32x2v xh[3], xl[3];
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) split4h(xc[n2 + q][j], xh[j], xl[j]);
+                    B1[q] = cat8(xh[0], xh[1]);
+                    B2[q] = cat8(xl[0], xl[1]);
+                    B3[q] = cat8(xh[2], xh[2]);
+                    B4[q] = cat8(xl[2], xl[2]);
+#pragma unroll
+                    for (int mo = 0; mo < 3; ++mo) a2[q][mo] = bvp[48 + 4 * mo];
+#pragma unroll
+                    for (int mo = 0; mo < 3; ++mo) xr[q][mo] = bload(rx[q], lane_off + 64 * mo);
+                }
+                const float s1i = wt.fc1_inv;
+                // fc1's fragments one pair of hidden blocks ahead, fc2's at the top of their pair: an LDS read issued right in
+                // front of its MFMA is a wait of a few hundred cycles, and this wave has no SIMD partner in the same phase
+                h8v fa[2][2], fb[2][2], fc[2][2];
+                auto load_fc1 = [&](int p, int buf) {
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        fa[buf][k] = FA(2 * p + k, 0);
+                        fb[buf][k] = FA(2 * p + k, 1);
+                        fc[buf][k] = FA(2 * p + k, 2);
+                    }
+                };
+                load_fc1(0, 0);
+#pragma unroll
+                for (int p = 0; p < 6; ++p) {
+                    const int cb = p & 1;
+                    f32x4 hq[2][2];
+#pragma unroll
+                    for (int q = 0; q < 2; ++q)
+#pragma unroll
+                        for (int k = 0; k < 2; ++k) hq[q][k] = bvp[4 * (2 * p + k)];
+                    if (p + 1 < 6) load_fc1(p + 1, cb ^ 1);
+                    h8v gh[3], gl[3];
+#pragma unroll
+                    for (int mo = 0; mo < 3; ++mo) {
+                        gh[mo] = FG(p, mo, 0);
+                        gl[mo] = FG(p, mo, 1);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int q = 0; q < 2; ++q)
+#pragma unroll
+                        for (int k = 0; k < 2; ++k) hq[q][k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[cb][k], B2[q], hq[q][k], 0, 0, 0);
+#pragma unroll
+                    for (int q = 0; q < 2; ++q)
+#pragma unroll
+                        for (int k = 0; k < 2; ++k) hq[q][k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[cb][k], B1[q], hq[q][k], 0, 0, 0);
+#pragma unroll
+                    for (int q = 0; q < 2; ++q)
+#pragma unroll
+                        for (int k = 0; k < 2; ++k) hq[q][k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fc[cb][k], B4[q], hq[q][k], 0, 0, 0);
+#pragma unroll
+                    for (int q = 0; q < 2; ++q)
+#pragma unroll
+                        for (int k = 0; k < 2; ++k) hq[q][k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fc[cb][k], B3[q], hq[q][k], 0, 0, 0);
+#pragma unroll
+                    for (int q = 0; q < 2; ++q)
+#pragma unroll
+                        for (int k = 0; k < 2; ++k) hq[q][k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[cb][k], B1[q], hq[q][k], 0, 0, 0);
+                    h8v Bhh[2], Bhl[2];
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        u32x2v hh[2], hl[2];
+#pragma unroll
+                        for (int k = 0; k < 2; ++k) split4h(gelu_phi4(hq[q][k] * s1i), hh[k], hl[k]);
+                        Bhh[q] = cat8(hh[0], hh[1]);
+                        Bhl[q] = cat8(hl[0], hl[1]);
+                    }
+#pragma unroll
+                    for (int q = 0; q < 2; ++q)
+#pragma unroll
+                        for (int mo = 0; mo < 3; ++mo) a2[q][mo] = __builtin_amdgcn_mfma_f32_16x16x32_f16(gh[mo], Bhl[q], a2[q][mo], 0, 0, 0);
+#pragma unroll
+                    for (int q = 0; q < 2; ++q)
+#pragma unroll
+                        for (int mo = 0; mo < 3; ++mo) a2[q][mo] = __builtin_amdgcn_mfma_f32_16x16x32_f16(gl[mo], Bhh[q], a2[q][mo], 0, 0, 0);
+#pragma unroll
+                    for (int q = 0; q < 2; ++q)
+#pragma unroll
+                        for (int mo = 0; mo < 3; ++mo) a2[q][mo] = __builtin_amdgcn_mfma_f32_16x16x32_f16(gh[mo], Bhh[q], a2[q][mo], 0, 0, 0);
+                }
+#pragma unroll
+                for (int mo = 0; mo < 3; ++mo) lv[mo] = bvp[60 + 4 * mo];
+                // ---- out = x + layerscale * r
+                f32x4 v[2][3];
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+#pragma unroll
+                    for (int mo = 0; mo < 3; ++mo) {
+                        v[q][mo] = xr[q][mo] + lv[mo] * a2[q][mo];
+                        bstore(ro[q], lane_off + 64 * mo, v[q][mo]);
+                    }
+                if constexpr (POOL) {
+                    // the two rows are one pooling row pair, pixels lr and lr ^ 1; floor semantics of MaxPool2d(2) fall out of
+                    // the descriptor (pooled rows / columns that do not exist have no records)
+                    const int Hp = H >> 1, Wp = W >> 1;
+                    const int pr = (cur.y0 >> 1) + 2 * bw + (n2 >> 1), pc0 = cur.x0 >> 1;
+                    const int nvalid = pr < Hp ? min(E_TW / 2, Wp - pc0) : 0;
+                    __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(
+                        (void*)(pool + (((size_t)cur.b * Hp + min(pr, Hp - 1)) * Wp + pc0) * kF), 0, max(nvalid, 0) * (kF * 4), 0x00020000);
+#pragma unroll
+                    for (int mo = 0; mo < 3; ++mo) {
+                        f32x4 m;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float a = fmaxf(v[0][mo][e], v[1][mo][e]);
+                            m[e] = fmaxf(a, __shfl_xor(a, 1));
+                        }
+                        bstore(rp, (lr & 1) ? 0x80000000u : (unsigned)((lr >> 1) * (kF * 4) + kk * 16 + 64 * mo), m);
+                    }
+                }
+                if constexpr (OUT3) {
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        float t[3];
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) {
+                            float pc = 0.f;
+#pragma unroll
+                            for (int mo = 0; mo < 3; ++mo) {
+                                const f32x4 w3 = bvp[M2_BV_FLOATS / 4 + c * 12 + 4 * mo];
+                                pc += (v[q][mo][0] * w3[0] + v[q][mo][1] * w3[1]) + (v[q][mo][2] * w3[2] + v[q][mo][3] * w3[3]);
+                            }
+                            pc += __shfl_xor(pc, 16);
+                            pc += __shfl_xor(pc, 32);
+                            t[c] = pc + BV[M2_BV_FLOATS + 144 + c];
+                        }
+                        if (kk == 0 && lr < valid[q]) {
+                            const size_t pp = (size_t)yrow[q] * W + cur.x0 + lr;
+                            if (o3.nchw) {
+#pragma unroll
+                                for (int c = 0; c < 3; ++c) o3.nchw[((size_t)cur.b * 3 + c) * o3.hw + pp] = t[c];
+                            }
+                            if (o3.nhwc4) reinterpret_cast<f32x4*>(o3.nhwc4)[(size_t)cur.b * o3.hw + pp] = f32x4{t[0], t[1], t[2], 0.f};
+                        }
+                    }
+                }
+            }
+            PSTAMP(3);
+#ifdef RVDD_STAMPS
+            ++ps_n;
+#endif
+            const int next_tile = tile + stride;
+            if (next_tile >= band_end) break;
+            tile = next_tile;
+        }
+    }
+#ifdef RVDD_STAMPS
+    // diagnostic build only: per-phase cycles of waves 0 (front) and 4 (back) of workgroup 0 over the first pixels of `out`
+    if (blockIdx.x == 0 && (tid == 0 || tid == 256)) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        float* o = out + (tid >> 8) * 8;
+        o[0] = (float)ps_n;
+        for (int i = 0; i < 6; ++i) o[1 + i] = (float)ps[i];
+    }
+#endif
+}
+
 // zero_pad_features (networks/new_unet.py:56-66): src [B][h][w] -> dst [B][H][W] at (oy,ox), zeros elsewhere
 __global__ void pad_copy_kernel(const float* __restrict__ src, float* __restrict__ dst, int B, int h, int w,
                                 int H, int W, int oy, int ox) {
@@ -1156,10 +1576,27 @@ static hipError_t launch_block_t(const float* x, float* out, const NextBlockW& w
     hipLaunchKernelGGL((convblock_kernel<OUT3, POOL, SPLIT>), dim3(grid), dim3(512), LDS, s, x, w, out, B, H, W, tx, ty, ntiles, o3, pool);
     return hipGetLastError();
 }
-// w.fc1_h set = the split-f16 MLP (the default); null = the f32-MFMA form (option next_split 0: the A/B reference)
+template <bool OUT3, bool POOL>
+static hipError_t launch_block_pipe(const float* x, float* out, const NextBlockW& w, int B, int H, int W, Out3 o3, hipStream_t s,
+                                    float* pool) {
+    if ((size_t)H * W * kF * 4 >= 0x80000000ull) return hipErrorInvalidValue;
+    static std::atomic<uint64_t> attr{0};
+    constexpr size_t LDS = F_LDS_BYTES_SPLIT + 64;
+    if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(convblock_pipe_kernel<OUT3, POOL>), LDS, attr); e != hipSuccess)
+        return e;
+    const int tx = (W + E_TW - 1) / E_TW, ty = (H + E_TH - 1) / E_TH;
+    const int ntiles = B * tx * ty;
+    if (ntiles <= 0) return hipSuccess;
+    const int grid = ((std::min(ntiles, num_cus()) + 7) / 8) * 8;
+    hipLaunchKernelGGL((convblock_pipe_kernel<OUT3, POOL>), dim3(grid), dim3(512), LDS, s, x, w, out, B, H, W, tx, ty, ntiles, o3, pool);
+    return hipGetLastError();
+}
+// w.fc1_h set = the split-f16 MLP (the default; w.pipe: as a two-stage pipeline over tiles); null = the f32-MFMA form
+// (option next_split 0: the A/B reference)
 template <bool OUT3, bool POOL = false>
 static hipError_t launch_block(const float* x, float* out, const NextBlockW& w, int B, int H, int W, Out3 o3, hipStream_t s,
                                float* pool = nullptr) {
+    if (w.fc1_h && w.pipe) return launch_block_pipe<OUT3, POOL>(x, out, w, B, H, W, o3, s, pool);
     return w.fc1_h ? launch_block_t<OUT3, POOL, true>(x, out, w, B, H, W, o3, s, pool)
                    : launch_block_t<OUT3, POOL, false>(x, out, w, B, H, W, o3, s, pool);
 }

@@ -134,6 +134,7 @@ struct rvdd_handle {
     bool fuse_upsample = true;    // UpConv's bilinear x2 inside the Winograd patch load (RVDD_FUSE_UPSAMPLE=0: separate kernel)
     bool next_fused = true;       // ConvNeXt ConvBlock as ONE kernel (RVDD_NEXT_FUSED=0 / option "next_fused" 0: dwln + mlp kernels, the A/B reference)
     bool next_split = true;       // ConvNeXt, fused blocks: the two 1x1 convs on the F16 matrix pipe with split f32 operands (RVDD_NEXT_SPLIT=0: f32 MFMA)
+    bool next_pipe = true;        // ConvNeXt, fused split-f16 blocks as a front / back pipeline over tiles (convblock_pipe_kernel; RVDD_NEXT_PIPE=0: convblock_kernel's phases)
     bool next_pool = true;        // ConvNeXt, fused blocks: MaxPool2d(2) from the epilogue of the block in front of a DownConv
     bool next_streams = false;    // ConvNeXt, two-kernel blocks, B >= 2: the two halves of the batch as two chains on two streams (measured: no gain)
     hipStream_t stream2 = nullptr;
@@ -836,6 +837,7 @@ int rvdd_create(const rvdd_cfg* cfg, rvdd_t** out) {
     if (const char* w4 = std::getenv("RVDD_WINO4")) h->wino4 = std::atoi(w4);
     if (const char* np = std::getenv("RVDD_NEXT_POOL")) h->next_pool = std::atoi(np) != 0;
     if (const char* nsp = std::getenv("RVDD_NEXT_SPLIT")) h->next_split = std::atoi(nsp) != 0;
+    if (const char* npp = std::getenv("RVDD_NEXT_PIPE")) h->next_pipe = std::atoi(npp) != 0;
     if (const char* ns = std::getenv("RVDD_NEXT_STREAMS")) h->next_streams = std::atoi(ns) != 0;
     if (const char* cv = std::getenv("RVDD_CONV")) {
         // f32 (the f32-MFMA kernels, direct or Winograd by launch size) | direct | winograd (that f32 kernel at every size) |
@@ -1082,6 +1084,12 @@ int rvdd_set_option(rvdd_t* h, const char* name, int32_t value) {
         h->next_split = value != 0;
         return RVDD_OK;
     }
+    if (std::strcmp(name, "next_pipe") == 0) {
+        // 0 = the fused ConvBlock's phases one after the other in all eight waves (convblock_kernel) instead of the pipeline over
+        // tiles (depth-wise + LayerNorm of tile t + 1 on waves 0-3 beside the MLP of tile t on waves 4-7); same bits
+        h->next_pipe = value != 0;
+        return RVDD_OK;
+    }
     if (std::strcmp(name, "next_pool") == 0) {
         // 0 = MaxPool2d(2) as its own kernel behind the fused block (A/B reference of the pooling epilogue; same bits)
         h->next_pool = value != 0;
@@ -1114,7 +1122,7 @@ int rvdd_set_option(rvdd_t* h, const char* name, int32_t value) {
         h->split16 = value == 0;
         return RVDD_OK;
     }
-    return fail(h, RVDD_ERR_ARG, "rvdd_set_option: unknown option '%s' (known: no_warp, warp_raw, prev_noisy_frame, conv_kernel, seq_major, graphs, fuse_upsample, next_fused, next_split, next_pool, next_streams, wino4)", name);
+    return fail(h, RVDD_ERR_ARG, "rvdd_set_option: unknown option '%s' (known: no_warp, warp_raw, prev_noisy_frame, conv_kernel, seq_major, graphs, fuse_upsample, next_fused, next_split, next_pipe, next_pool, next_streams, wino4)", name);
 }
 
 int rvdd_reset(rvdd_t* h) {

@@ -143,6 +143,7 @@ struct NextBlockW {          // device pointers, one ConvBlock (networks/new_une
     const float* fc1_h;
     const float* fc2_h;
     float fc1_scale, fc1_inv, fc2_scale, fc2_inv;
+    int pipe;                // 1 = convblock_pipe_kernel (front / back waves pipelined over tiles) instead of convblock_kernel
 };
 // one ConvBlock = dwln (x -> LayerNorm(dwconv7x7(x))) then mlp (ln, x -> x + ls * MLP(ln)); x NHWC48
 // co = the launch shares the CUs with a kernel of the other half-batch chain (runtime_next.inc): dwln one workgroup per

@@ -870,6 +870,38 @@ def test_split_path_outside_its_domain_stays_finite():
     assert (outs[0].cpu() - want).abs().max() > 1e-3 * scale
 
 
+def test_pipelined_convblock_equals_phased():
+    """convblock_pipe_kernel (the default: waves 0-3 run the depth-wise conv and the LayerNorm of tile t + 1 while waves
+    4-7 run the MLP of tile t, hand-over through the halo buffers behind two workgroup barriers, the front waves' own
+    LDS-counter barrier around their halo requests) against convblock_kernel (option next_pipe = 0: the same phases one
+    after the other in all eight waves): the same arithmetic per pixel in the same order, so the same bits -- plain,
+    pooling and 1x1-output variants, sizes with one tile, ragged tiles, more tiles than workgroups' first round, batches."""
+    from rvdd_release_amd import synth
+    from rvdd_release_amd.runtime import RvddRuntime
+    if "next-feat-future-iso3200" not in BUILT:
+        pytest.skip("ConvNeXt path not built")
+    arch, fut = "next+feat", 1
+    sd = load_weights(VARIANTS["next-feat-future-iso3200"][0])
+    for B, H, W in ((1, 16, 16), (3, 22, 130), (2, 130, 22), (1, 50, 66), (2, 72, 104), (1, 256, 256), (4, 360, 640)):
+        T = 4
+        seqs = [synth.make_sequence(T, H, W, iso=3200, seed=660 + b, device="cuda") for b in range(B)]
+        st = lambda f: torch.stack([f(s) for s in seqs], 0)
+        outs = []
+        for pipe in (1, 0):
+            rt = RvddRuntime(arch, fut, B, H, W, 0)
+            rt.set_option("next_pipe", pipe)
+            rt.load_state_dict(sd)
+            o = []
+            for t in range(1, T - fut):
+                o.append(rt.step(st(lambda s: s.raw[t - 1]) if t == 1 else None, st(lambda s: s.raw[t]),
+                                 st(lambda s: s.raw[t + 1]), st(lambda s: s.flow_prev[t]), st(lambda s: s.flow_next[t])).clone())
+            outs.append((o, rt.get_state()[1].clone()))
+            rt.close()
+        for a, b in zip(outs[0][0], outs[1][0]):
+            assert torch.equal(a, b), (B, H, W, float((a - b).abs().max()))
+        assert torch.equal(outs[0][1], outs[1][1]), (B, H, W)
+
+
 def test_pooling_epilogue_equals_maxpool_kernel():
     """MaxPool2d(2) in front of each DownConv (networks/new_unet.py:200-204) written from the epilogue of the fused
     ConvBlock ahead of it (the default) against the separate pooling kernel (option next_pool = 0): a maximum has no

@@ -18,6 +18,12 @@ for t in (1, 2):
     rt.step(st(s.raw[t - 1]) if t == 1 else None, st(s.raw[t]), st(s.raw[t + 1]), st(s.flow_prev[t]), st(s.flow_next[t]))
 torch.cuda.synchronize()
 _, feat = rt.get_state()
+if os.environ.get("RVDD_NEXT_PIPE") == "1":
+    a = feat[0, :16, 0, 0].cpu().tolist()
+    f, b = a[:8], a[8:]
+    print("front (wave 0), cycles per tile: loop top %.0f, waiting for halo chunks %.0f, taps %.0f, LayerNorm + exchange %.0f, barriers A + B %.0f" % tuple(x / f[0] for x in f[1:6]))
+    print("back  (wave 4), cycles per tile: loop top %.0f, barrier A %.0f, exchange read + barrier B %.0f, MLP of four rows %.0f" % tuple(x / b[0] for x in b[1:5]))
+    sys.exit(0)
 v = feat[0, :5, 0, 0].cpu().tolist()
 n = v[0]
 print("tiles", n, "cycles per tile (100 MHz ticks? shader cycles): dw %.0f ln+exch %.0f mlp %.0f wait %.0f total %.0f" % (v[1]/n, v[2]/n, v[3]/n, v[4]/n, sum(v[1:])/n))
