@@ -336,6 +336,37 @@ __device__ __forceinline__ f32x4 gelu_phi4(f32x4 v) {
     return o;
 }
 
+// The same for an argument known only up to a power of two, v = s h (h: fc1's accumulator in the filters' scale, s = 2^-k):
+// returns GELU(v) / s from h.  With t' = min(|h|, cap / s), q = t' P'(t') - 1, P' = P's Horner chain on the coefficients
+// C_i s^(6-i): every intermediate is the unscaled chain's times a power of two, so the result is gelu_phi4(s h) / s bit for
+// bit -- and the 48 multiplications per pixel group that formed s h are gone.  gc[0..5] = the scaled coefficients,
+// gc[6] = cap / s (NextBlockW::gelu_c, computed on the host; every constant twice, see there).
+__device__ __forceinline__ f32x4 gelu_phi4_scaled(f32x4 h, const float (&gc)[7][2]) {
+    const float zero = 0.0f, cap = gc[6][0];
+    f32x2 t[2], p[2], q[2];
+    f32x4 relu, o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        // v_med3_f32 through the intrinsic, NOT gelu_phi4's inline-asm v_min / v_max: h comes straight out of an MFMA here,
+        // and the wait states a vector read of an MFMA result needs are only inserted in front of instructions the compiler
+        // can see (inline asm reading the accumulator two cycles behind the MFMA read garbage)
+        t[k >> 1][k & 1] = __builtin_amdgcn_fmed3f(__builtin_fabsf(h[k]), zero, cap);
+        relu[k] = __builtin_amdgcn_fmed3f(h[k], zero, __builtin_inff());
+    }
+    auto K = [&](int i) { return f32x2{gc[i][0], gc[i][1]}; };
+    p[0] = p[1] = K(0);
+#pragma unroll
+    for (int i = 1; i < 6; ++i) {
+        p[0] = __builtin_elementwise_fma(p[0], t[0], K(i));
+        p[1] = __builtin_elementwise_fma(p[1], t[1], K(i));
+    }
+    q[0] = __builtin_elementwise_fma(t[0], p[0], f32x2{-1.0f, -1.0f});
+    q[1] = __builtin_elementwise_fma(t[1], p[1], f32x2{-1.0f, -1.0f});
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o[k] = fmaf(-fabsf(h[k]), __builtin_amdgcn_exp2f(q[k >> 1][k & 1]), relu[k]);
+    return o;
+}
+
 // OUT3: the network's last block also applies the 1x1 conv 48 -> 3 of the post-processing (new_unet.py:414-430) to the
 // map it has just formed, instead of a kernel that reads the 48-channel map back: each lane multiplies its 12 channels,
 // two shuffles sum the four channel groups of a pixel, lane group 0 stores the planar frame and the NHWC4 copy.
@@ -605,9 +636,17 @@ typedef unsigned int u32x2v __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void split4h(f32x4 x, u32x2v& hi, u32x2v& lo) {
     const fp16x2v h01 = __builtin_amdgcn_cvt_pkrtz(x[0], x[1]);
     const fp16x2v h23 = __builtin_amdgcn_cvt_pkrtz(x[2], x[3]);
-    const h2v l01 = {(_Float16)(x[0] - (float)h01[0]), (_Float16)(x[1] - (float)h01[1])};
-    const h2v l23 = {(_Float16)(x[2] - (float)h23[0]), (_Float16)(x[3] - (float)h23[1])};
-    hi = u32x2v{__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23)};
+    const unsigned u01 = __builtin_bit_cast(unsigned, h01), u23 = __builtin_bit_cast(unsigned, h23);
+    // x - hi in ONE instruction per value: v_fma_mix_f32 reads the f16 half in place (hipcc's own choice for the same
+    // expression is two conversions and a packed subtraction per pair: 16 cycles of the vector port against 8)
+    float r0, r1, r2, r3;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(u01), "v"(x[0]));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(u01), "v"(x[1]));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r2) : "v"(u23), "v"(x[2]));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r3) : "v"(u23), "v"(x[3]));
+    const h2v l01 = {(_Float16)r0, (_Float16)r1};
+    const h2v l23 = {(_Float16)r2, (_Float16)r3};
+    hi = u32x2v{u01, u23};
     lo = u32x2v{__builtin_bit_cast(unsigned, l01), __builtin_bit_cast(unsigned, l23)};
 }
 __device__ __forceinline__ h8v cat8(u32x2v a, u32x2v b) { return __builtin_bit_cast(h8v, u32x4{a[0], a[1], b[0], b[1]}); }
@@ -693,9 +732,11 @@ __global__ __launch_bounds__(512, 2) void convblock_kernel(const float* __restri
             __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc((void*)wt.fc2_h, 0, F_W2H_BYTES, 0x00020000);
             for (int k = wave; k < F_W1H_BYTES / 1024; k += 8) dma16(r1, W1 + k * 256, (unsigned)(k * 1024 + lane * 16));
             for (int k = wave; k < F_W2H_BYTES / 1024; k += 8) dma16(r2, W2 + k * 256, (unsigned)(k * 1024 + lane * 16));
-            // biases in the filters' scale (they seed the accumulators), the layerscale in fc2's inverse scale: all exact
+            // biases in their accumulators' scale (fc1's: the filters'; fc2's: its filters' times fc1's, whose hidden values the
+            // GELU hands over unscaled back -- gelu_phi4_scaled), the layerscale in the inverse of that: all exact
             for (int i = tid; i < M2_BV_FLOATS; i += 512)
-                BV[i] = i < 192 ? wt.fc1_b[i] * wt.fc1_scale : (i < 240 ? wt.fc2_b[i - 192] * wt.fc2_scale : wt.ls[i - 240] * wt.fc2_inv);
+                BV[i] = i < 192 ? wt.fc1_b[i] * wt.fc1_scale
+                                : (i < 240 ? wt.fc2_b[i - 192] * (wt.fc2_scale * wt.fc1_scale) : wt.ls[i - 240] * (wt.fc2_inv * wt.fc1_inv));
         } else {
             __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc((void*)wt.fc1_w, 0, M_W_FLOATS * 4, 0x00020000);
             __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc((void*)wt.fc2_w, 0, M_W_FLOATS * 4, 0x00020000);
@@ -875,7 +916,6 @@ __global__ __launch_bounds__(512, 2) void convblock_kernel(const float* __restri
                 for (int mo = 0; mo < 3; ++mo) a2[mo] = bvp[48 + 4 * mo];
 #pragma unroll
                 for (int mo = 0; mo < 3; ++mo) xr[mo] = bload(rx, lane_off + 64 * mo);
-                const float s1i = wt.fc1_inv;
 #pragma unroll
                 for (int p = 0; p < 6; ++p) {
                     // fc1 for hidden blocks 2p, 2p+1 (two accumulator chains side by side), small terms first
@@ -906,7 +946,7 @@ __global__ __launch_bounds__(512, 2) void convblock_kernel(const float* __restri
                     for (int k = 0; k < 2; ++k) hq[k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[k], B1, hq[k], 0, 0, 0);
                     u32x2v hh[2], hl[2];
 #pragma unroll
-                    for (int k = 0; k < 2; ++k) split4h(gelu_phi4(hq[k] * s1i), hh[k], hl[k]);
+                    for (int k = 0; k < 2; ++k) split4h(gelu_phi4_scaled(hq[k], wt.gelu_c), hh[k], hl[k]);
                     const h8v Bhh = cat8(hh[0], hh[1]), Bhl = cat8(hl[0], hl[1]);
 #pragma unroll
                     for (int mo = 0; mo < 3; ++mo) a2[mo] = __builtin_amdgcn_mfma_f32_16x16x32_f16(gh[mo], Bhl, a2[mo], 0, 0, 0);
@@ -1108,7 +1148,8 @@ __global__ __launch_bounds__(512, 2) void convblock_pipe_kernel(const float* __r
         for (int k = wave; k < F_W1H_BYTES / 1024; k += 8) dma16(r1, W1 + k * 256, (unsigned)(k * 1024 + lane * 16));
         for (int k = wave; k < F_W2H_BYTES / 1024; k += 8) dma16(r2, W2 + k * 256, (unsigned)(k * 1024 + lane * 16));
         for (int i = tid; i < M2_BV_FLOATS; i += 512)
-            BV[i] = i < 192 ? wt.fc1_b[i] * wt.fc1_scale : (i < 240 ? wt.fc2_b[i - 192] * wt.fc2_scale : wt.ls[i - 240] * wt.fc2_inv);
+            BV[i] = i < 192 ? wt.fc1_b[i] * wt.fc1_scale
+                                : (i < 240 ? wt.fc2_b[i - 192] * (wt.fc2_scale * wt.fc1_scale) : wt.ls[i - 240] * (wt.fc2_inv * wt.fc1_inv));
         if constexpr (OUT3) {
             if (tid < 147) BV[M2_BV_FLOATS + tid] = tid < 144 ? o3.w[tid] : o3.b[tid - 144];
         }
@@ -1329,7 +1370,6 @@ __global__ __launch_bounds__(512, 2) void convblock_pipe_kernel(const float* __r
 #pragma unroll
                     for (int mo = 0; mo < 3; ++mo) xr[q][mo] = bload(rx[q], lane_off + 64 * mo);
                 }
-                const float s1i = wt.fc1_inv;
                 // fc1's fragments one pair of hidden blocks ahead, fc2's at the top of their pair: an LDS read issued right in
                 // front of its MFMA is a wait of a few hundred cycles, and this wave has no SIMD partner in the same phase
                 h8v fa[2][2], fb[2][2], fc[2][2];
@@ -1383,7 +1423,7 @@ __global__ __launch_bounds__(512, 2) void convblock_pipe_kernel(const float* __r
                     for (int q = 0; q < 2; ++q) {
                         u32x2v hh[2], hl[2];
 #pragma unroll
-                        for (int k = 0; k < 2; ++k) split4h(gelu_phi4(hq[q][k] * s1i), hh[k], hl[k]);
+                        for (int k = 0; k < 2; ++k) split4h(gelu_phi4_scaled(hq[q][k], wt.gelu_c), hh[k], hl[k]);
                         Bhh[q] = cat8(hh[0], hh[1]);
                         Bhl[q] = cat8(hl[0], hl[1]);
                     }

@@ -143,6 +143,9 @@ struct NextBlockW {          // device pointers, one ConvBlock (networks/new_une
     const float* fc1_h;
     const float* fc2_h;
     float fc1_scale, fc1_inv, fc2_scale, fc2_inv;
+    float gelu_c[7][2];      // gelu_phi4_scaled's constants for s = fc1_inv: C_i s^(6-i), cap / s -- each TWICE: as scalar pairs
+                             // they are packed-f32 operands as they stand (hipcc 7.2 folds a splat of ONE kernel-argument scalar
+                             // into the pair that starts at it, i.e. (c_i, c_i+1): wrong numbers, found the hard way)
     int pipe;                // 1 = convblock_pipe_kernel (front / back waves pipelined over tiles) instead of convblock_kernel
 };
 // one ConvBlock = dwln (x -> LayerNorm(dwconv7x7(x))) then mlp (ln, x -> x + ls * MLP(ln)); x NHWC48
