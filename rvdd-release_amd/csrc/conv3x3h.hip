@@ -76,9 +76,17 @@ __device__ __forceinline__ void bstore(__amdgpu_buffer_rsrc_t r, unsigned off, f
 __device__ __forceinline__ void split4(f32x4 x, u32x2& hi, u32x2& lo) {
     const fp16x2 h01 = __builtin_amdgcn_cvt_pkrtz(x[0], x[1]);
     const fp16x2 h23 = __builtin_amdgcn_cvt_pkrtz(x[2], x[3]);
-    const h2 l01 = {(_Float16)(x[0] - (float)h01[0]), (_Float16)(x[1] - (float)h01[1])};
-    const h2 l23 = {(_Float16)(x[2] - (float)h23[0]), (_Float16)(x[3] - (float)h23[1])};
-    hi = u32x2{__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23)};
+    const unsigned u01 = __builtin_bit_cast(unsigned, h01), u23 = __builtin_bit_cast(unsigned, h23);
+    // x - hi as ONE v_fma_mix_f32 per value (the f16 half read in place); x comes from a buffer load or an interpolation,
+    // never straight out of an MFMA (inline asm behind an MFMA gets no wait states)
+    float r0, r1, r2, r3;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(u01), "v"(x[0]));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(u01), "v"(x[1]));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r2) : "v"(u23), "v"(x[2]));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r3) : "v"(u23), "v"(x[3]));
+    const h2 l01 = {(_Float16)r0, (_Float16)r1};
+    const h2 l23 = {(_Float16)r2, (_Float16)r3};
+    hi = u32x2{u01, u23};
     lo = u32x2{__builtin_bit_cast(unsigned, l01), __builtin_bit_cast(unsigned, l23)};
 }
 

@@ -29,7 +29,7 @@ for k in sorted(f):
     name = name.split("(")[0].replace(", 0>", ">") if "conv3x3" in name else name.split("(")[0]
     if name.startswith("mlp_kernel"):
         name = "mlp_kernel"                      # one instantiation; bench.py looks it up by its plain name
-    if name.startswith("convblock_kernel<false, false"):
+    if name.startswith("convblock_kernel<false, false") or name.startswith("convblock_pipe_kernel<false, false"):
         name = "convblock_kernel"                # the plain blocks of a frame-step (<false, true, .> also pool, <true, ..> = the last one, with the 1x1 conv)
     fm = sum(f[k]) / len(f[k])
     wm = sum(w[k]) / len(w[k]) if k in w else 0.0
