@@ -360,7 +360,7 @@ def main():
         traffic, traffic_src = None, None
         try:
             tj = json.load(open(os.path.join(REPO, "profiles", "traffic.json")))
-            ent = tj.get(config) or tj.get("C2" if config == "C5" else config)
+            ent = tj.get(config) or tj.get("C2" if config in ("C5", "C3") else config)      # C3 / C5: C2's maps and launch mix
             traffic, traffic_src = ent["kernels"].get(dom), ent.get("source")
         except Exception:
             pass
