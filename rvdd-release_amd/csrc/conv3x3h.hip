@@ -4,7 +4,7 @@
 //
 // Why.  On gfx950 v_mfma_f32_16x16x4_f32 runs at 64 FLOP/clk/SIMD (the vector rate, and ON the vector lanes: VALU work
 // beside it adds to its time), v_mfma_f32_16x16x32_f16 at 16x that, and leaves the vector issue port free half of its
-// cycles (tools/f16_mfma_bench.hip; profiles/r03_f16_mfma_bench.txt).  An f32 value x is split exactly into
+// cycles (tools/f16_mfma_bench.hip; profiles/r03e_f16_mfma_bench.txt).  An f32 value x is split exactly into
 //     x = hi + lo + r,   hi = f16(x) rounded toward zero,  lo = f16(x - hi),  |r| <= 2^-22 |x|  (2^-25 absolute below 2^-3:
 //                                                                                               lo is then subnormal, kept)
 // and a product of two split values is taken as hi.hi + hi.lo + lo.hi (each exact in the f32 accumulator; the dropped
@@ -23,8 +23,9 @@
 // ONCE per element and written to LDS as two planes, [pixel][hi 48 f16] and [pixel][lo 48 f16] (96 B per pixel, an odd
 // multiple of 32: every B fragment read of the kernel is bank-conflict free, tools/lds_b128_bench.hip).  The staging
 // stores between a tile's two barriers run at the LDS write port's ~60 B per clock whatever their width or pattern
-// (8-byte, 16-byte after a lane exchange, conflict-free or not: 0.75-1.3 k cycles per tile).  The split filter bank (14 chunks x 3 cout blocks x {hi, lo} x 1 KiB
-// lane-linear A fragments = 84 KiB) is DMA'd to LDS once per workgroup.  Wave w owns tile rows 2w, 2w+1 (two B
+// (8-byte, 16-byte after a lane exchange, conflict-free or not: 0.75-1.3 k cycles per tile).  The split filter bank
+// (14 chunks x 3 cout blocks x {hi, lo} x 1 KiB lane-linear A fragments = 84 KiB) is DMA'd to LDS once per workgroup,
+// beside the first tile's halo fetch.  Wave w owns tile rows 2w, 2w+1 (two B
 // fragments per chunk) and all 48 couts (three A fragments): per chunk 6 + 4 ds_read_b128 (hi and lo) feed 18 MFMAs on
 // six accumulators, the fragments of the next chunk being read while the current one is multiplied.
 #include "rvdd_internal.h"
