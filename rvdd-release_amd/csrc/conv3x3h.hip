@@ -121,8 +121,9 @@ __device__ unsigned long long g_stamps[8 * 8];      // [wave][phase 0..6, tiles]
 #endif
 
 // UPS (UpConv, networks/unet.py:88-147): `a.in` is the half-resolution map [B][H/2][W/2][48] and the conv input is its
-// bilinear x2 upsample (align_corners=False), interpolated in the halo fetch with the expressions of upsample2x_kernel
-// (prestage.hip) in the same order: the same bits as "upsample, then conv", the upsampled map is never written.
+// bilinear x2 upsample (align_corners=False), interpolated in the halo fetch (2x2 blocks of halo pixels from four source
+// pixels each) with the expressions of upsample2x_kernel (prestage.hip) in the same order: the same bits as "upsample,
+// then conv", the upsampled map is never written.
 template <int CIN, int EPI, bool ACC_IN, bool UPS = false>
 __global__ __launch_bounds__(NTHREADS) void conv3x3h_kernel(ConvArgs a) {
     using G = HGeo<CIN>;
@@ -192,15 +193,11 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3h_kernel(ConvArgs a) {
     // between the two barriers at the end of the tile.
     f32x4 pre[G::NR];
     u32x2 shi[G::NR], slo[G::NR];
-    f32x4 lo4[UPS ? 3 : 1][4];       // UPS: the 2x2 half-resolution pixels behind a halo piece, three rounds in flight
-    float up_ly[UPS ? 3 : 1];        // ... and their vertical weight (< 0: outside the upsampled map, the piece is zero)
     struct Src {
         __amdgpu_buffer_rsrc_t r;
         int org;
         bool xok;
-        int y0;
-        unsigned xo0, xo1;           // UPS: byte offsets of the two source columns (with this thread's channel piece)
-        float lx1;
+        int y0, x0;
     };
     auto source = [&](const TilePos& p, bool live) {
         Src q;
@@ -210,48 +207,88 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3h_kernel(ConvArgs a) {
         q.org = ((p.y0 - 1) * a.W + (p.x0 - 1)) * (CIN * 4);
         q.xok = ld_thread && (unsigned)(p.x0 - 1 + hx) < (unsigned)a.W;
         q.y0 = p.y0;
-        q.xo0 = q.xo1 = 0;
-        q.lx1 = 0.f;
-        if constexpr (UPS) {
-            const int X = p.x0 - 1 + hx;
-            const float px = fmaxf(0.5f * ((float)X + 0.5f) - 0.5f, 0.f);
-            const int x0 = (int)px;
-            const int x1 = x0 + (x0 < iw - 1 ? 1 : 0);
-            q.lx1 = px - (float)x0;
-            q.xo0 = (unsigned)(x0 * (CIN * 4) + part * 16);
-            q.xo1 = (unsigned)(x1 * (CIN * 4) + part * 16);
-        }
+        q.x0 = p.x0;
         return q;
     };
     auto fetch_round = [&](const Src& q, int r0) {
         const int hy = G::RPR * r0 + rp;
         const bool ok = q.xok && hy < IH && (unsigned)(q.y0 - 1 + hy) < (unsigned)a.H;
-        if constexpr (UPS) {
-            const int Y = q.y0 - 1 + hy, ih = a.H >> 1, iw = a.W >> 1;
-            const float py = fmaxf(0.5f * ((float)Y + 0.5f) - 0.5f, 0.f);
-            const int y0 = (int)py;
-            const int y1 = y0 + (y0 < ih - 1 ? 1 : 0);
-            up_ly[r0 % 3] = ok ? py - (float)y0 : -1.f;
-            const unsigned r0o = ok ? (unsigned)(y0 * iw * (CIN * 4)) : 0x80000000u, r1o = ok ? (unsigned)(y1 * iw * (CIN * 4)) : 0x80000000u;
-            lo4[r0 % 3][0] = bload(q.r, r0o + q.xo0);
-            lo4[r0 % 3][1] = bload(q.r, r0o + q.xo1);
-            lo4[r0 % 3][2] = bload(q.r, r1o + q.xo0);
-            lo4[r0 % 3][3] = bload(q.r, r1o + q.xo1);
-        } else {
-            const int off = g_lane + q.org + r0 * G::RPR * a.W * (CIN * 4);
-            pre[r0] = bload(q.r, ok ? (unsigned)off : 0x80000000u);
+        const int off = g_lane + q.org + r0 * G::RPR * a.W * (CIN * 4);
+        pre[r0] = bload(q.r, ok ? (unsigned)off : 0x80000000u);
+    };
+    // ---- UPS: the halo tile in 2x2 blocks.  Upsampled rows 2i+1, 2i+2 interpolate between the SAME two source rows
+    // (i, i+1, clamped as ATen clamps them), columns alike, and a tile's halo starts at an odd row and column: its 18x18
+    // pixels are 9x9 such blocks, each from four source pixels.  One work item = one block x one 16-B channel piece: four
+    // loads, two vertical interpolations shared by the block's two columns, four outputs -- against four loads and three
+    // interpolations per OUTPUT piece when every halo piece is fetched on its own (TA traffic / 4, a third fewer FMAs).
+    // Two items per thread (972 of 1024 slots).
+    constexpr int UNR = UPS ? 2 : 1;
+    int u_by[UNR], u_bx[UNR], u_part[UNR];
+    bool u_ok[UNR];
+#pragma unroll
+    for (int r0 = 0; r0 < UNR; ++r0) {
+        const int item = tid + NTHREADS * r0, blk = item / 12;
+        u_part[r0] = item - blk * 12;
+        u_by[r0] = blk / 9;
+        u_bx[r0] = blk - u_by[r0] * 9;
+        u_ok[r0] = blk < 81;
+    }
+    f32x4 ulo[UNR][4];                 // source pixels (row 0 col 0, row 0 col 1, row 1 col 0, row 1 col 1)
+    float u_ly[UNR][2], u_lx[UNR][2];  // weight of the second source row / column per block row / column; < 0: outside the map
+    u32x2 ushi[UNR][4], uslo[UNR][4];
+    auto fetch_ups = [&](const Src& q, int r0) {
+        const int ih = a.H >> 1, iw = a.W >> 1;
+        const int i = (q.y0 >> 1) - 1 + u_by[r0], jx = (q.x0 >> 1) - 1 + u_bx[r0];
+        const int rr0 = min(max(i, 0), ih - 1), cc0 = min(max(jx, 0), iw - 1);
+        const int rr1 = rr0 + (rr0 < ih - 1 ? 1 : 0), cc1 = cc0 + (cc0 < iw - 1 ? 1 : 0);
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int Y = q.y0 - 1 + 2 * u_by[r0] + e, X = q.x0 - 1 + 2 * u_bx[r0] + e;
+            const float py = fmaxf(0.5f * ((float)Y + 0.5f) - 0.5f, 0.f), px = fmaxf(0.5f * ((float)X + 0.5f) - 0.5f, 0.f);
+            u_ly[r0][e] = (unsigned)Y < (unsigned)a.H ? py - (float)(int)py : -1.f;
+            u_lx[r0][e] = (unsigned)X < (unsigned)a.W ? px - (float)(int)px : -1.f;
+        }
+        const bool any = u_ok[r0] && (u_ly[r0][0] >= 0.f || u_ly[r0][1] >= 0.f) && (u_lx[r0][0] >= 0.f || u_lx[r0][1] >= 0.f);
+        const unsigned p16 = (unsigned)(u_part[r0] * 16);
+        ulo[r0][0] = bload(q.r, any ? (unsigned)((rr0 * iw + cc0) * (CIN * 4)) + p16 : 0x80000000u);
+        ulo[r0][1] = bload(q.r, any ? (unsigned)((rr0 * iw + cc1) * (CIN * 4)) + p16 : 0x80000000u);
+        ulo[r0][2] = bload(q.r, any ? (unsigned)((rr1 * iw + cc0) * (CIN * 4)) + p16 : 0x80000000u);
+        ulo[r0][3] = bload(q.r, any ? (unsigned)((rr1 * iw + cc1) * (CIN * 4)) + p16 : 0x80000000u);
+    };
+    // vertical pass, then horizontal, each "a * wa, then one fused multiply-add": upsample2x_kernel's expressions in its order
+    auto interp_ups = [&](int r0) {
+        auto fma4 = [](f32x4 x, float sc, f32x4 c) { return __builtin_elementwise_fma(x, f32x4{sc, sc, sc, sc}, c); };
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const float ly1 = u_ly[r0][e], ly0 = 1.f - ly1;
+            const f32x4 c0 = fma4(ulo[r0][2], ly1, ulo[r0][0] * ly0), c1 = fma4(ulo[r0][3], ly1, ulo[r0][1] * ly0);
+#pragma unroll
+            for (int f = 0; f < 2; ++f) {
+                const float lx1 = u_lx[r0][f], lx0 = 1.f - lx1;
+                const f32x4 v = fma4(c1, lx1, c0 * lx0);
+                split4((ly1 < 0.f || lx1 < 0.f) ? f32x4{0.f, 0.f, 0.f, 0.f} : v, ushi[r0][2 * e + f], uslo[r0][2 * e + f]);
+            }
         }
     };
-    // UPS: round r0's four pixels -> its halo piece (vertical pass, then horizontal, each "a * wa, then one fused
-    // multiply-add", as upsample2x_kernel)
-    auto interp_round = [&](const Src& q, int r0) {
-        auto fma4 = [](f32x4 x, float sc, f32x4 c) { return __builtin_elementwise_fma(x, f32x4{sc, sc, sc, sc}, c); };
-        const float ly1 = up_ly[r0 % 3], ly0 = 1.f - ly1, lx1 = q.lx1, lx0 = 1.f - lx1;
-        const f32x4 c0 = fma4(lo4[r0 % 3][2], ly1, lo4[r0 % 3][0] * ly0), c1 = fma4(lo4[r0 % 3][3], ly1, lo4[r0 % 3][1] * ly0);
-        const f32x4 v = fma4(c1, lx1, c0 * lx0);
-        pre[r0] = ly1 < 0.f ? f32x4{0.f, 0.f, 0.f, 0.f} : v;
+    auto write_ups = [&]() {
+#pragma unroll
+        for (int r0 = 0; r0 < UNR; ++r0)
+            if (u_ok[r0]) {
+#pragma unroll
+                for (int e = 0; e < 2; ++e)
+#pragma unroll
+                    for (int f = 0; f < 2; ++f) {
+                        const unsigned ad = (unsigned)(G::W_BYTES + ((2 * u_by[r0] + e) * IW + 2 * u_bx[r0] + f) * G::S + u_part[r0] * 8);
+                        *(lds_u2*)(L + ad) = ushi[r0][2 * e + f];
+                        *(lds_u2*)(L + ad + G::PLANE) = uslo[r0][2 * e + f];
+                    }
+            }
     };
     auto write_tile = [&]() {       // split halves -> LDS
+        if constexpr (UPS) {
+            write_ups();
+            return;
+        }
 #pragma unroll
         for (int r0 = 0; r0 < G::NR; ++r0)
             if (ld_thread && G::RPR * r0 + rp < IH) {
@@ -303,13 +340,17 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3h_kernel(ConvArgs a) {
     locate(t, cur);
     {   // the first tile: fetched, split and staged before the loop
         const Src q = source(cur, t < t_end);
+        if constexpr (UPS) {
 #pragma unroll
-        for (int r0 = 0; r0 < G::NR; ++r0) {
-            fetch_round(q, r0);
-            if constexpr (UPS) interp_round(q, r0);
+            for (int r0 = 0; r0 < UNR; ++r0) fetch_ups(q, r0);
+#pragma unroll
+            for (int r0 = 0; r0 < UNR; ++r0) interp_ups(r0);
+        } else {
+#pragma unroll
+            for (int r0 = 0; r0 < G::NR; ++r0) fetch_round(q, r0);
+#pragma unroll
+            for (int r0 = 0; r0 < G::NR; ++r0) split4(pre[r0], shi[r0], slo[r0]);
         }
-#pragma unroll
-        for (int r0 = 0; r0 < G::NR; ++r0) split4(pre[r0], shi[r0], slo[r0]);
         write_tile();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's pieces of the filter bank have landed
     }
@@ -367,16 +408,26 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3h_kernel(ConvArgs a) {
             if constexpr (ACC_IN) {
                 if (j >= SH && j - SH < 6) side[(j - SH) / 3][(j - SH) % 3] = bload(pr, po[(j - SH) / 3], 64 * ((j - SH) % 3));
             }
-            if (j >= SH && j - SH < G::NR) fetch_round(qn, j - SH);
             if constexpr (UPS) {
-                if (j >= SH + 2 && j - SH - 2 < G::NR) interp_round(qn, j - SH - 2);      // two chunks after its loads were issued
-            }
+                // the two items' loads at chunks SH, SH + 1; their interpolation and split five chunks later
 #pragma unroll
-            for (int r0 = 0; r0 < G::NR; ++r0)
-                if (j == G::NCH - 1 - (G::NR - 1 - r0) / 3) {
-                    split4(pre[r0], shi[r0], slo[r0]);
-                    asm volatile("" : "+v"(shi[r0]), "+v"(slo[r0]));      // here, not sunk behind the barrier next to its use
+                for (int r0 = 0; r0 < UNR; ++r0) {
+                    if (j == SH + r0) fetch_ups(qn, r0);
+                    if (j == SH + 5 + 2 * r0) {
+                        interp_ups(r0);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) asm volatile("" : "+v"(ushi[r0][e]), "+v"(uslo[r0][e]));      // here, not behind the barrier
+                    }
                 }
+            } else {
+                if (j >= SH && j - SH < G::NR) fetch_round(qn, j - SH);
+#pragma unroll
+                for (int r0 = 0; r0 < G::NR; ++r0)
+                    if (j == G::NCH - 1 - (G::NR - 1 - r0) / 3) {
+                        split4(pre[r0], shi[r0], slo[r0]);
+                        asm volatile("" : "+v"(shi[r0]), "+v"(slo[r0]));      // here, not sunk behind the barrier next to its use
+                    }
+            }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int p = 0; p < 3; ++p) {
