@@ -238,7 +238,8 @@ int rvdd_timer_stop_ms(rvdd_t* h, void* stream, float* ms);   /* synchronises */
 
 /* Kernel A/B hook: time `iters` back-to-back launches of the 48->48 3x3 conv +
  * ReLU (the dominant kernel) on the handle's own level-`level` maps with code
- * variant `variant`; *ms = mean milliseconds per launch.  Synchronises. */
+ * variant `variant` (0..2: code variants of the direct f32-MFMA kernel, 3: the Winograd f32-MFMA kernel, 4: the
+ * split-f16 kernel, the default of the convunet); *ms = mean milliseconds per launch.  Synchronises. */
 int rvdd_debug_conv_bench(rvdd_t* h, int32_t variant, int32_t level, int32_t iters, float* ms, void* stream);
 
 const char* rvdd_version(void);
