@@ -19,11 +19,16 @@ afterwards and, with --collate-outputs, one all-gather of the output frames
   N > 1   config C5 (B = 8 sequences of 90 frames per GPU: 64 sequences on 8 GPUs), weak scaling;
           --scaling strong fixes the total at --sequences (64) instead and runs each rank's share in groups of B
 
-The JSON line carries `roofline` for the dominant kernel (the 48->48 3x3 conv on
-the f32 matrix cores, peak 157.3 TFLOP/s), measured with HIP events around a
-uniform sample of its launches inside the timed region, and `cpu_baseline`: the
-CPU oracle (oracle/rvdd_oracle.py, a torch-CPU restatement of the reference's
-PyTorch path) timed on this host's cores on a bounded sample of the same workload.
+The JSON line carries `roofline` for the dominant kernel (the 48->48 3x3 conv; by
+default on the F16 matrix pipe with split f32 operands, dense peak 2.5 PFLOP/s),
+measured with HIP events around a uniform sample of its launches inside the timed
+region -- `achieved` / `frac` are ALGORITHMIC flops, the executed-MFMA
+and HBM fractions sit beside them --, `cpu_baseline`: the CPU oracle
+(oracle/rvdd_oracle.py, a torch-CPU restatement of the reference's PyTorch path)
+timed on this host's cores on a bounded sample of the same workload, and
+`other_configs`: a short run of each of BASELINE.json's other configurations
+(C3, C4, C5's per-GPU share, C1) after the timed region, so that the driver's
+record holds them too.
 """
 import argparse
 import json
@@ -102,6 +107,9 @@ def parse_args(argv=None):
                     help="timed frames of a third CPU sample at min(affinity, cgroup quota, 64) threads, when that exceeds 16 (0 = skip)")
     ap.add_argument("--no-exact-ab", action="store_true",
                     help="skip the second, untimed-region-external run on the exact-f32-product kernels (one GPU only)")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the short runs of the other configurations after the timed region (one GPU, default config only)")
+    ap.add_argument("--other-steps", type=int, default=2, help="timed steps of each of those short runs")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--all-kernel-events", action="store_true",
                     help="diagnostic: bracket EVERY launch of every kernel (costs ~6 %% of the frame rate); "
@@ -196,6 +204,55 @@ def host_cpu_share():
     except OSError:
         pass
     return info
+
+
+def quick_config(name, steps, dev_index):
+    """A short run of another configuration at its default batch: 1 warm-up step, `steps` timed steps (wall clock between
+    device synchronisations), HIP events around every 3rd launch of its dominant kernel.  Inputs synthetic, resident in HBM."""
+    import torch
+    from safetensors.torch import load_file
+    from rvdd_release_amd import synth
+    from rvdd_release_amd.runtime import RvddRuntime
+    arch, stem, fut, iso, H, W, T, B, gflop = CONFIGS[name]
+    dev = torch.device("cuda", dev_index)
+    rt = RvddRuntime(arch, fut, B, H, W, dev_index)
+    rt.load_state_dict(load_file(os.path.join(REPO, "weights", stem + ".safetensors")))
+    seqs = [synth.make_sequence(T, H, W, iso=iso, seed=1000 * int(name[1]) + b, device=str(dev)) for b in range(B)]
+    raw = torch.stack([s.raw for s in seqs], 1).contiguous()
+    fprev = torch.stack([s.flow_prev for s in seqs], 1).contiguous()
+    fnext = torch.stack([s.flow_next for s in seqs], 1).contiguous() if fut else None
+    del seqs
+    n_out = T - 1 - fut
+    out = torch.empty(B, 3, H, W, dtype=torch.float32, device=dev)
+
+    def one():
+        rt.reset()
+        for t in range(1, T - fut):
+            rt.step(raw[t - 1] if t == 1 else None, raw[t], raw[t + 1] if fut else None, fprev[t],
+                    fnext[t] if fut else None, out=out)
+
+    one()
+    torch.cuda.synchronize()
+    rt.profile_select(DOMINANT[arch], EVENT_STRIDE)
+    rt.profile_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        one()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    prof = [p for p in rt.profile_read() if p["launches"] and p["name"] == DOMINANT[arch]]
+    rt.profile_enable(False)
+    rt.close()
+    res = {"workload": f"{name}: {DESCR[name]}", "value": round(steps * n_out * B / el, 2), "unit": "frames/s",
+           "ms_per_step": round(1e3 * el / steps, 3), "steps": steps, "warmup": 1, "sequences_in_lockstep": B,
+           "output_frames_per_step": n_out * B, "finite": bool(torch.isfinite(out).all())}
+    if prof:
+        res["dominant_kernel"] = prof[0]["name"]
+        res["avg_launch_us"] = round(1e3 * prof[0]["ms"] / prof[0]["launches"], 2)
+        res["launches_sampled"] = prof[0]["launches"]
+    del raw, fprev, fnext, out
+    torch.cuda.empty_cache()
+    return res
 
 
 def main():
@@ -370,13 +427,20 @@ def main():
         if dom == "convblock_kernel" and not split:
             factor, executed = 1.0, k["tflops"]
         peak = F16_PEAK_TFLOPS if split else FP32_PEAK_TFLOPS
-        roofline = {"bound": "mfma", "kernel": dom, "achieved": round(executed, 2), "peak": peak,
-                    "unit": "TFLOP/s", "frac": round(executed / peak, 4), "traffic": traffic,
-                    "traffic_source": traffic_src,
+        # `achieved` / `frac`: ALGORITHMIC flops of the layer (the direct conv's 2*9*Cin*Cout per pixel) over the
+        # measured launch time -- the contract's convention; `frac_executed_mfma` counts the MFMA flops the kernel issues
+        # (split products, K padding; Winograd executes fewer than algorithmic) and is the matrix pipe's utilisation;
+        # `frac_hbm` is the same launch against the 8 TB/s HBM roof
+        roofline = {"bound": "mfma", "kernel": dom, "achieved": round(k["tflops"], 2), "peak": peak,
+                    "unit": "TFLOP/s", "frac": round(k["tflops"] / peak, 4),
+                    "frac_algorithmic": round(k["tflops"] / peak, 4),
+                    "executed_mfma_tflops": round(executed, 2), "frac_executed_mfma": round(executed / peak, 4),
+                    "frac_hbm": round(k["gbps"] / 8000.0, 4), "hbm_peak_gbps": 8000.0,
+                    "traffic": traffic, "traffic_source": traffic_src,
                     "algorithmic_bytes_per_launch": round(k["bytes_per_launch"]),
                     "mfma_dtype": "f16 (f32 operands split hi + lo, f32 accumulation)" if split else "f32",
                     "hbm_gbps_algorithmic": round(k["gbps"], 1),
-                    "what_is_counted": ("F16 MFMA flops the kernel executes in its two 1x1 convs (114 MFMAs per 16 pixels; the depth-wise 7x7, "
+                    "what_is_executed": ("F16 MFMA flops the kernel executes in its two 1x1 convs (114 MFMAs per 16 pixels; the depth-wise 7x7, "
                                         "LayerNorm and GELU run on the vector ALU and bound the kernel: DESIGN.md 4.3c)")
                                        if split and dom == "convblock_kernel" else
                                        "F16 MFMA flops the kernel executes: 3 MFMAs per product (hi.hi, hi.lo, lo.hi), K 432 padded to 448"
@@ -409,6 +473,18 @@ def main():
                  "what": "every output frame of the last group of sequences, default (split-f16 matrix path) against exact-f32 products"}
         rt2.close()
         del outs2, d
+
+    # ---- the other configurations of BASELINE.json, a short run each (outside the timed region): C3, C4, C5's per-GPU
+    # share and C1 at their default batch, so that the driver's record holds more than the headline config
+    other = None
+    if world == 1 and not stub and not rehearsal and not args.no_other_configs and not args.online_flow and config == "C2" \
+            and not args.batch and not args.frames:
+        other = {}
+        for name in ("C3", "C4", "C5", "C1"):
+            try:
+                other[name] = quick_config(name, args.other_steps, dev_index)
+            except Exception as e:          # a failure here must not take the headline line with it
+                other[name] = {"error": f"{type(e).__name__}: {e}"}
 
     # ---- CPU baseline: the oracle on this host's cores, bounded sample, sequence 0
     cpu = None
@@ -480,11 +556,14 @@ def main():
         data += " (REHEARSAL: all ranks on one GPU, not a measurement)"
     if stub:
         data += " (STUB: CPU stand-in for the HIP runtime, launcher/collective test only, not a measurement)"
+    split_path = (_CONV.startswith("conv3x3h") if not arch.startswith("next") else
+                  (os.environ.get("RVDD_NEXT_SPLIT") != "0" and os.environ.get("RVDD_NEXT_FUSED") != "0"))
     line = {
         "metric": "frames/sec (whole job), recurrent video denoise+demosaic inference", "value": round(fps, 3),
         "unit": "frames/s", "n_gpus": world, "n_ranks_seen": n_ranks_seen, "distributed": distributed, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": args.scaling,
-        "vs_baseline": None, "dtype": "f32", "data": data,
+        "vs_baseline": None,
+        "dtype": "f32 (products as 3 split-f16 MFMAs, f32 accumulation)" if split_path else "f32", "data": data,
         "arithmetic": ("f32 in, f32 out, f32 accumulation; the convunet's 48-channel 3x3 convs multiply on the F16 matrix pipe with "
                        "every f32 operand split into two f16 halves (3 MFMAs per product): as close to the reference as the "
                        "f32-MFMA kernels (tests/split_precision_study.py, DESIGN.md 4.1c); RVDD_CONV=f32 runs those instead")
@@ -503,7 +582,8 @@ def main():
         "algorithmic_gflop_per_frame": gflop_frame,
         "whole_path_algorithmic_tflops": round(fps / world * gflop_frame / 1e3, 2),
         "task_psnr_db": round(psnr_mean, 3),
-        "roofline": roofline, "cpu_baseline": cpu, "exact_f32_kernels": exact, "collate": collate, "kernels": kernels,
+        "roofline": roofline, "cpu_baseline": cpu, "exact_f32_kernels": exact, "other_configs": other, "collate": collate,
+        "kernels": kernels,
     }
     if cpu:
         line["gpu_over_cpu"] = round(fps / cpu["value"], 1)

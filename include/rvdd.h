@@ -184,13 +184,15 @@ int rvdd_srgb_metrics(rvdd_t* h, const uint8_t* a, const uint8_t* b, int32_t n, 
  *              Not defined with feature recurrence (the reference fails on the shapes there): error.
  *   "prev_noisy_frame" (--prev_noisy_frame, :33, :335-337): the frame handed to the next step as "previous" is the
  *              demosaiced NOISY current frame, not the denoised one (the feature recurrence is unaffected).
- *   "conv_kernel": which kernel runs the convunet's 3x3 convs.  0 (default) = the 48-channel layers on the F16 matrix
- *              pipe with each f32 operand split into two f16 halves, three MFMAs per product, f32 accumulation
- *              (conv3x3h.hip: as close to the reference as the f32 kernels; activations
- *              must stay below 65504 in magnitude, beyond that the split saturates), the 16-channel first layer and
- *              UpConv's fused upsample on an f32-MFMA kernel chosen by launch size; 1 = the direct f32 kernel
- *              everywhere; 2 = the Winograd f32 kernel everywhere; 4 = f32 kernels chosen by launch size (1, 2, 4:
- *              exact-f32 products, the A/B reference, about 0.8 of the default's frame rate at 720p).
+ *   "conv_kernel": which kernel runs the convunet's 3x3 convs.  0 (default) = EVERY 3x3 conv of the net -- the
+ *              16-channel first layer and UpConv's fused upsample included -- on the F16 matrix pipe with each f32
+ *              operand split into two f16 halves, three MFMAs per product, f32 accumulation (conv3x3h.hip: as close
+ *              to the reference as the f32 kernels).  The f16 exponent range is not a limit
+ *              of the path: every map carries its max |x| per sequence and is multiplied by a power of two before
+ *              the split (block floating point, exact), so frames of any finite magnitude keep fp32 semantics
+ *              (tests/test_gpu_parity.py::test_split_path_any_magnitude).  1 = the direct f32 kernel everywhere;
+ *              2 = the Winograd f32 kernel everywhere; 4 = f32 kernels chosen by launch size (1, 2, 4: exact-f32
+ *              products, the A/B reference, about 0.7 of the default's frame rate at 720p).
  *   "seq_major": 1 = the full-resolution stages of the convunet run one sequence at a time (measured slower; off).
  *   "fuse_upsample": 0 = UpConv's bilinear x2 upsample runs as its own kernel instead of inside the Winograd patch
  *              load of the conv behind it (default 1; same bits either way).
@@ -198,13 +200,17 @@ int rvdd_srgb_metrics(rvdd_t* h, const uint8_t* a, const uint8_t* b, int32_t n, 
  *   "next_fused": 0 = ConvNeXtUnet's ConvBlock (networks/new_unet.py:74-103) as two kernels (depth-wise + LayerNorm,
  *               then the MLP) instead of the one fused kernel: the A/B reference; same results to a few ulp.
  *   "next_split": 0 = the fused ConvBlock multiplies its two 1x1 convs on the f32 matrix pipe (exact-f32 products) instead
- *               of the F16 pipe with split f32 operands (the default, as "conv_kernel" 0; the A/B reference).
+ *               of the F16 pipe with split f32 operands (the default, as "conv_kernel" 0; the A/B reference).  The split
+ *               operands are bounded by the block's LayerNorm whatever the frames are; a block whose weights would let
+ *               them leave the f16 range (checked at rvdd_finalize_weights) runs the f32 form by itself.
  *   "next_pipe": 0 = the fused ConvBlock runs its three phases one after the other in all eight waves of a workgroup
  *               (convblock_kernel) instead of as a pipeline over tiles -- depth-wise conv and LayerNorm of the next tile on
  *               four waves beside the MLP of the current one on the other four (convblock_pipe_kernel, the default with
  *               next_split; same bits either way).
  *   "next_pool": 0 = with next_fused, MaxPool2d(2) in front of a DownConv (new_unet.py:200-204) as its own kernel instead
  *               of the fused block's epilogue (default 1; same bits either way).
+ *   "block_fp": 0 = the split-f16 convs split their operands without the per-map power of two (the A/B reference of the block
+ *               floating point; right only while every activation stays within 2^-14 .. 65504).  Default 1.
  *   "wino4":    1 / 2 = the plain and two-pass 48 -> 48 3x3 convs on the Winograd F(4x4,3x3) kernel where a launch has
  *               at least 400 units / at every size (measured slower than F(2x2,3x3) on MI355X; off; a few ulp apart).
  *   "next_streams": 1 = with next_fused = 0 and a batch of at least two sequences, the two halves of the batch run as

@@ -14,6 +14,13 @@
 // fixtures: 2.3e-6 from the reference's frames (the f32 kernels of this library: 3e-6); f16 overflows at 65504, the
 // largest activation of those runs is 8.8, and the round-toward-zero split saturates instead of producing infinities.
 //
+// Block floating point (rvdd_internal.h, amax_shift): the f16 exponent range is NOT a limit of this kernel.  Every input
+// map carries words per sequence with the bits of its max |x| (written by the kernel that produced the map -- this
+// kernel, netin_kernel; the warped features share the words of the features they were gathered from); where that maximum
+// lies outside [2^-6, 2^12) the halo values are multiplied by the power of two that puts it into [2^3, 2^4) before they are split, and the sums are scaled back by its inverse in the epilogue's one fma --
+// both exact.  Frames of any finite magnitude (1e5 times brighter, 2^-12 times dimmer than the documented [-1, 1]) keep
+// the 22 significand bits of the split (tests/test_gpu_parity.py::test_split_path_any_magnitude).
+//
 // Orientation as conv3x3.hip: D[cout][pixel] += W[cout][k] X[k][pixel]; lane l holds pixel l & 15 and, per MFMA, the
 // eight consecutive k of group l >> 4.  k runs (tap, channel): 8-channel group G = 4 chunk + (l >> 4) is channels
 // 8 (G % 6) .. +7 of tap G / 6 (CIN = 48: 54 groups, 14 chunks of 32, the last two groups zero filters).
@@ -57,7 +64,7 @@ struct HGeo {
     static constexpr int PLANE = IH * IW * HI;
     static constexpr int W_BYTES = NCH * 3 * 2 * 1024;
     static constexpr int I_BYTES = 2 * PLANE;
-    static constexpr int P_FLOATS = 48 + 3 * 48 + 4;         // bias, PostConvs[1] weights and bias
+    static constexpr int P_FLOATS = 48 + 3 * 48 + 4 + 8;     // bias, PostConvs[1] weights and bias, one word per wave (amax reduction)
     static constexpr int LDS_BYTES = W_BYTES + I_BYTES + P_FLOATS * 4;
     static constexpr int SEG = CIN / 4;                      // 16-B pieces of one f32 pixel
     static constexpr int ROWSEG = IW * SEG;                  // ... of one halo row
@@ -73,13 +80,19 @@ __device__ __forceinline__ void bstore(__amdgpu_buffer_rsrc_t r, unsigned off, f
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, off, 0, 0);
 }
 
-// x (four f32) -> hi, lo (four f16 each, as two dwords): hi toward zero (never an infinity), lo = x - hi to nearest
-__device__ __forceinline__ void split4(f32x4 x, u32x2& hi, u32x2& lo) {
+// x (four f32; SCALED: sc x, sc = the map's power-of-two scale) -> hi, lo (four f16 each, as two dwords): hi toward zero
+// (never an infinity), lo = x - hi to nearest.  x - hi as ONE v_fma_mix_f32 per value (the f16 half read in place); x comes
+// from a buffer load or an interpolation, never straight out of an MFMA (inline asm behind an MFMA gets no wait states).
+// Issue cost per four values (tools/valu_rate_bench.hip, profiles/r04_valu_rate_bench.txt): 37 cycles; the scaling adds two
+// v_pk_mul_f32 (10 cycles), which is why a map that needs no scaling (amax_shift) takes the unscaled form.  The same split
+// made of v_fma_mixlo/hi_f16 -- scale, subtraction and rounding in one instruction per half -- is 8 instructions of 7.4
+// cycles each: slower (measured in the kernel too).
+template <bool SCALED>
+__device__ __forceinline__ void split4(f32x4 x, float sc, u32x2& hi, u32x2& lo) {
+    if constexpr (SCALED) x = x * sc;
     const fp16x2 h01 = __builtin_amdgcn_cvt_pkrtz(x[0], x[1]);
     const fp16x2 h23 = __builtin_amdgcn_cvt_pkrtz(x[2], x[3]);
     const unsigned u01 = __builtin_bit_cast(unsigned, h01), u23 = __builtin_bit_cast(unsigned, h23);
-    // x - hi as ONE v_fma_mix_f32 per value (the f16 half read in place); x comes from a buffer load or an interpolation,
-    // never straight out of an MFMA (inline asm behind an MFMA gets no wait states)
     float r0, r1, r2, r3;
     asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(u01), "v"(x[0]));
     asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(u01), "v"(x[1]));
@@ -90,7 +103,6 @@ __device__ __forceinline__ void split4(f32x4 x, u32x2& hi, u32x2& lo) {
     hi = u32x2{u01, u23};
     lo = u32x2{__builtin_bit_cast(unsigned, l01), __builtin_bit_cast(unsigned, l23)};
 }
-
 struct TilePos {
     int b, y0, x0;
 };
@@ -139,24 +151,6 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3h_kernel(ConvArgs a) {
     const int n = lane & 15;
     const int g = lane >> 4;
 
-    {   // split filter bank -> LDS (linear copy of the host arrangement), every workgroup starting at another piece
-        __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, G::W_BYTES, 0x00020000);
-        constexpr int NP = G::W_BYTES / 1024;
-        const int rot = (int)((blockIdx.x * 37u) % (unsigned)NP);
-        for (int i = wave; i < NP; i += NTHREADS / 64) {
-            int k = i + rot;
-            if (k >= NP) k -= NP;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lds_void*)(smem + k * 1024), 16, (unsigned)(k * 1024 + lane * 16), 0, 0, 0);
-        }
-    }
-    if (tid < kF) Pl[tid] = a.bias[tid];
-    if constexpr (EPI == EPI_RELU_OUT3) {
-        if (tid >= 64 && tid < 64 + 3 * kF) Pl[kF + tid - 64] = a.w3[tid - 64];
-        else if (tid >= 256 && tid < 259) Pl[4 * kF + tid - 256] = a.b3[tid - 256];
-    }
-    // (no wait here: the bank's DMA runs beside the first tile's halo fetch; both are awaited in front of the tile loop,
-    // whose first barrier publishes bank, parameters and tile together)
-
     // ---- tiles of this workgroup: the workgroups of one XCD (blockIdx & 7) share a contiguous eighth of the tile list,
     // walked side by side, so that the halo columns two neighbours both read meet in that XCD's L2
     int t, t_end, t_step;
@@ -178,6 +172,62 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3h_kernel(ConvArgs a) {
         p.y0 = ty * TH;
         p.x0 = (rr - ty * a.tiles_x) * TW;
     };
+
+    // block floating point: the power of two for a sequence of the input map and its inverse (1, 1 without amax words).
+    // The word is requested with the next tile's addresses, IN FRONT of its halo loads, and looked at where the first of those
+    // loads is split: the wait the compiler counts for it there is the wait for the halo data anyway.  (Looked at where it is
+    // requested it cost 4 % of the layer: as a vector load an s_waitcnt vmcnt(0) in the chunk loop -- a drain of the loads and
+    // stores in flight --, as a scalar load an s_waitcnt lgkmcnt(0) that also waits for the fragment reads.)
+    unsigned ab_nxt = 0;
+    auto amax_fetch = [&](int b, bool live) {      // lane l < kAmaxLines: word l of the sequence; no words / no tile: 0
+        // (a plain load from a clamped address and a select: a buffer descriptor of its own cost the kernel four scalar
+        // registers it does not have -- the two-pass and fused-upsample instantiations spilled eight)
+        const bool ok = a.amax_in && live && b < a.B;
+        const unsigned* words = a.amax_in ? a.amax_in : reinterpret_cast<const unsigned*>(a.bias);      // (never read through when null)
+        const unsigned v = words[ok ? (b * kAmaxSeqWords + (lane & (kAmaxLines - 1)) * kAmaxLineWords) : 0];
+        ab_nxt = (ok && lane < kAmaxLines) ? v : 0u;
+    };
+    auto scale_from = [&](unsigned bits, float& sc, float& inv) {
+        const int k = amax_shift(amax_lines_max(bits));
+        sc = pow2f(k);
+        inv = pow2f(-k);
+    };
+    // Does any sequence this workgroup works on need the scaling at all?  With frames in the reference's [-1, 1] none does
+    // (amax_shift: 0 inside [2^-6, 2^12)), and the tile loop then runs in its second form below: no per-tile word, no
+    // multiplication in the split (two v_pk_mul_f32 per four values: 1.5 % of the layer), the filters' scale alone in the
+    // epilogue.  Decided once, per workgroup.  The words (of up to four sequences; a workgroup whose tiles span more takes the
+    // scaled form) are requested BEFORE the filter bank's DMA -- vmcnt retires in order: behind it the answer would wait for all
+    // 84 KiB -- and looked at behind it, when they have long arrived.
+    unsigned ab_first[4] = {0, 0, 0, 0};
+    bool many_seqs = false;
+    if (a.amax_in && t < t_end) {
+        const int b_first = t / tiles_per_img, b_last = (t + (t_end - 1 - t) / t_step * t_step) / tiles_per_img;
+        many_seqs = b_last - b_first >= 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            amax_fetch(b_first + i, b_first + i <= b_last);
+            ab_first[i] = ab_nxt;
+        }
+    }
+
+    {   // split filter bank -> LDS (linear copy of the host arrangement), every workgroup starting at another piece
+        __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, G::W_BYTES, 0x00020000);
+        constexpr int NP = G::W_BYTES / 1024;
+        const int rot = (int)((blockIdx.x * 37u) % (unsigned)NP);
+        for (int i = wave; i < NP; i += NTHREADS / 64) {
+            int k = i + rot;
+            if (k >= NP) k -= NP;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lds_void*)(smem + k * 1024), 16, (unsigned)(k * 1024 + lane * 16), 0, 0, 0);
+        }
+    }
+    if (tid < kF) Pl[tid] = a.bias[tid];
+    if constexpr (EPI == EPI_RELU_OUT3) {
+        if (tid >= 64 && tid < 64 + 3 * kF) Pl[kF + tid - 64] = a.w3[tid - 64];
+        else if (tid >= 256 && tid < 259) Pl[4 * kF + tid - 256] = a.b3[tid - 256];
+    }
+    // (no wait here: the bank's DMA runs beside the first tile's halo fetch; both are awaited in front of the tile loop,
+    // whose first barrier publishes bank, parameters and tile together)
+
 
     // ---- halo fetch: thread -> (row rp of the round, halo column hx, 16-B piece `part`), the same for every tile
     const int rp = tid / G::ROWSEG;
@@ -256,7 +306,8 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3h_kernel(ConvArgs a) {
         ulo[r0][3] = bload(q.r, any ? (unsigned)((rr1 * iw + cc1) * (CIN * 4)) + p16 : 0x80000000u);
     };
     // vertical pass, then horizontal, each "a * wa, then one fused multiply-add": upsample2x_kernel's expressions in its order
-    auto interp_ups = [&](int r0) {
+    auto interp_ups = [&](int r0, float sc_st, auto scaled_tag) {
+        constexpr bool SC_ = decltype(scaled_tag)::value;
         auto fma4 = [](f32x4 x, float sc, f32x4 c) { return __builtin_elementwise_fma(x, f32x4{sc, sc, sc, sc}, c); };
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
@@ -266,7 +317,7 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3h_kernel(ConvArgs a) {
             for (int f = 0; f < 2; ++f) {
                 const float lx1 = u_lx[r0][f], lx0 = 1.f - lx1;
                 const f32x4 v = fma4(c1, lx1, c0 * lx0);
-                split4((ly1 < 0.f || lx1 < 0.f) ? f32x4{0.f, 0.f, 0.f, 0.f} : v, ushi[r0][2 * e + f], uslo[r0][2 * e + f]);
+                split4<SC_>((ly1 < 0.f || lx1 < 0.f) ? f32x4{0.f, 0.f, 0.f, 0.f} : v, sc_st, ushi[r0][2 * e + f], uslo[r0][2 * e + f]);
             }
         }
     };
@@ -312,17 +363,11 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3h_kernel(ConvArgs a) {
     asm volatile("" : "+v"(abase[0]), "+v"(abase[1]));
     h8 Af[2][3][2], Bf[2][2][2];
     auto read_frags = [&](int buf, int j) {
-#ifdef RVDD_EXP_NO_B
-        if (j < 2)       // experiment: pixel fragments read for the first two chunks only
-#endif
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
             for (int hl = 0; hl < 2; ++hl)
                 Bf[buf][nt][hl] = __builtin_bit_cast(h8, *(lds_f4*)(L + boff[j] + nt * IW * G::S + hl * G::PLANE));
-#ifdef RVDD_EXP_NO_A
-        if (j < 2)       // experiment (tools/conv3x3h_bench.hip): filter fragments read for the first two chunks only
-#endif
 #pragma unroll
         for (int mt = 0; mt < 3; ++mt)
 #pragma unroll
@@ -334,22 +379,45 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3h_kernel(ConvArgs a) {
 
     const unsigned map_bytes = (unsigned)(a.H * a.W * kF * 4);
     const unsigned out_bytes = (unsigned)(a.Hout * a.Wout * kF * 4);
-    const float ws = a.wscale;
 
+    float sc_nxt = 1.f, inv_cur = 1.f, inv_nxt = 1.f;
+    float amx = 0.f;        // max |x| of what this wave has stored for sequence amx_b
+    int amx_b = -1, pend_b = -1;
+    unsigned* Rl = reinterpret_cast<unsigned*>(Pl + G::P_FLOATS - 8);      // one word per wave
+    auto amax_send = [&](int b) {      // wave 0, behind a barrier: the workgroup's maximum for sequence b, to one of its kAmaxLines lines
+        unsigned t = lane < NTHREADS / 64 ? Rl[lane] : 0u;
+        t = amax_lines_max(t);
+        if (lane == 0 && t) atomicMax(a.amax_out + (size_t)b * kAmaxSeqWords + (blockIdx.x % kAmaxLines) * kAmaxLineWords, t);
+    };
+
+    bool any_scaled = many_seqs;
+    if (a.amax_in) {
+        unsigned need = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) need |= (unsigned)amax_shift(amax_lines_max(ab_first[i]));
+        any_scaled = any_scaled || need != 0;
+    }
+
+    auto tile_loop = [&](auto scaled_tag) {
+    constexpr bool SC = decltype(scaled_tag)::value;
     TilePos cur, nxt;
     locate(t, cur);
     {   // the first tile: fetched, split and staged before the loop
+        if constexpr (SC) {
+            amax_fetch(cur.b, t < t_end);
+            scale_from(ab_nxt, sc_nxt, inv_cur);
+        }
         const Src q = source(cur, t < t_end);
         if constexpr (UPS) {
 #pragma unroll
             for (int r0 = 0; r0 < UNR; ++r0) fetch_ups(q, r0);
 #pragma unroll
-            for (int r0 = 0; r0 < UNR; ++r0) interp_ups(r0);
+            for (int r0 = 0; r0 < UNR; ++r0) interp_ups(r0, sc_nxt, scaled_tag);
         } else {
 #pragma unroll
             for (int r0 = 0; r0 < G::NR; ++r0) fetch_round(q, r0);
 #pragma unroll
-            for (int r0 = 0; r0 < G::NR; ++r0) split4(pre[r0], shi[r0], slo[r0]);
+            for (int r0 = 0; r0 < G::NR; ++r0) split4<SC>(pre[r0], sc_nxt, shi[r0], slo[r0]);
         }
         write_tile();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's pieces of the filter bank have landed
@@ -362,6 +430,8 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3h_kernel(ConvArgs a) {
     __amdgpu_buffer_rsrc_t orr_prev = __builtin_amdgcn_make_buffer_rsrc((void*)a.out, 0, 0, 0x00020000);
 #pragma unroll
     for (int i = 0; i < NOUT; ++i) outv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // one 16-B piece of the previous tile's results: they ride between the chunks of the current tile's MFMA loop
+    auto store_prev = [&](int i) { bstore(orr_prev, so_prev[EPI == EPI_POOL ? 0 : i / 3] + 64 * (i % 3), outv[i]); };
     STAMP_DECL;
 #pragma unroll 1
     while (t < t_end) {
@@ -379,6 +449,7 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3h_kernel(ConvArgs a) {
         auto addresses = [&]() {
             locate(t + t_step, nxt);
             qn = source(nxt, t + t_step < t_end);
+            if constexpr (SC) amax_fetch(nxt.b, t + t_step < t_end);
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
                 const bool ok = yy0 + nt < a.H && xx < a.W;
@@ -404,9 +475,12 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3h_kernel(ConvArgs a) {
             const int cb = j & 1;
             if (j + 1 < G::NCH) read_frags(cb ^ 1, j + 1);
             if (j == SH) addresses();
-            if (j >= SH && j - SH < NOUT) bstore(orr_prev, so_prev[EPI == EPI_POOL ? 0 : (j - SH) / 3] + 64 * ((j - SH) % 3), outv[j - SH]);
+            if (j >= SH && j - SH < NOUT) store_prev(j - SH);
             if constexpr (ACC_IN) {
                 if (j >= SH && j - SH < 6) side[(j - SH) / 3][(j - SH) % 3] = bload(pr, po[(j - SH) / 3], 64 * ((j - SH) % 3));
+            }
+            if constexpr (SC) {
+                if (j == (UPS ? SH + 5 : G::NCH - 1 - (G::NR - 1) / 3)) scale_from(ab_nxt, sc_nxt, inv_nxt);      // the chunk of the first split
             }
             if constexpr (UPS) {
                 // the two items' loads at chunks SH, SH + 1; their interpolation and split five chunks later
@@ -414,7 +488,7 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3h_kernel(ConvArgs a) {
                 for (int r0 = 0; r0 < UNR; ++r0) {
                     if (j == SH + r0) fetch_ups(qn, r0);
                     if (j == SH + 5 + 2 * r0) {
-                        interp_ups(r0);
+                        interp_ups(r0, sc_nxt, scaled_tag);
 #pragma unroll
                         for (int e = 0; e < 4; ++e) asm volatile("" : "+v"(ushi[r0][e]), "+v"(uslo[r0][e]));      // here, not behind the barrier
                     }
@@ -424,7 +498,7 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3h_kernel(ConvArgs a) {
 #pragma unroll
                 for (int r0 = 0; r0 < G::NR; ++r0)
                     if (j == G::NCH - 1 - (G::NR - 1 - r0) / 3) {
-                        split4(pre[r0], shi[r0], slo[r0]);
+                        split4<SC>(pre[r0], sc_nxt, shi[r0], slo[r0]);
                         asm volatile("" : "+v"(shi[r0]), "+v"(slo[r0]));      // here, not sunk behind the barrier next to its use
                     }
             }
@@ -443,12 +517,14 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3h_kernel(ConvArgs a) {
             __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
-        for (int j = G::NCH - SH; j < NOUT; ++j) bstore(orr_prev, so_prev[EPI == EPI_POOL ? 0 : j / 3] + 64 * (j % 3), outv[j]);      // CIN 16: five chunks
+        for (int j = G::NCH - SH; j < NOUT; ++j) store_prev(j);      // CIN 16: five chunks
         STAMP(3);
 
         // ---- epilogue: scale back, bias / partial sums, activation; the 48-channel results wait in registers for the
         // next tile's chunks
         f32x4 v[2][3];
+        float m3 = 0.f;        // EPI_RELU_OUT3: max |output frame| over this lane's two pixels
+        const float ws = SC ? a.wscale * inv_cur : a.wscale;      // the filters' and the map's powers of two, undone together
 #pragma unroll
         for (int mt = 0; mt < 3; ++mt) {
             const f32x4 bias = *reinterpret_cast<const f32x4*>(Pl + 16 * mt + 4 * g);
@@ -469,6 +545,7 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3h_kernel(ConvArgs a) {
                 }
         } else {
             float o3[2][3];
+            m3 = 0.f;
             if constexpr (EPI == EPI_RELU_OUT3) {
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt) o3[nt][0] = o3[nt][1] = o3[nt][2] = 0.f;
@@ -508,6 +585,8 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3h_kernel(ConvArgs a) {
                         q += __shfl_xor(q, 32);
                         tq[c] = q + Pl[4 * kF + c];
                     }
+                    // (the output frame's maximum joins the features' in this launch's words: the next step's input bound reads them)
+                    if (yy0 + nt < a.H && xx < a.W) m3 = fmaxf(m3, fmaxf(fmaxf(fabsf(tq[0]), fabsf(tq[1])), fabsf(tq[2])));
                     if (g == 0 && yy0 + nt < a.H && xx < a.W) {
                         const size_t pidx = (size_t)(yy0 + nt) * a.W + xx;
 #pragma unroll
@@ -518,12 +597,35 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3h_kernel(ConvArgs a) {
                 }
             }
         }
+        if (a.amax_out) {      // max |x| of what this tile stores (pixels outside the map do not count), per sequence
+            if (cur.b != amx_b) {          // (every wave of the workgroup is on the same tile: they all come through here together)
+                if (amx_b >= 0) {
+                    const unsigned wm = wave_max_u32(__float_as_uint(amx));
+                    if (lane == 0) Rl[wave] = wm;
+                    pend_b = amx_b;        // wave 0 sends it off behind the barrier below
+                }
+                amx = 0.f;
+                amx_b = cur.b;
+            }
+            float m0 = 0.f, m1 = 0.f;
+#pragma unroll
+            for (int i = 0; i < NOUT; ++i) {
+                const float mi = fmaxf(fmaxf(fabsf(outv[i][0]), fabsf(outv[i][1])), fmaxf(fabsf(outv[i][2]), fabsf(outv[i][3])));
+                if (EPI == EPI_POOL || i < 3) m0 = fmaxf(m0, mi);
+                else m1 = fmaxf(m1, mi);
+            }
+            amx = fmaxf(fmaxf(amx, m3), fmaxf(so[0] == 0x80000000u ? 0.f : m0, so[1] == 0x80000000u ? 0.f : m1));
+        }
         so_prev[0] = so[0];
         so_prev[1] = so[1];
         orr_prev = __builtin_amdgcn_make_buffer_rsrc((void*)(a.out + (size_t)cur.b * a.Hout * a.Wout * kF), 0, out_bytes, 0x00020000);
         STAMP(4);
         __syncthreads();       // every wave has read its last fragment of this tile: the next one may be staged
         STAMP(5);
+        if (pend_b >= 0) {     // the finished sequence's maximum: one atomic for the workgroup
+            if (wave == 0) amax_send(pend_b);
+            pend_b = -1;
+        }
         write_tile();
         STAMP(6);
 #ifdef RVDD_STAMPS
@@ -531,11 +633,21 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3h_kernel(ConvArgs a) {
 #endif
         t += t_step;
         cur = nxt;
+        inv_cur = inv_nxt;
+    }
+    if (a.amax_out && amx_b >= 0) {
+        const unsigned wm = wave_max_u32(__float_as_uint(amx));
+        if (lane == 0) Rl[wave] = wm;
+        __syncthreads();
+        if (wave == 0) amax_send(amx_b);
     }
     // the last tile's results
 #pragma unroll
-    for (int j = 0; j < NOUT; ++j) bstore(orr_prev, so_prev[EPI == EPI_POOL ? 0 : j / 3] + 64 * (j % 3), outv[j]);
+    for (int j = 0; j < NOUT; ++j) store_prev(j);
     STAMP_FLUSH;
+    };      // tile_loop
+    if (any_scaled) tile_loop(std::true_type{});
+    else tile_loop(std::false_type{});
 }
 
 template <int CIN, int EPI, bool ACC_IN, bool UPS = false>

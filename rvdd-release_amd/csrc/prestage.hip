@@ -274,6 +274,41 @@ __global__ __launch_bounds__(256) void netin_kernel(const float* __restrict__ ra
     o[2] = f32x4{n[2], 0.f, 0.f, 0.f};
 }
 
+// An upper bound of max |network input| per sequence, for the block floating point of the conv behind it (rvdd_internal.h),
+// from what the input is made of instead of from its 16-channel map (a pass over that map, or a maximum inside netin_kernel's
+// 28 800 blocks, costs 100 us and more per frame-step at 720p; this kernel reads the packed raw frames, 1/16 of it):
+//   |bicubic gather of x| <= 1.375^2 max |x| (A = -0.75: the taps' absolute sum peaks at 1.375 per axis),
+//   |Hamilton-Adams(raw)| <= 3 max |raw| (green: a two-sample mean plus a quarter of a Laplacian, <= 2 M; red / blue: a
+//   two-sample mean plus a quarter of a Laplacian of those greens, <= 3 M),
+// so max |netin| <= 5.7 max(max |raw|, max |previous output|) < 16 max(...) -- and >= max |raw_cur|, whose samples the demosaic
+// keeps: the bound is never more than 16 x too large, four of the seventeen binades the split's full precision spans.
+// Up to three raw frames (the current one, the next one, and on the first step of a video the previous one, whose demosaic is
+// the "previous output"; each nullable); `prev_words` (nullable) = words whose maximum bounds the previous output (the slot
+// PostConvs wrote in the last step: features and output frame together); grid (blocks, B).
+__global__ __launch_bounds__(256) void netin_bound_kernel(const float* __restrict__ raw_a, const float* __restrict__ raw_b,
+                                                          const float* __restrict__ raw_c, int64_t n, int64_t rbs,
+                                                          const unsigned* __restrict__ prev_words, unsigned* __restrict__ words) {
+    __shared__ unsigned red[4];
+    const int b = blockIdx.y;
+    float m = 0.f;
+    for (int pass = 0; pass < 3; ++pass) {
+        const float* src = pass == 0 ? raw_a : pass == 1 ? raw_b : raw_c;
+        if (!src) continue;
+        const f32x4* p = reinterpret_cast<const f32x4*>(src + (size_t)b * rbs);
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < (n >> 2); i += (int64_t)gridDim.x * 256) {
+            const f32x4 v = p[i];
+            m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+        }
+    }
+    unsigned bits = __float_as_uint(m);
+    if (blockIdx.x == 0 && prev_words && threadIdx.x < kAmaxLines)
+        bits = max(bits, prev_words[(size_t)b * kAmaxSeqWords + threadIdx.x * kAmaxLineWords]);
+    // x 16: four up on the exponent (a maximum that is zero, denormal, or within 2^4 of overflow stays as it is)
+    const unsigned e = (bits >> 23) & 0xffu;
+    if (e >= 1 && e < 250) bits += 4u << 23;
+    amax_commit_block(words, b, blockIdx.x, __uint_as_float(bits), red);
+}
+
 // grid = (ceil(W/32), H, B), 192 threads = 16 PAIRS of horizontally adjacent pixels x 12 float4 chunks.
 //  * The 16 taps of a pixel (flow upsample, coordinate round trip, cubic weights: ~150 VALU instructions) are
 //    computed ONCE per pixel by the first 32 threads and shared through LDS; computed by each of the 12 lanes of
@@ -620,11 +655,52 @@ hipError_t launch_netin(const float* raw_cur, float* green_scratch, const float*
     return hipGetLastError();
 }
 
+hipError_t launch_netin_bound(const float* raw_a, const float* raw_b, const float* raw_c, int B, int h, int w, int64_t raw_bstride,
+                              const unsigned* prev_words, unsigned* words, hipStream_t s) {
+    const int64_t n = (int64_t)4 * h * w;
+    if (B <= 0 || n <= 0) return hipSuccess;
+    if ((n & 3) || (raw_bstride & 3)) return hipErrorInvalidValue;      // 16-B loads (n = 4hw: always)
+    int nblk = (int)((n / 4 + 256 * 8 - 1) / (256 * 8));
+    nblk = nblk < 1 ? 1 : (nblk > 64 ? 64 : nblk);
+    hipLaunchKernelGGL(netin_bound_kernel, dim3(nblk, B), dim3(256), 0, s, raw_a, raw_b, raw_c, n, raw_bstride ? raw_bstride : n,
+                       prev_words, words);
+    return hipGetLastError();
+}
+
 hipError_t launch_warp48(const float* src, const float* flow_raw, float* dst, int B, int H, int W,
                          hipStream_t s, int64_t flow_bstride) {
     if (!B || !H || !W) return hipSuccess;
     hipLaunchKernelGGL(warp48_kernel, dim3((W + 31) / 32, H, B), dim3(192), 0, s, src, flow_raw, dst, B, H, W,
                        flow_bstride ? flow_bstride : (int64_t)2 * (H / 2) * (W / 2));
+    return hipGetLastError();
+}
+
+// max |x| per sequence of a dense map [B][n] (rvdd_internal.h: amax words of the maps that no kernel of a frame-step wrote --
+// caller-supplied network inputs and features, a recurrent state handed in through rvdd_set_state)
+// (`up`: binades added to the maximum, for a map that stands for something up to 2^up times larger)
+__global__ __launch_bounds__(256) void amax_reduce_kernel(const float* __restrict__ map, int64_t n, unsigned* __restrict__ words, int up) {
+    __shared__ unsigned red[4];
+    const int b = blockIdx.y;
+    const f32x4* p = reinterpret_cast<const f32x4*>(map + (size_t)b * n);
+    const int64_t n4 = n >> 2;
+    float m = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const f32x4 v = p[i];
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) m = fmaxf(m, fabsf(map[(size_t)b * n + 4 * n4 + threadIdx.x]));
+    unsigned bits = __float_as_uint(m);
+    const unsigned e = (bits >> 23) & 0xffu;
+    if (up && e >= 1 && e + up < 254) bits += (unsigned)up << 23;
+    amax_commit_block(words, b, blockIdx.x, __uint_as_float(bits), red);
+}
+
+hipError_t launch_amax_reduce(const float* map, int B, int64_t hw_c, unsigned* words, hipStream_t s, int up) {
+    if (B <= 0 || hw_c <= 0) return hipSuccess;
+    if ((hw_c & 3) && B > 1) return hipErrorInvalidValue;      // 16-B loads per sequence
+    int nblk = (int)((hw_c / 4 + 256 * 8 - 1) / (256 * 8));
+    nblk = nblk < 1 ? 1 : (nblk > 128 ? 128 : nblk);
+    hipLaunchKernelGGL(amax_reduce_kernel, dim3(nblk, B), dim3(256), 0, s, map, hw_c, words, up);
     return hipGetLastError();
 }
 

@@ -88,6 +88,15 @@ constexpr int cu_enc(int level, int j) { return level == 0 ? CU_ENC0_0 + j : CU_
 constexpr int cu_down(int i) { return CU_DOWN0 + 3 * i; }
 constexpr int cu_up(int i) { return CU_UP0 + 3 * i; }
 constexpr int cu_dec(int i, int j) { return CU_DEC0_0 + 3 * i + j; }
+// amax words (rvdd_internal.h: block floating point of the split-f16 kernels): one slot of B x kAmaxSeqWords words per map a
+// split kernel reads -- the output of every conv layer (AMAX_LAYER0 + its CuLayer), the network input, the features a caller
+// hands to rvdd_unet_forward, and the RECURRENT features: the map PostConvs[0] writes in one step is the map the next step
+// gathers its warped features from (a bicubic gather never exceeds 1.9 x the map's maximum, far inside the margin of the
+// scaling, so the warped map shares the words), which makes its words the one slot that must survive the zeroing at the
+// start of a step -- two of them, used in turn (rvdd_handle::feat_par), at the two ends of the array so that "everything
+// except the one being read" is one contiguous memset.
+enum { AMAX_FEAT0 = 0, AMAX_LAYER0 = 1, AMAX_NETIN = AMAX_LAYER0 + CU_COUNT, AMAX_FWDFEAT, AMAX_FEAT1, AMAX_SLOTS };
+constexpr int amax_layer(int layer) { return AMAX_LAYER0 + layer; }
 
 // The ConvBlocks of the ConvNeXt net by position in the schedule (run_convnext), resolved once like the above.
 enum NxBlock {
@@ -129,6 +138,8 @@ struct rvdd_handle {
     bool use_wino = true;         // 48->48 3x3 convs: Winograd F(2x2,3x3) (RVDD_CONV=direct selects the direct kernel)
     bool split16 = true;          // 48->48 3x3 convs on the F16 matrix pipe with split f32 operands (conv3x3h.hip); RVDD_CONV=f32 | direct |
                                   // winograd / "conv_kernel" 1, 2, 4 select the f32-MFMA kernels (the A/B reference)
+    bool bfp = true;              // block floating point of the split-f16 convs (amax words per map and sequence; RVDD_BFP=0 / option "block_fp" 0:
+                                  // operands split as they are, the round-3 behaviour with its 2^-14 .. 65504 domain -- A/B reference only)
     int wino4 = 0;                // 1 = F(4x4,3x3) (wino4x4.hip) for the plain / two-pass 48->48 layers of the large levels (RVDD_WINO4)
     int seq_major = 0;            // 1 = full-resolution stages one sequence at a time (see seq_major_on)
     bool fuse_upsample = true;    // UpConv's bilinear x2 inside the Winograd patch load (RVDD_FUSE_UPSAMPLE=0: separate kernel)
@@ -157,6 +168,9 @@ struct rvdd_handle {
     float* green = nullptr;      // [B][H][W]
     float* featw = nullptr;      // NHWC48 warped features
     float* lastfeat = nullptr;   // NHWC48 recurrent features
+    unsigned* amax = nullptr;    // [AMAX_SLOTS][B][kAmaxSeqWords] max |x| per map and sequence, zeroed at the start of every forward
+    int feat_par = 0;            // the recurrent features' words: a step reads AMAX_FEAT[feat_par ^ 1] and writes AMAX_FEAT[feat_par]
+    int amax_feat_in = AMAX_FWDFEAT, amax_post_out = amax_layer(CU_POST);      // what the current forward uses for the two
     double* loss_partial = nullptr;
     double* loss_result = nullptr;
     float* scratch = nullptr;
@@ -524,6 +538,11 @@ const char* conv_name_h(int epi, bool acc) {
     return names[epi][acc];
 }
 
+// the amax words (rvdd_internal.h) of map `slot`, from sequence b0 on
+unsigned* amax_words(const rvdd_t* h, int slot, size_t b0 = 0) { return h->amax + ((size_t)slot * h->cfg.batch + b0) * kAmaxSeqWords; }
+constexpr size_t amax_bytes(int B, int nslots) { return (size_t)nslots * B * kAmaxSeqWords * sizeof(unsigned); }
+constexpr int amax_feat_slot(int par) { return par ? AMAX_FEAT1 : AMAX_FEAT0; }
+
 struct ConvCall {
     const float* in = nullptr;
     int src = 0;             // which weight slice of the layer
@@ -538,6 +557,8 @@ struct ConvCall {
     float* out3_nchw = nullptr;    // EPI_RELU_OUT3 targets
     float* out3_nhwc4 = nullptr;
     bool ups = false;        // `in` is the half-resolution map whose bilinear x2 upsample the conv reads (UpConv)
+    int amax_in = -1;        // amax slot of `in` (-1: no scaling) and of `out` (-1: no split kernel reads it)
+    int amax_out = -1;
 };
 
 bool wino_applies(const rvdd_t* h, int H, int W) {
@@ -599,6 +620,8 @@ int run_conv(rvdd_t* h, const Conv3& L, const ConvCall& c, hipStream_t s, Sub su
     a.b3 = h->b_out;
     a.out3_nchw = c.out3_nchw ? c.out3_nchw + px_in * 3 : nullptr;
     a.out3_nhwc4 = c.out3_nhwc4 ? c.out3_nhwc4 + px_in * 4 : nullptr;
+    a.amax_in = (c.amax_in >= 0 && h->bfp) ? amax_words(h, c.amax_in, sub.b0) : nullptr;
+    a.amax_out = (c.amax_out >= 0 && h->bfp) ? amax_words(h, c.amax_out, sub.b0) : nullptr;
     const bool c16_ok = cin != 48 && !c.acc_in && (c.epi == EPI_NONE || c.epi == EPI_RELU);
     if (c.ups && !(cin == 48 && ((h->split16 && L.wh[c.src]) || (L.wu[c.src] && wino_applies(h, c.H, c.W)))))
         return fail(h, RVDD_ERR_STATE, "run_conv: the fused upsample exists in the split-f16 and the Winograd kernels only");
@@ -642,6 +665,7 @@ int run_conv(rvdd_t* h, const Conv3& L, const ConvCall& c, hipStream_t s, Sub su
 // What rvdd_step does in front of the net (demosaic, warps): the caller's frame and flow pointers of one step.
 // run_convunet calls it per sequence when the full-resolution stages run depth first; null for rvdd_unet_forward.
 struct StepInputs {
+    const float* raw_prev = nullptr;      // only on the first step of a video
     const float* raw_cur = nullptr;
     const float* raw_next = nullptr;
     const float* flow_prev = nullptr;
@@ -657,17 +681,22 @@ int run_convunet(rvdd_t* h, const float* netin, const float* featw, float* feat_
     const int B = h->cfg.batch;
     Level* lv = h->lv;
     const Conv3* cu = h->cu;
-    auto conv = [&](int layer, const float* in, float* out, int lvl, int epi, Sub sub) {
+    // `from` = the amax slot of the input map (L(the layer that wrote it), AMAX_NETIN, h->amax_feat_in); a layer's output slot is L(its id)
+    auto conv = [&](int layer, const float* in, int from, float* out, int lvl, int epi, Sub sub) {
         ConvCall c;
         c.in = in; c.out = out; c.H = lv[lvl].H; c.W = lv[lvl].W; c.epi = epi;
+        c.amax_in = from; c.amax_out = amax_layer(layer);
         return run_conv(h, cu[layer], c, s, sub);
     };
+    const auto L = amax_layer;
     // two-source (virtual concat) conv: pass 1 leaves bias + sum over source A in `part`
-    auto conv2 = [&](int layer, const float* inA, const float* inB, float* out, int lvl, Sub sub) {
+    auto conv2 = [&](int layer, const float* inA, int fromA, const float* inB, int fromB, float* out, int lvl, Sub sub) {
         ConvCall c;
         c.in = inA; c.src = 0; c.out = lv[lvl].part; c.H = lv[lvl].H; c.W = lv[lvl].W; c.epi = EPI_NONE;
+        c.amax_in = fromA;
         RC(run_conv(h, cu[layer], c, s, sub));
         c.in = inB; c.src = 1; c.acc_in = lv[lvl].part; c.out = out; c.epi = EPI_RELU;
+        c.amax_in = fromB; c.amax_out = amax_layer(layer);
         return run_conv(h, cu[layer], c, s, sub);
     };
     const Sub all{0, B};
@@ -682,30 +711,32 @@ int run_convunet(rvdd_t* h, const float* netin, const float* featw, float* feat_
         const Sub sb = sub_at(k);
         if (prologue) RC(run_prologue(h, *prologue, sb, s));
         if (feat) {
-            RC(conv(CU_PRE, netin, lv[0].t[0], 0, EPI_NONE, sb));                           // :742 (no activation)
-            RC(conv2(CU_ENC0_0, lv[0].t[0], featw, lv[0].t[1], 0, sb));                     // cat[y, old_features] :743
+            RC(conv(CU_PRE, netin, AMAX_NETIN, lv[0].t[0], 0, EPI_NONE, sb));               // :742 (no activation)
+            RC(conv2(CU_ENC0_0, lv[0].t[0], L(CU_PRE), featw, h->amax_feat_in, lv[0].t[1], 0, sb)); // cat[y, old_features] :743
         } else {
-            RC(conv(CU_ENC0_0, netin, lv[0].t[1], 0, EPI_RELU, sb));
+            RC(conv(CU_ENC0_0, netin, AMAX_NETIN, lv[0].t[1], 0, EPI_RELU, sb));
         }
-        RC(conv(CU_ENC0_1, lv[0].t[1], lv[0].skip, 0, EPI_RELU, sb));
-        RC(conv(CU_DOWN0, lv[0].skip, lv[1].t[0], 0, EPI_POOL, sb));                        // :207-208
+        RC(conv(CU_ENC0_1, lv[0].t[1], L(CU_ENC0_0), lv[0].skip, 0, EPI_RELU, sb));
+        RC(conv(CU_DOWN0, lv[0].skip, L(CU_ENC0_1), lv[1].t[0], 0, EPI_POOL, sb));          // :207-208
     }
     // ---- encoder levels 1..3 (all sequences per launch: these levels need the batch to fill the chip)
     for (int i = 1; i <= 3; ++i) {
-        if (i > 1) RC(conv(cu_down(i - 1), lv[i - 1].skip, lv[i].t[0], i - 1, EPI_POOL, all));
-        RC(conv(cu_enc(i, 0), lv[i].t[0], lv[i].t[1], i, EPI_RELU, all));
-        RC(conv(cu_enc(i, 1), lv[i].t[1], i < 3 ? lv[i].skip : lv[3].t[2], i, EPI_RELU, all));
+        if (i > 1) RC(conv(cu_down(i - 1), lv[i - 1].skip, L(cu_enc(i - 1, 1)), lv[i].t[0], i - 1, EPI_POOL, all));
+        RC(conv(cu_enc(i, 0), lv[i].t[0], L(cu_down(i - 1)), lv[i].t[1], i, EPI_RELU, all));
+        RC(conv(cu_enc(i, 1), lv[i].t[1], L(cu_enc(i, 0)), i < 3 ? lv[i].skip : lv[3].t[2], i, EPI_RELU, all));
     }
     // ---- bottleneck: d = e3 + d1 + d2 (:561-567)
     float* e3 = lv[3].t[2];
-    RC(conv(CU_BOT0, e3, lv[3].t[0], 3, EPI_RELU, all));
+    RC(conv(CU_BOT0, e3, L(cu_enc(3, 1)), lv[3].t[0], 3, EPI_RELU, all));
     {
         ConvCall c;
         c.in = lv[3].t[0]; c.out = lv[3].t[1]; c.H = lv[3].H; c.W = lv[3].W;
         c.epi = EPI_RELU_ADD2; c.res1 = e3; c.res2 = lv[3].t[0];
+        c.amax_in = L(CU_BOT0); c.amax_out = L(CU_BOT1);
         RC(run_conv(h, cu[CU_BOT1], c, s));
     }
     const float* d = lv[3].t[1];
+    int d_from = L(CU_BOT1);
     // ---- decoder (:570-579); its last level again per sequence, together with the post convs
     float* fdst = feat_dst ? feat_dst : lv[0].t[2];
     for (int i = 0; i < 3; ++i) {
@@ -729,21 +760,28 @@ int run_convunet(rvdd_t* h, const float* netin, const float* featw, float* feat_
             c.out = lv[hi].t[1]; c.H = uh; c.W = uw; c.epi = EPI_RELU;
             c.Hout = lv[hi].H; c.Wout = lv[hi].W;
             c.oy = (lv[hi].H - uh) / 2; c.ox = (lv[hi].W - uw) / 2;
+            // (an interpolated value never exceeds the map's maximum: the upsampled map shares the words of its source)
+            c.amax_in = d_from; c.amax_out = L(cu_up(i));
             if (uh != lv[hi].H || uw != lv[hi].W)
                 HIPCHK(h, hipMemsetAsync(lv[hi].t[1] + hi_px * kF, 0, (size_t)sb.nb * lv[hi].H * lv[hi].W * kF * sizeof(float), s));
             RC(run_conv(h, cu[cu_up(i)], c, s, sb));
-            RC(conv2(cu_dec(i, 0), lv[hi].skip, lv[hi].t[1], lv[hi].t[0], hi, sb));        // cat(skip, dec) :541
-            RC(conv(cu_dec(i, 1), lv[hi].t[0], lv[hi].t[1], hi, EPI_RELU, sb));
+            RC(conv2(cu_dec(i, 0), lv[hi].skip, L(cu_enc(hi, 1)), lv[hi].t[1], L(cu_up(i)), lv[hi].t[0], hi, sb));        // cat(skip, dec) :541
+            RC(conv(cu_dec(i, 1), lv[hi].t[0], L(cu_dec(i, 0)), lv[hi].t[1], hi, EPI_RELU, sb));
             if (hi > 0) continue;
             // ---- post: hooked 48-ch map = next frame's features (:808-812), then 1x1 -> 3
-            if (wino_applies(h, lv[0].H, lv[0].W)) {
-                // PostConvs[1] (1x1, 48 -> 3) rides in the epilogue of PostConvs[0]'s Winograd kernel
+            if (h->split16 || wino_applies(h, lv[0].H, lv[0].W)) {
+                // PostConvs[1] (1x1, 48 -> 3) rides in the epilogue of PostConvs[0]'s kernel (split-f16: at every size; Winograd
+                // f32: where it runs) -- and with it the output frame's share of the words the next step's input bound reads
                 ConvCall pc;
                 pc.in = lv[0].t[1]; pc.out = fdst; pc.H = lv[0].H; pc.W = lv[0].W; pc.epi = EPI_RELU_OUT3;
                 pc.out3_nchw = out_nchw; pc.out3_nhwc4 = out_nhwc4;
+                pc.amax_in = L(cu_dec(2, 1)); pc.amax_out = h->amax_post_out;
                 RC(run_conv(h, cu[CU_POST], pc, s, sb));
             } else {
-                RC(conv(CU_POST, lv[0].t[1], fdst, 0, EPI_RELU, sb));
+                ConvCall pc;
+                pc.in = lv[0].t[1]; pc.out = fdst; pc.H = lv[0].H; pc.W = lv[0].W; pc.epi = EPI_RELU;
+                pc.amax_in = L(cu_dec(2, 1)); pc.amax_out = h->amax_post_out;
+                RC(run_conv(h, cu[CU_POST], pc, s, sb));
                 const size_t px0 = (size_t)sb.b0 * h->cfg.height * h->cfg.width;
                 const double px = (double)sb.nb * h->cfg.height * h->cfg.width;
                 Scope sc(h, s, "conv1x1_out_kernel", 2.0 * 48 * 3 * px, px * (192.0 + 12.0 + 16.0));
@@ -752,6 +790,7 @@ int run_convunet(rvdd_t* h, const float* netin, const float* featw, float* feat_
             }
         }
         d = lv[hi].t[1];
+        d_from = L(cu_dec(i, 1));
     }
     if (per_seq) h->serpentine = !h->serpentine;
     return RVDD_OK;
@@ -835,6 +874,7 @@ int rvdd_create(const rvdd_cfg* cfg, rvdd_t** out) {
     if (const char* fu = std::getenv("RVDD_FUSE_UPSAMPLE")) h->fuse_upsample = std::atoi(fu) != 0;
     if (const char* nf = std::getenv("RVDD_NEXT_FUSED")) h->next_fused = std::atoi(nf) != 0;
     if (const char* w4 = std::getenv("RVDD_WINO4")) h->wino4 = std::atoi(w4);
+    if (const char* bf = std::getenv("RVDD_BFP")) h->bfp = std::atoi(bf) != 0;
     if (const char* np = std::getenv("RVDD_NEXT_POOL")) h->next_pool = std::atoi(np) != 0;
     if (const char* nsp = std::getenv("RVDD_NEXT_SPLIT")) h->next_split = std::atoi(nsp) != 0;
     if (const char* npp = std::getenv("RVDD_NEXT_PIPE")) h->next_pipe = std::atoi(npp) != 0;
@@ -871,6 +911,7 @@ int rvdd_create(const rvdd_cfg* cfg, rvdd_t** out) {
         A(&h->featw, npix * kF);
         A(&h->lastfeat, npix * kF);
     }
+    if (rc == RVDD_OK) rc = dmalloc(h, reinterpret_cast<void**>(&h->amax), amax_bytes(B, AMAX_SLOTS));
     if (rc == RVDD_OK) rc = dmalloc(h, reinterpret_cast<void**>(&h->loss_partial), 2 * 1024 * sizeof(double));
     if (rc == RVDD_OK) rc = dmalloc(h, reinterpret_cast<void**>(&h->loss_result), 2 * sizeof(double));
     if (rc != RVDD_OK) {
@@ -1100,6 +1141,16 @@ int rvdd_set_option(rvdd_t* h, const char* name, int32_t value) {
         h->next_streams = value != 0 && h->stream2 != nullptr;
         return RVDD_OK;
     }
+    if (std::strcmp(name, "block_fp") == 0) {
+        // 0 = the split-f16 convs split their operands as they are (no per-map power of two): the round-3 behaviour, right only
+        // while every activation stays inside 2^-14 .. 65504 -- kept as the A/B reference of the block floating point
+        h->bfp = value != 0;
+        if (h->amax) {
+            ENTER(h);
+            HIPCHK(h, hipMemset(h->amax, 0, amax_bytes(h->cfg.batch, AMAX_SLOTS)));      // no stale words across the switch
+        }
+        return RVDD_OK;
+    }
     if (std::strcmp(name, "wino4") == 0) {
         // 0 = off, 1 = F(4x4,3x3) for the plain / two-pass 48 -> 48 layers where a launch has >= 400 units, 2 = at every size
         if (value < 0 || value > 2) return fail(h, RVDD_ERR_ARG, "rvdd_set_option: wino4 must be 0, 1 or 2");
@@ -1122,7 +1173,7 @@ int rvdd_set_option(rvdd_t* h, const char* name, int32_t value) {
         h->split16 = value == 0;
         return RVDD_OK;
     }
-    return fail(h, RVDD_ERR_ARG, "rvdd_set_option: unknown option '%s' (known: no_warp, warp_raw, prev_noisy_frame, conv_kernel, seq_major, graphs, fuse_upsample, next_fused, next_split, next_pipe, next_pool, next_streams, wino4)", name);
+    return fail(h, RVDD_ERR_ARG, "rvdd_set_option: unknown option '%s' (known: no_warp, warp_raw, prev_noisy_frame, conv_kernel, seq_major, graphs, fuse_upsample, next_fused, next_split, next_pipe, next_pool, next_streams, wino4, block_fp)", name);
 }
 
 int rvdd_reset(rvdd_t* h) {
@@ -1149,6 +1200,9 @@ int run_prologue(rvdd_t* h, const StepInputs& in, Sub sb, hipStream_t s) {
     const float* fn_ = in.flow_next ? in.flow_next + o * in.flowf : nullptr;
     float* green = h->green + o * img;
     float* netin = h->netin + o * img * kNetInC;
+    // amax words of the maps the split-f16 convs read first (block floating point, rvdd_internal.h)
+    const bool bfp = h->bfp && h->split16 && !h->is_next();
+    unsigned* amax_netin = bfp ? amax_words(h, AMAX_NETIN, o) : nullptr;
     if (h->warp_raw && !nw) {
         // warp_frame with --warp_raw (models/recurrent_model.py:149-152): HA(warp(remosaick(frame), raw-resolution flow)).
         // remosaick(HA(raw)) is raw itself, so the next frame is warped as it came.  next4 is free in this mode: its
@@ -1173,6 +1227,7 @@ int run_prologue(rvdd_t* h, const StepInputs& in, Sub sb, hipStream_t s) {
                                           (int64_t)H * W * kNetInC, kNetInC, 1, s));
             }
         }
+        if (amax_netin) HIPCHK(h, launch_amax_reduce(netin, n, (int64_t)img * kNetInC, amax_netin, s));
     } else {
         // the whole NHWC16 input pixel in one pass: warp of the previous output | demosaic of the current frame |
         // warp of the demosaicked next frame
@@ -1182,6 +1237,14 @@ int run_prologue(rvdd_t* h, const StepInputs& in, Sub sb, hipStream_t s) {
             HIPCHK(h, launch_demosaic(rn_, green, next4, n, H / 2, W / 2, (int64_t)H * W * 4, 4, 1, s, (int64_t)in.rawf));
         }
         Scope sc(h, s, "netin(ha_green+netin_kernel)", 0.0, (double)n * img * (16.0 + 16.0 + 48.0 + (next4 ? 16.0 : 0.0)));
+        if (amax_netin) {
+            // (block floating point) a bound of max |netin| from the raw frames and from the words PostConvs wrote last step;
+            // with --prev_noisy_frame the "previous output" is a demosaicked frame whose raw data is gone: its own maximum
+            const float* rp_ = in.raw_prev ? in.raw_prev + o * in.rawf : nullptr;
+            HIPCHK(h, launch_netin_bound(rc_, rn_, rp_, n, H / 2, W / 2, (int64_t)in.rawf,
+                                         in.raw_prev ? nullptr : amax_words(h, h->amax_feat_in, o), amax_netin, s));
+            if (h->prev_noisy && !in.raw_prev) HIPCHK(h, launch_amax_reduce(h->lastden4 + o * img * 4, n, (int64_t)img * 4, amax_netin, s, 1));
+        }
         HIPCHK(h, launch_netin(rc_, green, h->lastden4 + o * img * 4, fp_, next4, fn_, netin, n, H / 2, W / 2, s, (int64_t)in.rawf,
                                (int64_t)in.flowf));
     }
@@ -1199,9 +1262,15 @@ int enqueue_step(rvdd_t* h, const float* raw_prev, const float* raw_cur, const f
     const int B = h->cfg.batch, H = h->cfg.height, W = h->cfg.width;
     const size_t npix = (size_t)B * H * W;
     StepInputs in;
+    in.raw_prev = init ? raw_prev : nullptr;
     in.raw_cur = raw_cur; in.raw_next = raw_next; in.flow_prev = flow_prev; in.flow_next = flow_next;
     in.rawf = raw_stride ? (size_t)raw_stride : (size_t)4 * (H / 2) * (W / 2);
     in.flowf = flow_stride ? (size_t)flow_stride : (size_t)2 * (H / 2) * (W / 2);
+    // amax words: everything but the recurrent features' words this step reads (zero features at the start of a video: zero words)
+    h->amax_feat_in = amax_feat_slot(h->feat_par ^ 1);
+    h->amax_post_out = amax_feat_slot(h->feat_par);
+    if (init) HIPCHK(h, hipMemsetAsync(h->amax, 0, amax_bytes(B, AMAX_SLOTS), s));
+    else HIPCHK(h, hipMemsetAsync(amax_words(h, h->feat_par ? AMAX_LAYER0 : AMAX_FEAT0), 0, amax_bytes(B, AMAX_SLOTS - 1), s));
     if (init) {
         // lastden = n[:, :3] (demosaiced previous noisy frame), features = 0
         // (models/recurrent_model.py:233-245)
@@ -1258,7 +1327,10 @@ int rvdd_step_strided(rvdd_t* h, const float* raw_prev, const float* raw_cur, co
     const bool init = h->need_init;
     auto eager = [&]() -> int {
         const int rc = enqueue_step(h, raw_prev, raw_cur, raw_next, flow_prev, flow_next, raw_stride, flow_stride, out_rgb, init, s);
-        if (rc == RVDD_OK) h->need_init = false;
+        if (rc == RVDD_OK) {
+            h->need_init = false;
+            h->feat_par ^= 1;          // the features' amax words this step wrote are the ones the next step reads
+        }
         return rc;
     };
     if (!h->use_graphs || h->prof_on || !h->ran_eagerly || !h->gstream) {
@@ -1266,7 +1338,7 @@ int rvdd_step_strided(rvdd_t* h, const float* raw_prev, const float* raw_cur, co
         return eager();
     }
     rvdd_handle::StepKey key{{init ? raw_prev : nullptr, raw_cur, raw_next, flow_prev, flow_next, out_rgb},
-                             {raw_stride, flow_stride}, (init ? 1 : 0) | (h->serpentine ? 2 : 0)};
+                             {raw_stride, flow_stride}, (init ? 1 : 0) | (h->serpentine ? 2 : 0) | (h->feat_par ? 4 : 0)};
     auto it = h->graphs.find(key);
     if (it == h->graphs.end()) {
         hipGraph_t g = nullptr;
@@ -1308,6 +1380,7 @@ int rvdd_step_strided(rvdd_t* h, const float* raw_prev, const float* raw_cur, co
     HIPCHK(h, hipEventRecord(h->g_out, h->gstream));
     HIPCHK(h, hipStreamWaitEvent(s, h->g_out, 0));
     h->need_init = false;
+    h->feat_par ^= 1;
     if (seq_major_on(h)) h->serpentine = !h->serpentine;
     return RVDD_OK;
 }
@@ -1337,6 +1410,11 @@ int rvdd_set_state(rvdd_t* h, const float* lastden, const float* lastfeat, void*
     if (lastfeat) {
         if (!h->has_feat()) return fail(h, RVDD_ERR_ARG, "rvdd_set_state: this architecture has no recurrent features");
         HIPCHK(h, launch_nchw_to_nhwc(lastfeat, h->lastfeat, B, kF, H, W, kF, s));
+        if (h->bfp && h->split16 && !h->is_next()) {      // the words the next step reads for these features (block floating point)
+            unsigned* w = amax_words(h, amax_feat_slot(h->feat_par ^ 1));
+            HIPCHK(h, hipMemsetAsync(w, 0, amax_bytes(B, 1), s));
+            HIPCHK(h, launch_amax_reduce(h->lastfeat, B, (int64_t)H * W * kF, w, s));
+        }
     }
     return RVDD_OK;
 }
@@ -1367,6 +1445,14 @@ int rvdd_unet_forward(rvdd_t* h, const float* x, const float* feat_in, float* ou
     const int B = h->cfg.batch, H = h->cfg.height, W = h->cfg.width;
     HIPCHK(h, launch_nchw_to_nhwc(x, h->netin, B, h->cin_real(), H, W, kNetInC, s));
     if (h->has_feat()) HIPCHK(h, launch_nchw_to_nhwc(feat_in, h->featw, B, kF, H, W, kF, s));
+    // amax words of the caller's maps (block floating point of the split-f16 convs); the recurrent features' words stay as they are
+    h->amax_feat_in = AMAX_FWDFEAT;
+    h->amax_post_out = amax_layer(CU_POST);
+    HIPCHK(h, hipMemsetAsync(amax_words(h, AMAX_LAYER0), 0, amax_bytes(B, AMAX_FEAT1 - AMAX_LAYER0), s));
+    if (h->bfp && h->split16 && !h->is_next()) {
+        HIPCHK(h, launch_amax_reduce(h->netin, B, (int64_t)H * W * kNetInC, amax_words(h, AMAX_NETIN), s));
+        if (h->has_feat()) HIPCHK(h, launch_amax_reduce(h->featw, B, (int64_t)H * W * kF, amax_words(h, AMAX_FWDFEAT), s));
+    }
     RC(run_net(h, h->netin, h->featw, h->lv[0].t[2], out, nullptr, s, nullptr));
     if (h->has_feat() && feat_out) HIPCHK(h, launch_nhwc_to_nchw(h->lv[0].t[2], feat_out, B, kF, H, W, kF, s));
     return RVDD_OK;

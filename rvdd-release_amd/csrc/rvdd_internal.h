@@ -62,7 +62,83 @@ struct ConvArgs {
     float* out3_nchw;     // [B][3][H][W]
     float* out3_nhwc4;    // [B][H][W][4] copy for the next frame's warp, or nullptr
     float wscale;         // conv3x3h.hip: 2^-s, the filters having been scaled by 2^s before the f16 split
+    // conv3x3h.hip, block floating point per map and sequence (see amax_shift below): amax_in[b][kAmaxSeqWords] = words whose
+    // maximum is the bits of max |x| over sequence b of the input map (null: no scaling), amax_out[b][kAmaxSeqWords] receives
+    // the same for the map this launch writes (null: nobody reads that map as a split operand)
+    const unsigned* amax_in;
+    unsigned* amax_out;
 };
+
+// ---- block floating point for the split-f16 operands --------------------------------------------------------------------
+// An f16 half saturates at 65504 and loses its low bits below 2^-14; an f32 activation has neither limit.  Every map that
+// a split-f16 kernel reads therefore carries, per sequence, kAmaxLines words (one per 128-byte line) whose maximum is the
+// bits of max |x| over the map, written by the kernel that produced the map (atomic max on the integer bits, which order
+// like the non-negative floats they are).  The reader multiplies by the power of two that puts that maximum into
+// [2^3, 2^4) before it splits -- the range the trained nets' activations have by themselves -- and scales the sums back in
+// its epilogue; both exact.  A zero / non-finite / absurdly small maximum (< 2^-95) means "no scaling".
+// Atomics are the cost to watch here (measured, profiles/r04_amax_atomics.txt): the waves of a persistent kernel finish
+// together, and one atomic per wave on one word per sequence (2048 on 8 addresses) serialised for 13 us at the tail of every
+// conv launch; one per wave of the streaming kernels (10^5 per launch) cost 4 % of a frame-step even spread over 64 words of
+// two cache lines.  So: a workgroup reduces through LDS first (amax_commit_block), and the workgroups of a launch spread
+// over kAmaxLines separate lines per sequence.
+constexpr int kAmaxTargetExp = 3;
+constexpr int kAmaxLines = 16;          // words per sequence, each at the start of its own 128-byte line
+constexpr int kAmaxLineWords = 32;
+constexpr int kAmaxSeqWords = kAmaxLines * kAmaxLineWords;
+// The shift for a map whose max |x| has these bits.  A maximum inside [2^-6, 2^12) -- every map of the trained nets on frames
+// in the reference's [-1, 1] -- needs none: the f16 halves are as far from overflow (x16 at least) and as precise relative to
+// the map's maximum (2^-19 at worst) as they need to be, the reader then skips the multiplication (it is not free: the chunk
+// loop of conv3x3h_kernel has no spare vector-issue slot, 18 v_pk_mul_f32 per tile cost 1.5 % of a layer) and in-domain
+// frames keep the bits they had before the scaling existed.  Outside the window: the shift that puts the maximum into [8, 16).
+__host__ __device__ inline int amax_shift(unsigned bits) {
+    const int e = (int)((bits >> 23) & 0xffu);
+    if (e < 32 || e == 255) return 0;                      // zero, absurdly small, inf / nan: leave alone
+    if (e >= 127 - 6 && e < 127 + 12) return 0;
+    return kAmaxTargetExp - (e - 127);
+}
+__host__ __device__ inline float pow2f(int k) {          // 2^k, |k| <= 126
+    const unsigned u = (unsigned)(127 + k) << 23;
+    float f;
+    __builtin_memcpy(&f, &u, 4);
+    return f;
+}
+#ifdef __HIPCC__
+// max over the 64 lanes of a wave of an unsigned value (DPP; every lane must be active): the result, wave-uniform
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true));      // row_shr:1
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true));      // row_shr:2
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true));      // row_shr:4
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true));      // row_shr:8
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, true));      // row_bcast:15 into rows 1, 3
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, true));      // row_bcast:31 into rows 2, 3
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+// the reader's side: lane l < kAmaxLines holds word l of its sequence (other lanes 0) -> the maximum, wave-uniform
+__device__ __forceinline__ unsigned amax_lines_max(unsigned v) {
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true));
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true));
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true));
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true));
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 15);
+}
+// One WORKGROUP's contribution to the amax words of sequence b (the same b in every thread): m >= 0 per lane; `red` = one
+// LDS word per wave; `spread` = any number that differs between the workgroups that finish together.  Contains a
+// __syncthreads(): every thread of the workgroup must arrive.  One atomic per workgroup, nothing returned, nobody waits.
+__device__ __forceinline__ void amax_commit_block(unsigned* words, int b, unsigned spread, float m, unsigned* red) {
+    const unsigned mx = wave_max_u32(__float_as_uint(m));
+    const int wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    if ((threadIdx.x & 63) == 0) red[wave] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned t = red[0];
+        for (int i = 1; i < nw; ++i) t = max(t, red[i]);
+        if (t) atomicMax(words + (size_t)b * kAmaxSeqWords + (spread % kAmaxLines) * kAmaxLineWords, t);
+    }
+}
+#endif
+// amax words of a dense NHWC map [B][HW][C] (the maps no split kernel's producer wrote: caller-supplied inputs and states)
+hipError_t launch_amax_reduce(const float* map, int B, int64_t hw_c, unsigned* words, hipStream_t s, int up = 0);
+
 
 // cin = 16 or 48.  Returns hipGetLastError().
 hipError_t launch_conv3x3(const ConvArgs& a, int cin, int epi, hipStream_t s);
@@ -75,7 +151,8 @@ size_t wino3x3_weight_floats();
 hipError_t launch_wino4x4(const ConvArgs& a, int epi, hipStream_t s);
 size_t wino4x4_weight_floats();
 // the same layers on the F16 matrix pipe with split f32 operands (conv3x3h.hip); a.w = the split bank arranged by
-// arrange_conv3x3h (runtime.hip), a.wscale its scale; cin 48, every epilogue, with or without a.acc_in; no a.ups
+// arrange_conv3x3h (runtime.hip), a.wscale its scale; cin 48 (every epilogue, with or without a.acc_in, with a.ups for
+// UpConv's fused upsample) or 16 (the zero-padded network input): every 3x3 conv of the convunet by default
 hipError_t launch_conv3x3h(const ConvArgs& a, int cin, int epi, hipStream_t s);
 size_t conv3x3h_weight_bytes(int cin);
 void conv3x3_set_variant(int v);   // A/B switch used by rvdd_debug_conv_bench only
@@ -97,6 +174,10 @@ hipError_t launch_warp3(const float* src4, const float* flow_raw, float* dst, in
 hipError_t launch_netin(const float* raw_cur, float* green_scratch, const float* prev4, const float* flow_prev,
                         const float* next4, const float* flow_next, float* netin, int B, int h, int w, hipStream_t s,
                         int64_t raw_bstride = 0, int64_t flow_bstride = 0);
+// amax words of that network input (block floating point of the split-f16 convs, below): an upper bound from the packed raw
+// frames it is made of (up to three, each nullable) and from `prev_words`, words that bound the previous output (nullable)
+hipError_t launch_netin_bound(const float* raw_a, const float* raw_b, const float* raw_c, int B, int h, int w, int64_t raw_bstride,
+                              const unsigned* prev_words, unsigned* words, hipStream_t s);
 // src NHWC48 -> dst NHWC48.
 hipError_t launch_warp48(const float* src, const float* flow_raw, float* dst, int B, int H, int W,
                          hipStream_t s, int64_t flow_bstride = 0);

@@ -38,9 +38,9 @@ def parity_psnr(a, b):
 
 @pytest.fixture(params=["auto", "winograd", "f32"])
 def conv_kernel(request, monkeypatch):
-    """Which kernel runs the 3x3 convs.  "auto" is the default: every 48-channel layer on the F16 matrix pipe with
-    split f32 operands (conv3x3h.hip) at every size, the first layer and UpConv's fused upsample on an f32 kernel
-    picked by launch size; "f32" picks among the f32-MFMA kernels by launch size, so small frames run the direct
+    """Which kernel runs the 3x3 convs.  "auto" is the default: EVERY 3x3 conv of the convunet on the F16 matrix pipe with
+    split f32 operands (conv3x3h.hip) at every size -- the 16-channel first layer and UpConv's fused upsample included;
+    "f32" picks among the f32-MFMA kernels by launch size, so small frames run the direct
     kernel; "winograd" forces the Winograd f32 kernel at every size: ragged tiles in x and y, the zero_pad_features
     output placement, the 16-channel first layer and the fused 1x1 epilogue all run at the fixture sizes the
     reference pinned.  Read by rvdd_create (RVDD_CONV)."""
@@ -843,31 +843,41 @@ def test_split_f16_matrix_path_matches_f32_kernels(arch, stem, fut, opt):
             assert (a - b).abs().max() < 2e-5 and parity_psnr(a.cpu(), b.cpu()) > 120.0, (B, H, W, float((a - b).abs().max()))
 
 
-def test_split_path_outside_its_domain_stays_finite():
-    """The split-f16 matrix path needs |activation| < 65504 (include/rvdd.h, "conv_kernel").  Frames a hundred thousand
-    times brighter than the [-1, 1] the reference feeds push the first layers past that: the round-toward-zero split
-    saturates, so the default path returns finite (wrong) frames, never NaN or infinity, and the f32-MFMA kernels
-    (conv_kernel 4) return the exact products' frames, as the header says."""
+@pytest.mark.parametrize("arch,stem,fut", [
+    ("convunet+feat", "recurrent-convunet+feat-iso3200", 0),
+    ("convunet", "recurrent-convunet-future-iso3200", 1),
+    ("next+feat", "recurrent-ConvNeXtUnet+feat-future-iso3200", 1),
+])
+@pytest.mark.parametrize("mag", [1.0e5, 2.0 ** 20, 2.0 ** -8, 2.0 ** -12])
+def test_split_path_any_magnitude(arch, stem, fut, mag):
+    """The reference's convs are fp32 at any magnitude (networks/unet.py:26-76, new_unet.py:74-103).  The default path
+    multiplies f16 halves, whose exponent range is 2^-14 .. 65504 -- and must not care: the split-f16 convs carry one
+    power of two per map and sequence (block floating point, rvdd_internal.h: amax words written by the producing kernel),
+    the ConvNeXt MLP's operands are bounded by its LayerNorm whatever the frames are (checked against the weights at
+    load).  Frames 1e5 / 2^20 times brighter and 2^-8 / 2^-12 times dimmer than the [-1, 1] the reference feeds, three
+    recurrent steps (so the recurrent features and the previous output carry the magnitude too): every frame within
+    1e-4 of the oracle RELATIVE to the frame's own max-abs, and never a NaN or an infinity."""
     from rvdd_release_amd import synth
     from rvdd_release_amd.runtime import RvddRuntime
-    sd = load_weights("recurrent-convunet+feat-iso3200")
-    s = synth.make_sequence(3, 64, 96, iso=3200, seed=5, device="cuda")
-    big = 1.0e5
-    outs = {}
-    for conv in (0, 4):
-        rt = RvddRuntime("convunet+feat", 0, 1, 64, 96, 0)
-        rt.set_option("conv_kernel", conv)
-        rt.load_state_dict(sd)
-        o = rt.step((s.raw[0] * big)[None], (s.raw[1] * big)[None], None, s.flow_prev[1][None], None).clone()
-        outs[conv] = o
-        rt.close()
-        assert torch.isfinite(o).all(), conv
-    want = O.RecurrentOracle(sd, future=0).step((s.raw[0] * big).cpu()[None], (s.raw[1] * big).cpu()[None], None,
-                                                 s.flow_prev[1].cpu()[None], None, first=True)
-    scale = float(want.abs().max())
-    assert (outs[4].cpu() - want).abs().max() < 1e-4 * scale          # exact products: right at any magnitude
-    # ... and the case IS outside the split path's domain (activations of ~1e6 inside the net): its frames are off
-    assert (outs[0].cpu() - want).abs().max() > 1e-3 * scale
+    if arch.startswith("next") and "next-iso3200" not in BUILT:
+        pytest.skip("ConvNeXt path not built")
+    sd = load_weights(stem)
+    H, W, T = 64, 96, 4 + fut
+    s = synth.make_sequence(T, H, W, iso=3200, seed=5, device="cuda")
+    raw = s.raw * mag
+    rt = RvddRuntime(arch, fut, 1, H, W, 0)
+    rt.load_state_dict(sd)
+    outs = []
+    for t in range(1, T - fut):
+        outs.append(rt.step(raw[t - 1][None] if t == 1 else None, raw[t][None], raw[t + 1][None] if fut else None,
+                            s.flow_prev[t][None], s.flow_next[t][None] if fut else None).clone().cpu())
+    rt.close()
+    want = O.RecurrentOracle(sd, future=fut).run_sequence(raw.cpu(), s.flow_prev.cpu(), s.flow_next.cpu())
+    for t, (got, ref) in enumerate(zip(outs, want)):
+        assert torch.isfinite(got).all(), (mag, t)
+        scale = float(ref.abs().max())
+        err = float((got[0] - ref).abs().max())
+        assert err < 1e-4 * scale, (arch, mag, t, err, scale)
 
 
 def test_pipelined_convblock_equals_phased():

@@ -3,7 +3,7 @@
 # usage (GPU box, repo root): bash tools/bench_all.sh <tag>
 TAG=${1:-r02}
 for cfg in C1 C2 C3 C4; do
-  timeout -k 10 400 python bench.py --config $cfg --steps 5 --warmup 2 --cpu-frames $([ $cfg = C4 ] && echo 4 || echo 10) 2>/dev/null | grep '^{' > gpurun_out/${TAG}_$cfg.json.log
+  timeout -k 10 400 python bench.py --config $cfg --no-other-configs --steps 5 --warmup 2 --cpu-frames $([ $cfg = C4 ] && echo 4 || echo 10) 2>/dev/null | grep '^{' > gpurun_out/${TAG}_$cfg.json.log
   python -c "
 import json; d=json.loads(open('gpurun_out/${TAG}_$cfg.json.log').read())
 print('$cfg', d['value'], 'frames/s  roofline', d['roofline']['frac'] if d['roofline'] else None, ' cpu', d['cpu_baseline']['value'] if d['cpu_baseline'] else None, 'psnr', d['task_psnr_db'], 'parity', d['cpu_baseline']['gpu_vs_cpu_parity_psnr_db'] if d['cpu_baseline'] else None)"

@@ -12,7 +12,7 @@ ROOT=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$ROOT/gpurun_out/pmc_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python3 $ROOT/bench.py --steps 1 --warmup 1 --cpu-frames 0 --no-exact-ab --frames 4 --no-kernel-events $*"
+BENCH="python3 $ROOT/bench.py --steps 1 --warmup 1 --cpu-frames 0 --no-exact-ab --no-other-configs --frames 4 --no-kernel-events $*"
 rc=0; i=0
 IFS=':' read -ra GS <<< "$GROUPS_"
 for G in "${GS[@]}"; do

@@ -3,7 +3,7 @@
 CFG=${1:-C2}
 ROOT=${GRAFT_REPO_ROOT:-$PWD}
 cd $ROOT
-python bench.py --config $CFG --steps ${STEPS:-8} --warmup 1 --cpu-frames 0 --cpu-frames-8 0 --cpu-frames-wide 0 --no-exact-ab > gpurun_out/power_${CFG}_bench.json 2>/dev/null &
+python bench.py --config $CFG --steps ${STEPS:-8} --warmup 1 --cpu-frames 0 --cpu-frames-8 0 --cpu-frames-wide 0 --no-exact-ab --no-other-configs > gpurun_out/power_${CFG}_bench.json 2>/dev/null &
 BP=$!
 for i in $(seq 1 60); do
   rocm-smi --showpower --showclocks --showtemp 2>/dev/null | grep -E "Power|sclk|mclk|junction" | tr '\n' ' '; echo

@@ -11,7 +11,7 @@ ROOT=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$ROOT/gpurun_out/resid
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 200 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAVES SQ_BUSY_CYCLES --output-format csv -d $OUT -- python3 $ROOT/bench.py --steps 1 --warmup 1 --cpu-frames 0 --frames 4 --no-kernel-events "$@" > $OUT/log 2>&1 || { tail -5 $OUT/log; exit 1; }
+timeout -k 10 200 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAVES SQ_BUSY_CYCLES --output-format csv -d $OUT -- python3 $ROOT/bench.py --steps 1 --warmup 1 --cpu-frames 0 --no-exact-ab --no-other-configs --frames 4 --no-kernel-events "$@" > $OUT/log 2>&1 || { tail -5 $OUT/log; exit 1; }
 python3 - "$KERN" $OUT <<'PY'
 import csv, glob, sys, collections
 kern, out = sys.argv[1], sys.argv[2]
