@@ -209,6 +209,9 @@ int rvdd_srgb_metrics(rvdd_t* h, const uint8_t* a, const uint8_t* b, int32_t n, 
  *               next_split; same bits either way).
  *   "next_pool": 0 = with next_fused, MaxPool2d(2) in front of a DownConv (new_unet.py:200-204) as its own kernel instead
  *               of the fused block's epilogue (default 1; same bits either way).
+ *   "conv_groups": 2 = the split-f16 conv kernel's eight waves work as two groups of four, each on an 8x16-pixel tile with a
+ *               barrier of its own, instead of all eight on one 16x16-pixel tile (default 1; process-wide; same sums in the same
+ *               order, same bits; measured: no gain in the net).
  *   "block_fp": 0 = the split-f16 convs split their operands without the per-map power of two (the A/B reference of the block
  *               floating point; right only while every activation stays within 2^-14 .. 65504).  Default 1.
  *   "wino4":    1 / 2 = the plain and two-pass 48 -> 48 3x3 convs on the Winograd F(4x4,3x3) kernel where a launch has

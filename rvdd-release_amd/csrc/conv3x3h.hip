@@ -48,11 +48,20 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) void lds_void;
 
-constexpr int TH = 16, TW = 16, IH = TH + 2, IW = TW + 2;
+constexpr int TW = 16, IW = TW + 2;
 constexpr int NTHREADS = 512;
 
-template <int CIN>
+// NGRP = 1 (the default): the eight waves of a workgroup share one 16x16-pixel tile.  NGRP = 2 (round 4, option "conv_groups"):
+// two GROUPS of four waves, one wave of each per SIMD, each group with its own 8x16-pixel tile, halo planes and barrier (an
+// LDS counter), walking the tile list independently -- while one group is between its barriers (epilogue, staging stores) the
+// other group's wave keeps the SIMD's matrix pipe busy.  Same sums in the same order, same bits; 2.6 % faster on its own
+// (tools/conv3x3h_bench.hip), nothing in the net (profiles/r04_conv_two_groups_ab.txt): the tile loop is bound by what it
+// issues besides the MFMAs (profiles/r04_conv3x3h_tile_loop_parts.txt), and the 8-row tile's halo is 1.41x its pixels.
+template <int CIN, int NGRP>
 struct HGeo {
+    static constexpr int TH = 16 / NGRP, IH = TH + 2;        // tile rows of a group (two per wave), with halo
+    static constexpr int NT = NTHREADS / NGRP;               // threads of a group
+    static constexpr int WPG = NT / 64;                      // waves of a group
     static constexpr int GPT = CIN / 8;                      // 8-channel groups per tap
     static constexpr int NG = 9 * GPT;                       // groups of the whole filter
     static constexpr int NCH = (NG + 3) / 4;                 // K chunks of 32 (one MFMA deep)
@@ -63,12 +72,12 @@ struct HGeo {
                                                              // interleaved [hi | lo | pad] image of 224 B per pixel
     static constexpr int PLANE = IH * IW * HI;
     static constexpr int W_BYTES = NCH * 3 * 2 * 1024;
-    static constexpr int I_BYTES = 2 * PLANE;
-    static constexpr int P_FLOATS = 48 + 3 * 48 + 4 + 8;     // bias, PostConvs[1] weights and bias, one word per wave (amax reduction)
-    static constexpr int LDS_BYTES = W_BYTES + I_BYTES + P_FLOATS * 4;
+    static constexpr int I_BYTES = 2 * PLANE;                // one group's two planes
+    static constexpr int P_FLOATS = 48 + 3 * 48 + 4 + 8 + 4; // bias, PostConvs[1] weights and bias, one word per wave (amax reduction), the groups' barrier counters
+    static constexpr int LDS_BYTES = W_BYTES + NGRP * I_BYTES + P_FLOATS * 4;
     static constexpr int SEG = CIN / 4;                      // 16-B pieces of one f32 pixel
     static constexpr int ROWSEG = IW * SEG;                  // ... of one halo row
-    static constexpr int RPR = NTHREADS / ROWSEG;            // halo rows fetched per round of one load per thread
+    static constexpr int RPR = NT / ROWSEG;                  // halo rows fetched per round of one load per thread of the group
     static constexpr int NR = (IH + RPR - 1) / RPR;          // rounds per tile
     static constexpr int A_SPLIT = 7;                        // chunks reached from the first A base pointer (< 64 KiB of offsets)
 };
@@ -136,18 +145,22 @@ __device__ unsigned long long g_stamps[8 * 8];      // [wave][phase 0..6, tiles]
 // bilinear x2 upsample (align_corners=False), interpolated in the halo fetch (2x2 blocks of halo pixels from four source
 // pixels each) with the expressions of upsample2x_kernel (prestage.hip) in the same order: the same bits as "upsample,
 // then conv", the upsampled map is never written.
-template <int CIN, int EPI, bool ACC_IN, bool UPS = false>
+template <int CIN, int EPI, bool ACC_IN, bool UPS = false, int NGRP = 2>
 __global__ __launch_bounds__(NTHREADS) void conv3x3h_kernel(ConvArgs a) {
-    using G = HGeo<CIN>;
+    using G = HGeo<CIN, NGRP>;
+    constexpr int TH = G::TH, IH = G::IH;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     typedef __attribute__((address_space(3))) unsigned char lds_u8;
     typedef __attribute__((address_space(3))) f32x4 lds_f4;
     typedef __attribute__((address_space(3))) u32x2 lds_u2;
     lds_u8* L = (lds_u8*)smem;
-    float* Pl = reinterpret_cast<float*>(smem + G::W_BYTES + G::I_BYTES);
+    float* Pl = reinterpret_cast<float*>(smem + G::W_BYTES + NGRP * G::I_BYTES);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave / G::WPG, gw = wave - grp * G::WPG;      // group, wave inside it (waves w and w + 4 share a SIMD)
+    const int gtid = tid - grp * G::NT;                           // thread inside the group
+    const unsigned plane0 = (unsigned)(G::W_BYTES + grp * G::I_BYTES);      // the group's halo planes
     const int n = lane & 15;
     const int g = lane >> 4;
 
@@ -221,6 +234,7 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3h_kernel(ConvArgs a) {
         }
     }
     if (tid < kF) Pl[tid] = a.bias[tid];
+    if (tid >= 480 && tid < 484) reinterpret_cast<unsigned*>(Pl)[G::P_FLOATS - 4 + tid - 480] = 0u;      // the groups' barrier counters
     if constexpr (EPI == EPI_RELU_OUT3) {
         if (tid >= 64 && tid < 64 + 3 * kF) Pl[kF + tid - 64] = a.w3[tid - 64];
         else if (tid >= 256 && tid < 259) Pl[4 * kF + tid - 256] = a.b3[tid - 256];
@@ -230,13 +244,13 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3h_kernel(ConvArgs a) {
 
 
     // ---- halo fetch: thread -> (row rp of the round, halo column hx, 16-B piece `part`), the same for every tile
-    const int rp = tid / G::ROWSEG;
-    const int rem = tid - rp * G::ROWSEG;
+    const int rp = gtid / G::ROWSEG;
+    const int rem = gtid - rp * G::ROWSEG;
     const int hx = rem / G::SEG;
     const int part = rem - hx * G::SEG;
     const bool ld_thread = rp < G::RPR;
     const int g_lane = (rp * a.W + hx) * (CIN * 4) + part * 16;           // byte offset inside the image, relative to the halo origin
-    const unsigned l_lane = (unsigned)(G::W_BYTES + (rp * IW + hx) * G::S + part * 8);
+    const unsigned l_lane = plane0 + (unsigned)((rp * IW + hx) * G::S + part * 8);
     // One round = one 16-B load per thread (RPR halo rows).  The rounds of the NEXT tile are issued one per chunk inside
     // this tile's MFMA loop (a CU's texture path moves 64 B per clock: the 72 KiB of a halo tile are 1100 cycles of it, and
     // issued in one burst they stood in front of the MFMAs), split in registers under the last chunks, and written to LDS
@@ -271,17 +285,18 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3h_kernel(ConvArgs a) {
     // pixels are 9x9 such blocks, each from four source pixels.  One work item = one block x one 16-B channel piece: four
     // loads, two vertical interpolations shared by the block's two columns, four outputs -- against four loads and three
     // interpolations per OUTPUT piece when every halo piece is fetched on its own (TA traffic / 4, a third fewer FMAs).
-    // Two items per thread (972 of 1024 slots).
-    constexpr int UNR = UPS ? 2 : 1;
+    // Two items per thread (972 of 1024 slots); a group of four waves with its 10x18 halo: 5x9 blocks, three per thread.
+    constexpr int UNR = UPS ? (NGRP == 1 ? 2 : 3) : 1;
+    constexpr int UBLK = (IH / 2) * 9;
     int u_by[UNR], u_bx[UNR], u_part[UNR];
     bool u_ok[UNR];
 #pragma unroll
     for (int r0 = 0; r0 < UNR; ++r0) {
-        const int item = tid + NTHREADS * r0, blk = item / 12;
+        const int item = gtid + G::NT * r0, blk = item / 12;
         u_part[r0] = item - blk * 12;
         u_by[r0] = blk / 9;
         u_bx[r0] = blk - u_by[r0] * 9;
-        u_ok[r0] = blk < 81;
+        u_ok[r0] = blk < UBLK;
     }
     f32x4 ulo[UNR][4];                 // source pixels (row 0 col 0, row 0 col 1, row 1 col 0, row 1 col 1)
     float u_ly[UNR][2], u_lx[UNR][2];  // weight of the second source row / column per block row / column; < 0: outside the map
@@ -329,7 +344,7 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3h_kernel(ConvArgs a) {
                 for (int e = 0; e < 2; ++e)
 #pragma unroll
                     for (int f = 0; f < 2; ++f) {
-                        const unsigned ad = (unsigned)(G::W_BYTES + ((2 * u_by[r0] + e) * IW + 2 * u_bx[r0] + f) * G::S + u_part[r0] * 8);
+                        const unsigned ad = plane0 + (unsigned)(((2 * u_by[r0] + e) * IW + 2 * u_bx[r0] + f) * G::S + u_part[r0] * 8);
                         *(lds_u2*)(L + ad) = ushi[r0][2 * e + f];
                         *(lds_u2*)(L + ad + G::PLANE) = uslo[r0][2 * e + f];
                     }
@@ -357,7 +372,7 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3h_kernel(ConvArgs a) {
         const int tap = Gi / G::GPT;
         const int c0 = (Gi - tap * G::GPT) * 8;
         const int ky = tap / 3, kx = tap - 3 * ky;
-        boff[j] = (unsigned)(G::W_BYTES + ((2 * wave + ky) * IW + n + kx) * G::S + c0 * 2);
+        boff[j] = plane0 + (unsigned)(((2 * gw + ky) * IW + n + kx) * G::S + c0 * 2);
     }
     unsigned abase[2] = {(unsigned)(lane * 16), (unsigned)(lane * 16 + G::A_SPLIT * 6 * 1024)};
     asm volatile("" : "+v"(abase[0]), "+v"(abase[1]));
@@ -383,11 +398,30 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3h_kernel(ConvArgs a) {
     float sc_nxt = 1.f, inv_cur = 1.f, inv_nxt = 1.f;
     float amx = 0.f;        // max |x| of what this wave has stored for sequence amx_b
     int amx_b = -1, pend_b = -1;
-    unsigned* Rl = reinterpret_cast<unsigned*>(Pl + G::P_FLOATS - 8);      // one word per wave
-    auto amax_send = [&](int b) {      // wave 0, behind a barrier: the workgroup's maximum for sequence b, to one of its kAmaxLines lines
-        unsigned t = lane < NTHREADS / 64 ? Rl[lane] : 0u;
+    unsigned* Rl = reinterpret_cast<unsigned*>(Pl + G::P_FLOATS - 12) + grp * G::WPG;      // one word per wave of the group
+    auto amax_send = [&](int b) {      // the group's first wave, behind a barrier: the group's maximum for sequence b, to one of the kAmaxLines lines
+        unsigned t = lane < G::WPG ? Rl[lane] : 0u;
         t = amax_lines_max(t);
-        if (lane == 0 && t) atomicMax(a.amax_out + (size_t)b * kAmaxSeqWords + (blockIdx.x % kAmaxLines) * kAmaxLineWords, t);
+        if (lane == 0 && t)
+            atomicMax(a.amax_out + (size_t)b * kAmaxSeqWords + ((blockIdx.x * NGRP + grp) % kAmaxLines) * kAmaxLineWords, t);
+    };
+    // The group's barrier.  One group = the whole workgroup: s_barrier.  Two groups: a counter in LDS every wave of the group
+    // adds one to and polls (s_barrier counts all eight waves, and the point of the groups is that they do NOT wait for each
+    // other).  LDS operations of a wave complete in order, so "my staging stores / fragment reads are done" is lgkmcnt(0) in
+    // front of the add -- and nothing else: no vmcnt wait, the halo loads and result stores in flight stay in flight.
+    typedef __attribute__((address_space(3))) unsigned lds_u32;
+    lds_u32* gbar = (lds_u32*)(lds_u8*)(smem + G::W_BYTES + NGRP * G::I_BYTES + (G::P_FLOATS - 4) * 4) + grp;
+    unsigned gcount = 0;
+    auto gsync = [&]() {
+        if constexpr (NGRP == 1) {
+            __syncthreads();
+        } else {
+            gcount += G::WPG;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (lane == 0) __hip_atomic_fetch_add(gbar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            while (__hip_atomic_load(gbar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < gcount) __builtin_amdgcn_s_sleep(1);
+            asm volatile("" ::: "memory");
+        }
     };
 
     bool any_scaled = many_seqs;
@@ -397,6 +431,10 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3h_kernel(ConvArgs a) {
         for (int i = 0; i < 4; ++i) need |= (unsigned)amax_shift(amax_lines_max(ab_first[i]));
         any_scaled = any_scaled || need != 0;
     }
+
+    // the groups take the workgroup's tiles in turn
+    t += grp * t_step;
+    t_step *= NGRP;
 
     auto tile_loop = [&](auto scaled_tag) {
     constexpr bool SC = decltype(scaled_tag)::value;
@@ -421,6 +459,7 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3h_kernel(ConvArgs a) {
         }
         write_tile();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's pieces of the filter bank have landed
+        __syncthreads();       // bank, parameters, barrier counters and both groups' first tiles: the one barrier all eight waves share
     }
     // results of the tile before, stored one 16-B piece per chunk inside the current tile's MFMA loop (before the first
     // tile: out-of-range offsets, the stores are dropped)
@@ -431,18 +470,21 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3h_kernel(ConvArgs a) {
 #pragma unroll
     for (int i = 0; i < NOUT; ++i) outv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     // one 16-B piece of the previous tile's results: they ride between the chunks of the current tile's MFMA loop
-    auto store_prev = [&](int i) { bstore(orr_prev, so_prev[EPI == EPI_POOL ? 0 : i / 3] + 64 * (i % 3), outv[i]); };
+    auto store_prev = [&](int i) {
+        bstore(orr_prev, so_prev[EPI == EPI_POOL ? 0 : i / 3] + 64 * (i % 3), outv[i]);
+    };
     STAMP_DECL;
 #pragma unroll 1
     while (t < t_end) {
         STAMP(0);
-        __syncthreads();       // tile t is staged
+        gsync();               // tile t is staged
         STAMP(1);
         // The first chunk's MFMAs go out at once; the tile's address work (next tile's position, this tile's store and
         // side-load offsets) follows them and runs under them, and everything that needs it starts at chunk SH.
         constexpr int SH = G::NCH >= 12 ? 1 : 0;
+        constexpr int US = NGRP == 1 ? 1 : 3, UL = NGRP == 1 ? 5 : 3, UI = NGRP == 1 ? 2 : 3;      // UPS: load stride, load -> use, use stride
         Src qn;
-        const int yy0 = cur.y0 + 2 * wave, xx = cur.x0 + n;
+        const int yy0 = cur.y0 + 2 * gw, xx = cur.x0 + n;
         unsigned po[2], so[2];
         f32x4 side[2][3];
         __amdgpu_buffer_rsrc_t pr;
@@ -457,7 +499,7 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3h_kernel(ConvArgs a) {
                 so[nt] = ok ? (unsigned)((((yy0 + nt + a.oy) * a.Wout + xx + a.ox) * kF + 4 * g) * 4) : 0x80000000u;
             }
             if constexpr (EPI == EPI_POOL) {
-                const int pr_ = (cur.y0 >> 1) + wave, pc = xx >> 1;
+                const int pr_ = (cur.y0 >> 1) + gw, pc = xx >> 1;
                 const bool ok = !(n & 1) && pr_ < a.Hout && pc < a.Wout;
                 so[0] = ok ? (unsigned)(((pr_ * a.Wout + pc) * kF + 4 * g) * 4) : 0x80000000u;
             }
@@ -480,14 +522,16 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3h_kernel(ConvArgs a) {
                 if (j >= SH && j - SH < 6) side[(j - SH) / 3][(j - SH) % 3] = bload(pr, po[(j - SH) / 3], 64 * ((j - SH) % 3));
             }
             if constexpr (SC) {
-                if (j == (UPS ? SH + 5 : G::NCH - 1 - (G::NR - 1) / 3)) scale_from(ab_nxt, sc_nxt, inv_nxt);      // the chunk of the first split
+                if (j == (UPS ? SH + UL : G::NCH - 1 - (G::NR - 1) / 3)) scale_from(ab_nxt, sc_nxt, inv_nxt);      // the chunk of the first split
             }
             if constexpr (UPS) {
-                // the two items' loads at chunks SH, SH + 1; their interpolation and split five chunks later
+                // one workgroup-wide tile: the two items' loads at chunks SH, SH + 1, their interpolation and split five chunks
+                // later; a group's tile: three items, each loaded when the one before has been interpolated (UL chunks later), so
+                // that only one item's sixteen source registers are alive at a time (all three at once did not fit: scratch)
 #pragma unroll
                 for (int r0 = 0; r0 < UNR; ++r0) {
-                    if (j == SH + r0) fetch_ups(qn, r0);
-                    if (j == SH + 5 + 2 * r0) {
+                    if (j == SH + US * r0) fetch_ups(qn, r0);
+                    if (j == SH + UL + UI * r0) {
                         interp_ups(r0, sc_nxt, scaled_tag);
 #pragma unroll
                         for (int e = 0; e < 4; ++e) asm volatile("" : "+v"(ushi[r0][e]), "+v"(uslo[r0][e]));      // here, not behind the barrier
@@ -598,11 +642,11 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3h_kernel(ConvArgs a) {
             }
         }
         if (a.amax_out) {      // max |x| of what this tile stores (pixels outside the map do not count), per sequence
-            if (cur.b != amx_b) {          // (every wave of the workgroup is on the same tile: they all come through here together)
+            if (cur.b != amx_b) {          // (every wave of the group is on the same tile: they all come through here together)
                 if (amx_b >= 0) {
                     const unsigned wm = wave_max_u32(__float_as_uint(amx));
-                    if (lane == 0) Rl[wave] = wm;
-                    pend_b = amx_b;        // wave 0 sends it off behind the barrier below
+                    if (lane == 0) Rl[gw] = wm;
+                    pend_b = amx_b;        // the group's first wave sends it off behind the barrier below
                 }
                 amx = 0.f;
                 amx_b = cur.b;
@@ -620,10 +664,10 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3h_kernel(ConvArgs a) {
         so_prev[1] = so[1];
         orr_prev = __builtin_amdgcn_make_buffer_rsrc((void*)(a.out + (size_t)cur.b * a.Hout * a.Wout * kF), 0, out_bytes, 0x00020000);
         STAMP(4);
-        __syncthreads();       // every wave has read its last fragment of this tile: the next one may be staged
+        gsync();               // every wave of the group has read its last fragment of this tile: the next one may be staged
         STAMP(5);
-        if (pend_b >= 0) {     // the finished sequence's maximum: one atomic for the workgroup
-            if (wave == 0) amax_send(pend_b);
+        if (pend_b >= 0) {     // the finished sequence's maximum: one atomic for the group
+            if (gw == 0) amax_send(pend_b);
             pend_b = -1;
         }
         write_tile();
@@ -637,9 +681,9 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3h_kernel(ConvArgs a) {
     }
     if (a.amax_out && amx_b >= 0) {
         const unsigned wm = wave_max_u32(__float_as_uint(amx));
-        if (lane == 0) Rl[wave] = wm;
-        __syncthreads();
-        if (wave == 0) amax_send(amx_b);
+        if (lane == 0) Rl[gw] = wm;
+        gsync();
+        if (gw == 0) amax_send(amx_b);
     }
     // the last tile's results
 #pragma unroll
@@ -650,25 +694,34 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3h_kernel(ConvArgs a) {
     else tile_loop(std::false_type{});
 }
 
-template <int CIN, int EPI, bool ACC_IN, bool UPS = false>
-hipError_t launch_h(const ConvArgs& a0, hipStream_t s) {
+template <int CIN, int EPI, bool ACC_IN, bool UPS, int NGRP>
+hipError_t launch_g(const ConvArgs& a0, hipStream_t s) {
     static std::atomic<uint64_t> attr_done{0};
-    using G = HGeo<CIN>;
-    void (*kern)(ConvArgs) = conv3x3h_kernel<CIN, EPI, ACC_IN, UPS>;
+    using G = HGeo<CIN, NGRP>;
+    constexpr int TH = G::TH;
+    void (*kern)(ConvArgs) = conv3x3h_kernel<CIN, EPI, ACC_IN, UPS, NGRP>;
     if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(kern), G::LDS_BYTES, attr_done); e != hipSuccess) return e;
     ConvArgs a = a0;
     a.tiles_x = (a.W + TW - 1) / TW;
     a.tiles_y = (a.H + TH - 1) / TH;
     a.ntiles = a.B * a.tiles_x * a.tiles_y;
     const int cus = current_device_cus();
-    const int grid = a.ntiles < cus ? a.ntiles : cus;
+    const int want = (a.ntiles + NGRP - 1) / NGRP;         // one tile per group at least
+    const int grid = want < cus ? want : cus;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHREADS), G::LDS_BYTES, s, a);
     return hipGetLastError();
 }
 
+int g_conv3x3h_groups = 1;      // conv3x3h_set_groups: 2 = two groups of four waves with an 8x16-pixel tile each (measured: no gain in the net)
+template <int CIN, int EPI, bool ACC_IN, bool UPS = false>
+hipError_t launch_h(const ConvArgs& a, hipStream_t s) {
+    return g_conv3x3h_groups == 1 ? launch_g<CIN, EPI, ACC_IN, UPS, 1>(a, s) : launch_g<CIN, EPI, ACC_IN, UPS, 2>(a, s);
+}
+
 }  // namespace
 
-size_t conv3x3h_weight_bytes(int cin) { return cin == 48 ? HGeo<48>::W_BYTES : HGeo<16>::W_BYTES; }
+size_t conv3x3h_weight_bytes(int cin) { return cin == 48 ? HGeo<48, 1>::W_BYTES : HGeo<16, 1>::W_BYTES; }
+void conv3x3h_set_groups(int g) { g_conv3x3h_groups = g == 1 ? 1 : 2; }
 
 hipError_t launch_conv3x3h(const ConvArgs& a, int cin, int epi, hipStream_t s) {
     if (a.B <= 0 || a.H <= 0 || a.W <= 0) return hipSuccess;

@@ -875,6 +875,7 @@ int rvdd_create(const rvdd_cfg* cfg, rvdd_t** out) {
     if (const char* nf = std::getenv("RVDD_NEXT_FUSED")) h->next_fused = std::atoi(nf) != 0;
     if (const char* w4 = std::getenv("RVDD_WINO4")) h->wino4 = std::atoi(w4);
     if (const char* bf = std::getenv("RVDD_BFP")) h->bfp = std::atoi(bf) != 0;
+    if (const char* cg = std::getenv("RVDD_CONV_GROUPS")) conv3x3h_set_groups(std::atoi(cg));      // process-wide A/B switch
     if (const char* np = std::getenv("RVDD_NEXT_POOL")) h->next_pool = std::atoi(np) != 0;
     if (const char* nsp = std::getenv("RVDD_NEXT_SPLIT")) h->next_split = std::atoi(nsp) != 0;
     if (const char* npp = std::getenv("RVDD_NEXT_PIPE")) h->next_pipe = std::atoi(npp) != 0;
@@ -1141,6 +1142,13 @@ int rvdd_set_option(rvdd_t* h, const char* name, int32_t value) {
         h->next_streams = value != 0 && h->stream2 != nullptr;
         return RVDD_OK;
     }
+    if (std::strcmp(name, "conv_groups") == 0) {
+        // 2 = the split-f16 conv kernel's eight waves as two groups of four, each with an 8x16-pixel tile and a barrier of its own;
+        // 1 (default) = one 16x16-pixel tile per workgroup.  Process-wide; same bits either way.
+        if (value != 1 && value != 2) return fail(h, RVDD_ERR_ARG, "rvdd_set_option: conv_groups must be 1 or 2");
+        conv3x3h_set_groups(value);
+        return RVDD_OK;
+    }
     if (std::strcmp(name, "block_fp") == 0) {
         // 0 = the split-f16 convs split their operands as they are (no per-map power of two): the round-3 behaviour, right only
         // while every activation stays inside 2^-14 .. 65504 -- kept as the A/B reference of the block floating point
@@ -1173,7 +1181,7 @@ int rvdd_set_option(rvdd_t* h, const char* name, int32_t value) {
         h->split16 = value == 0;
         return RVDD_OK;
     }
-    return fail(h, RVDD_ERR_ARG, "rvdd_set_option: unknown option '%s' (known: no_warp, warp_raw, prev_noisy_frame, conv_kernel, seq_major, graphs, fuse_upsample, next_fused, next_split, next_pipe, next_pool, next_streams, wino4, block_fp)", name);
+    return fail(h, RVDD_ERR_ARG, "rvdd_set_option: unknown option '%s' (known: no_warp, warp_raw, prev_noisy_frame, conv_kernel, seq_major, graphs, fuse_upsample, next_fused, next_split, next_pipe, next_pool, next_streams, wino4, block_fp, conv_groups)", name);
 }
 
 int rvdd_reset(rvdd_t* h) {
@@ -1269,8 +1277,10 @@ int enqueue_step(rvdd_t* h, const float* raw_prev, const float* raw_cur, const f
     // amax words: everything but the recurrent features' words this step reads (zero features at the start of a video: zero words)
     h->amax_feat_in = amax_feat_slot(h->feat_par ^ 1);
     h->amax_post_out = amax_feat_slot(h->feat_par);
-    if (init) HIPCHK(h, hipMemsetAsync(h->amax, 0, amax_bytes(B, AMAX_SLOTS), s));
-    else HIPCHK(h, hipMemsetAsync(amax_words(h, h->feat_par ? AMAX_LAYER0 : AMAX_FEAT0), 0, amax_bytes(B, AMAX_SLOTS - 1), s));
+    if (h->bfp && h->split16 && !h->is_next()) {
+        if (init) HIPCHK(h, hipMemsetAsync(h->amax, 0, amax_bytes(B, AMAX_SLOTS), s));
+        else HIPCHK(h, hipMemsetAsync(amax_words(h, h->feat_par ? AMAX_LAYER0 : AMAX_FEAT0), 0, amax_bytes(B, AMAX_SLOTS - 1), s));
+    }
     if (init) {
         // lastden = n[:, :3] (demosaiced previous noisy frame), features = 0
         // (models/recurrent_model.py:233-245)
@@ -1448,8 +1458,8 @@ int rvdd_unet_forward(rvdd_t* h, const float* x, const float* feat_in, float* ou
     // amax words of the caller's maps (block floating point of the split-f16 convs); the recurrent features' words stay as they are
     h->amax_feat_in = AMAX_FWDFEAT;
     h->amax_post_out = amax_layer(CU_POST);
-    HIPCHK(h, hipMemsetAsync(amax_words(h, AMAX_LAYER0), 0, amax_bytes(B, AMAX_FEAT1 - AMAX_LAYER0), s));
     if (h->bfp && h->split16 && !h->is_next()) {
+        HIPCHK(h, hipMemsetAsync(amax_words(h, AMAX_LAYER0), 0, amax_bytes(B, AMAX_FEAT1 - AMAX_LAYER0), s));
         HIPCHK(h, launch_amax_reduce(h->netin, B, (int64_t)H * W * kNetInC, amax_words(h, AMAX_NETIN), s));
         if (h->has_feat()) HIPCHK(h, launch_amax_reduce(h->featw, B, (int64_t)H * W * kF, amax_words(h, AMAX_FWDFEAT), s));
     }

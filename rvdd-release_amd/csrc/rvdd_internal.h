@@ -155,6 +155,7 @@ size_t wino4x4_weight_floats();
 // UpConv's fused upsample) or 16 (the zero-padded network input): every 3x3 conv of the convunet by default
 hipError_t launch_conv3x3h(const ConvArgs& a, int cin, int epi, hipStream_t s);
 size_t conv3x3h_weight_bytes(int cin);
+void conv3x3h_set_groups(int g);   // 1 (default) = one 16x16 tile per workgroup; 2 = two groups of four waves with an 8x16 tile each (A/B)
 void conv3x3_set_variant(int v);   // A/B switch used by rvdd_debug_conv_bench only
 
 // -------------------------------------------------------------- pre-stages --

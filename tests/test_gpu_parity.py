@@ -880,6 +880,42 @@ def test_split_path_any_magnitude(arch, stem, fut, mag):
         assert err < 1e-4 * scale, (arch, mag, t, err, scale)
 
 
+def test_conv_two_wave_groups_same_bits():
+    """Option "conv_groups" 2: the split-f16 conv kernel's eight waves as two groups of four, each on an 8x16-pixel tile with halo
+    planes and an LDS-counter barrier of its own, instead of all eight on one 16x16-pixel tile.  The same sums in the same order:
+    the same bits -- every epilogue (two-pass layers, pooling, bottleneck sum, fused upsample and 1x1 output, zero-padded
+    placement), ragged tiles, fewer tiles than groups, batches, both convunet families, three recurrent steps."""
+    from rvdd_release_amd import synth
+    from rvdd_release_amd.runtime import RvddRuntime
+    for arch, stem, fut in (("convunet+feat", "recurrent-convunet+feat-iso3200", 0), ("convunet", "recurrent-convunet-future-iso3200", 1)):
+        sd = load_weights(stem)
+        for B, H, W in ((1, 16, 16), (2, 72, 104), (1, 180, 320), (3, 50, 66), (2, 256, 256)):
+            T = 4 + fut
+            seqs = [synth.make_sequence(T, H, W, iso=3200, seed=900 + b, device="cuda") for b in range(B)]
+            st = lambda f: torch.stack([f(s) for s in seqs], 0)
+            outs = []
+            try:
+                for groups in (1, 2):
+                    rt = RvddRuntime(arch, fut, B, H, W, 0)
+                    rt.set_option("conv_groups", groups)
+                    rt.load_state_dict(sd)
+                    o = []
+                    for t in range(1, T - fut):
+                        o.append(rt.step(st(lambda s: s.raw[t - 1]) if t == 1 else None, st(lambda s: s.raw[t]),
+                                         st(lambda s: s.raw[t + 1]) if fut else None, st(lambda s: s.flow_prev[t]),
+                                         st(lambda s: s.flow_next[t]) if fut else None).clone())
+                    if arch.endswith("feat"):
+                        o.append(rt.get_state()[1])
+                    outs.append(o)
+                    rt.close()
+            finally:
+                rt = RvddRuntime(arch, fut, 1, 16, 16, 0)
+                rt.set_option("conv_groups", 1)          # process-wide switch: back to the default
+                rt.close()
+            for a, b in zip(*outs):
+                assert torch.equal(a, b), (arch, B, H, W, float((a - b).abs().max()))
+
+
 def test_pipelined_convblock_equals_phased():
     """convblock_pipe_kernel (the default: waves 0-3 run the depth-wise conv and the LayerNorm of tile t + 1 while waves
     4-7 run the MLP of tile t, hand-over through the halo buffers behind two workgroup barriers, the front waves' own

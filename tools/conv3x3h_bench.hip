@@ -4,6 +4,7 @@
 // the two imply.
 #include "../rvdd-release_amd/csrc/conv3x3h.hip"
 
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <cstdlib>
@@ -11,10 +12,12 @@
 
 int main(int argc, char** argv) {
     const int B = argc > 1 ? atoi(argv[1]) : 4, H = argc > 2 ? atoi(argv[2]) : 720, W = argc > 3 ? atoi(argv[3]) : 1280;
+    const int groups = argc > 4 ? atoi(argv[4]) : 2;
+    conv3x3h_set_groups(groups);
     const size_t px = (size_t)B * H * W;
     std::vector<float> x(px * 48);
     srand(3);
-    for (auto& v : x) v = (float)rand() / RAND_MAX * 2.f - 0.5f;
+    for (auto& v : x) v = fmaxf((float)rand() / RAND_MAX * 2.f - 0.9f, 0.f);      // ReLU-like: 45 % zeros (random dense maps draw more power than the nets')
     std::vector<uint16_t> w(conv3x3h_weight_bytes(48) / 2);
     for (auto& v : w) {
         _Float16 hv = (_Float16)((float)rand() / RAND_MAX - 0.5f);
@@ -50,7 +53,13 @@ int main(int argc, char** argv) {
     const double tiles = (double)st[7];
     double tot0 = 0;
     for (int i = 0; i < 7; ++i) tot0 += (double)st[i];
-    printf("B %d H %d W %d: %.1f us per launch; %.0f tiles per workgroup; wave 0: %.0f cycles per tile; implied clock %.2f GHz\n", B, H, W,
+    printf("groups %d XP %d  B %d H %d W %d: %.1f us per launch; %.0f tiles per workgroup; wave 0: %.0f cycles per tile; implied clock %.2f GHz\n", groups,
+#ifdef RVDD_XP
+           RVDD_XP,
+#else
+           0,
+#endif
+           B, H, W,
            1e3 * ms / iters, tiles / iters / 256, tot0 / tiles, tot0 / iters / 256 / (1e3 * ms / iters) / 1e3);
     printf("  %-38s", "cycles per tile, wave:");
     for (int w = 0; w < 8; ++w) printf(" %7d", w);
