@@ -98,17 +98,17 @@ def test_no_kernel_spills_to_scratch():
             "mlp_kernel<1, 4, true>", "wino3x3_kernel<4, false>")
     # conv3x3h_kernel holds two forms of its tile loop since round 4 (with and without the block floating point's scaling,
     # chosen per workgroup): the instantiations with the most loop invariants (second pass of the two-source layers, fused
-    # upsample, bottleneck sum, fused 1x1 output) keep a few of them in lanes of a vector register -- written once at the top
+    # upsample, bottleneck sum, fused 1x1 output, the 16-channel first layer) keep a few of them in lanes of a vector register -- written once at the top
     # of the kernel, read back with one v_readlane per tile at most; the plain layers (60 % of the launches) keep none
-    few = ("conv3x3h_kernel<48, 0, true, ", "conv3x3h_kernel<48, 1, true, ", "conv3x3h_kernel<48, 1, false, true>",
-           "conv3x3h_kernel<48, 3, ", "conv3x3h_kernel<48, 4, ")
+    few = ("conv3x3h_kernel<48, 0, true, ", "conv3x3h_kernel<48, 1, true, ", "conv3x3h_kernel<48, 1, false, true, ",
+           "conv3x3h_kernel<48, 3, ", "conv3x3h_kernel<48, 4, ", "conv3x3h_kernel<16, ")
     once = once + few
     bad = [(r["name"], r["sgpr_spill_count"]) for r in rows if r["name"].startswith(hot) and not r["name"].startswith(once)
            and r.get("sgpr_spill_count", 0)]
     assert not bad, bad
     bad = [(r["name"], r["sgpr_spill_count"]) for r in rows if r["name"].startswith(once) and r.get("sgpr_spill_count", 0) > 16]
     assert not bad, bad
-    bad = [(r["name"], r["sgpr_spill_count"]) for r in rows if r["name"].startswith(few) and r.get("sgpr_spill_count", 0) > 10]
+    bad = [(r["name"], r["sgpr_spill_count"]) for r in rows if r["name"].startswith(few) and r.get("sgpr_spill_count", 0) > 14]
     assert not bad, bad
     # the pipelined ConvBlock is C4's hot kernel (about 25 launches per frame-step), not a once-per-step variant: its plain
     # instantiation is pinned at what it has today, the pooling / 1x1-output ones at a handful
