@@ -209,6 +209,11 @@ int rvdd_srgb_metrics(rvdd_t* h, const uint8_t* a, const uint8_t* b, int32_t n, 
  *               next_split; same bits either way).
  *   "next_pool": 0 = with next_fused, MaxPool2d(2) in front of a DownConv (new_unet.py:200-204) as its own kernel instead
  *               of the fused block's epilogue (default 1; same bits either way).
+ *   "fuse_pre": 0 = preprocessing_layer (3x3, no activation, networks/unet.py:742) and the first source of EncoderConvs[0][0]
+ *               (3x3, :743) run as the two convs they are, instead of as their composition -- ONE 5x5 conv of the network
+ *               input plus a fix of the border ring, where the zero padding between the two layers matters (default 1, the
+ *               feature-recurrent convunet on the split-f16 path; the A/B reference: the same linear map, summed in another
+ *               order, a few 1e-7 apart).
  *   "conv_groups": 2 = the split-f16 conv kernel's eight waves work as two groups of four, each on an 8x16-pixel tile with a
  *               barrier of its own, instead of all eight on one 16x16-pixel tile (default 1; process-wide; same sums in the same
  *               order, same bits; measured: no gain in the net).

@@ -704,6 +704,53 @@ hipError_t launch_amax_reduce(const float* map, int B, int64_t hw_c, unsigned* w
     return hipGetLastError();
 }
 
+// The border ring of the composed first layer (runtime.hip compose_pre_enc0).  The composition treats the preprocessing
+// layer's output y as if it existed outside the image (b1 + partial windows of the zero-extended input); the reference pads it
+// with ZEROS (networks/unet.py:742-743, padding=1 on both convs).  For a border pixel p the composed sum therefore carries
+// sum over the taps d with q = p + d - 1 outside the image of W2[d] y~(q), y~(q) = b1 + sum over taps e with q + e - 1 inside of
+// W1[e] x(q + e - 1): subtracted here.  One 64-thread block per border pixel (2 W + 2 (H - 2) of them per sequence), thread = channel.
+// netin NHWC16, w1 [9][16][48 m], w2 [9][48 m][48 o], part NHWC48.
+__global__ __launch_bounds__(64) void pre_border_fix_kernel(const float* __restrict__ netin, const float* __restrict__ w1,
+                                                            const float* __restrict__ b1, const float* __restrict__ w2,
+                                                            float* __restrict__ part, int H, int W) {
+    __shared__ float ys[48];
+    const int b = blockIdx.y, t = threadIdx.x;
+    int i = blockIdx.x, py, px;
+    if (i < W) { py = 0; px = i; }
+    else if (i < 2 * W) { py = H - 1; px = i - W; }
+    else if (i < 2 * W + H - 2) { py = i - 2 * W + 1; px = 0; }
+    else { py = i - 2 * W - (H - 2) + 1; px = W - 1; }
+    const float* x = netin + (size_t)b * H * W * kNetInC;
+    float corr = 0.f;
+    for (int d = 0; d < 9; ++d) {
+        const int qy = py + d / 3 - 1, qx = px + d % 3 - 1;
+        if ((unsigned)qy < (unsigned)H && (unsigned)qx < (unsigned)W) continue;      // q inside: the composition is right
+        float y = 0.f;
+        if (t < 48) {
+            y = b1[t];
+            for (int e = 0; e < 9; ++e) {
+                const int ry = qy + e / 3 - 1, rx = qx + e % 3 - 1;
+                if ((unsigned)ry >= (unsigned)H || (unsigned)rx >= (unsigned)W) continue;
+                const float* xp = x + ((size_t)ry * W + rx) * kNetInC;
+                for (int c = 0; c < kNetInC; ++c) y = fmaf(w1[(e * kNetInC + c) * 48 + t], xp[c], y);
+            }
+            ys[t] = y;
+        }
+        __syncthreads();
+        if (t < 48)
+            for (int m = 0; m < 48; ++m) corr = fmaf(w2[((size_t)d * 48 + m) * 48 + t], ys[m], corr);
+        __syncthreads();
+    }
+    if (t < 48) part[((size_t)b * H * W + (size_t)py * W + px) * kF + t] -= corr;
+}
+
+hipError_t launch_pre_border_fix(const float* netin, const float* w1, const float* b1, const float* w2, float* part, int B, int H, int W,
+                                 hipStream_t s) {
+    if (B <= 0 || H < 2 || W < 2) return hipSuccess;
+    hipLaunchKernelGGL(pre_border_fix_kernel, dim3(2 * W + 2 * (H - 2), B), dim3(64), 0, s, netin, w1, b1, w2, part, H, W);
+    return hipGetLastError();
+}
+
 hipError_t launch_warp_nchw(const float* x, const float* flow, float* y, int n, int c, int H, int W,
                             hipStream_t s) {
     const size_t np = (size_t)n * H * W;

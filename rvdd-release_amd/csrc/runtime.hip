@@ -156,6 +156,14 @@ struct rvdd_handle {
 
     // weights
     Conv3 cu[CU_COUNT];       // convunet layers in schedule order (CuLayer)
+    // preprocessing_layer composed with the first source of EncoderConvs[0][0] (feat nets; conv3x3h.hip HGeo, KS = 5)
+    float* pre5_w = nullptr;  // the composed 5x5 bank (split f16)
+    float pre5_inv = 1.f;
+    float* pre5_b = nullptr;  // [48] composed bias
+    float* pre_w1 = nullptr;  // [9][16][48]: preprocessing_layer weight, tap-major, input channel, its output channel m (border fix)
+    float* pre_b1 = nullptr;  // [48]
+    float* pre_w2 = nullptr;  // [9][48 m][48 o]: EncoderConvs[0][0] weight over the preprocessing layer's channels (border fix)
+    bool fuse_pre = true;     // RVDD_FUSE_PRE=0 / option "fuse_pre" 0: the two layers one after the other (A/B reference)
     float* w_out = nullptr;   // [3][48]
     float* b_out = nullptr;   // [3]
     NextBlk nx[NX_COUNT];     // ConvNeXt blocks in schedule order (NxBlock)
@@ -247,6 +255,12 @@ void drop_graphs(rvdd_t* h) {
                         __FILE__, __LINE__);                                                \
     } while (0)
 
+#define RC(expr)               \
+    do {                       \
+        int rc__ = (expr);     \
+        if (rc__) return rc__; \
+    } while (0)
+
 int dmalloc(rvdd_t* h, void** p, size_t bytes, bool zero = true) {
     HIPCHK(h, hipMalloc(p, bytes ? bytes : 16));
     h->allocs.push_back(*p);
@@ -327,27 +341,29 @@ float f16_value(uint16_t u) {
 // keeping |w'| <= 1024, returned as 2^-s), hi = f16(w') toward zero, lo = f16(w' - hi); stored
 // [chunk 14][cout block 3][hi, lo][lane = 16g + (cout & 15)][e 8] as f16 with 8-channel group G = 4 chunk + g = channels
 // 8 (G % 6) + e of tap G / 6 (groups 54, 55 zero): lane-linear 16-B A fragments of v_mfma_f32_16x16x32_f16.
-std::vector<float> arrange_conv3x3h(const HostTensor& t, int c0, float* inv_scale, int cin_pad = 48) {
+// (ks = 5: the composed first layer, [48][cin][5][5], 13 chunks)
+std::vector<float> arrange_conv3x3h(const HostTensor& t, int c0, float* inv_scale, int cin_pad = 48, int ks = 3) {
     const int cin_total = (int)t.shape[1];
     const int nc = cin_pad == 48 ? 48 : std::min(cin_total, 16);      // 16: the first layer, 6 or 9 real channels, zero filters beyond
-    const int gpt = cin_pad / 8, ng = 9 * gpt, nch = (ng + 3) / 4;
+    const int ntap = ks * ks;
+    const int gpt = cin_pad / 8, ng = ntap * gpt, nch = (ng + 3) / 4;
     float mx = 0.f;
     for (int co = 0; co < 48; ++co)
         for (int c = 0; c < nc; ++c)
-            for (int k = 0; k < 9; ++k) mx = std::max(mx, std::fabs(t.data[((size_t)co * cin_total + c0 + c) * 9 + k]));
+            for (int k = 0; k < ntap; ++k) mx = std::max(mx, std::fabs(t.data[((size_t)co * cin_total + c0 + c) * ntap + k]));
     int sft = 0;
     if (mx > 0.f && std::isfinite(mx)) sft = std::min(40, std::max(-40, (int)std::floor(std::log2(1024.0 / mx))));
     const float sc = std::ldexp(1.0f, sft);
     *inv_scale = std::ldexp(1.0f, -sft);
     const size_t halves = (size_t)nch * 3 * 2 * 512;
-    if (halves * 2 != conv3x3h_weight_bytes(cin_pad)) return {};
+    if (halves * 2 != (ks == 5 ? conv5x5h_weight_bytes() : conv3x3h_weight_bytes(cin_pad))) return {};
     std::vector<uint16_t> bank(halves, 0);
     for (int G = 0; G < ng; ++G) {
         const int j = G / 4, g = G % 4, tap = G / gpt, cg = (G % gpt) * 8;
         for (int co = 0; co < 48; ++co)
             for (int e = 0; e < 8; ++e) {
                 if (cg + e >= nc) continue;
-                const float w = t.data[((size_t)co * cin_total + c0 + cg + e) * 9 + tap] * sc;      // exact: a power of two
+                const float w = t.data[((size_t)co * cin_total + c0 + cg + e) * ntap + tap] * sc;      // exact: a power of two
                 const uint16_t hi = f16_bits(w, true);
                 const uint16_t lo = f16_bits(w - f16_value(hi), false);
                 const size_t frag = ((size_t)(j * 3 + co / 16) * 2) * 512 + (size_t)(g * 16 + co % 16) * 8 + e;
@@ -381,6 +397,56 @@ std::vector<float> arrange_wino4x4(const HostTensor& t, int c0) {
                 out[((((size_t)third * 36 + pos) * 3 + j) * 64 + g * 16 + lr) * 4 + ii] = (float)u[pos / 6][pos % 6];
         }
     return out;
+}
+
+// preprocessing_layer (3x3, cin -> 48, NO activation: networks/unet.py:742) followed by the first 48 input channels of
+// EncoderConvs[0][0] (3x3, :743) is one linear map of the network input: out(p) = sum_d W2[d] y(p + d - 1), y(q) = b1 +
+// sum_e W1[e] x(q + e - 1)  =>  out(p) = b + sum_u Wc[u] x(p + u - 2), Wc[u] = sum_{d + e = u} W2[d] W1[e] (5x5, 48 x cin),
+// b = sum_d W2[d] b1 (+ the layer's own bias, which the pass already adds).  Composed in double.  One 16-channel 5x5 conv
+// (K = 400) instead of a 16 -> 48 conv, a full-resolution 48-channel map written and read back, and a 48 -> 48 conv (K = 576).
+// The one thing the composition gets wrong is the zero padding BETWEEN the layers: y is ZERO outside the image, the composed
+// conv sees b1 + (partial windows) there.  Only pixels on the image border are affected; launch_pre_border_fix subtracts those
+// terms (it needs W1, b1, W2 in plain layouts).
+int compose_pre_enc0(rvdd_t* h) {
+    const HostTensor& w1 = h->staged.at("preprocessing_layer.weight");            // [48 m][cin][3][3]
+    const HostTensor& b1 = h->staged.at("preprocessing_layer.bias");
+    const HostTensor& w2 = h->staged.at("EncoderConvs.0.blocks.0.0.weight");      // [48 o][96][3][3], channels 0..47 = m
+    const int cin = (int)w1.shape[1];
+    HostTensor wc;
+    wc.shape = {48, cin, 5, 5};
+    std::vector<double> acc((size_t)48 * cin * 25, 0.0);
+    for (int o = 0; o < 48; ++o)
+        for (int m = 0; m < 48; ++m)
+            for (int d = 0; d < 9; ++d) {
+                const double a = w2.data[((size_t)o * 96 + m) * 9 + d];
+                if (a == 0.0) continue;
+                const int dy = d / 3, dx = d % 3;
+                for (int c = 0; c < cin; ++c)
+                    for (int e = 0; e < 9; ++e)
+                        acc[((size_t)o * cin + c) * 25 + (dy + e / 3) * 5 + dx + e % 3] += a * (double)w1.data[((size_t)m * cin + c) * 9 + e];
+            }
+    wc.data.resize(acc.size());
+    for (size_t i = 0; i < acc.size(); ++i) wc.data[i] = (float)acc[i];
+    std::vector<float> bc(48);
+    for (int o = 0; o < 48; ++o) {
+        double b = 0.0;
+        for (int m = 0; m < 48; ++m)
+            for (int d = 0; d < 9; ++d) b += (double)w2.data[((size_t)o * 96 + m) * 9 + d] * (double)b1.data[m];
+        bc[o] = (float)(b + (double)h->staged.at("EncoderConvs.0.blocks.0.0.bias").data[o]);      // + the layer's own bias (pass 1 adds it)
+    }
+    RC(upload(h, &h->pre5_w, arrange_conv3x3h(wc, 0, &h->pre5_inv, 16, 5)));
+    RC(upload(h, &h->pre5_b, bc));
+    std::vector<float> a1((size_t)9 * 16 * 48, 0.f), a2((size_t)9 * 48 * 48);
+    for (int e = 0; e < 9; ++e)
+        for (int c = 0; c < cin; ++c)
+            for (int m = 0; m < 48; ++m) a1[((size_t)e * 16 + c) * 48 + m] = w1.data[((size_t)m * cin + c) * 9 + e];
+    for (int d = 0; d < 9; ++d)
+        for (int m = 0; m < 48; ++m)
+            for (int o = 0; o < 48; ++o) a2[((size_t)d * 48 + m) * 48 + o] = w2.data[((size_t)o * 96 + m) * 9 + d];
+    RC(upload(h, &h->pre_w1, a1));
+    RC(upload(h, &h->pre_b1, b1.data));
+    RC(upload(h, &h->pre_w2, a2));
+    return RVDD_OK;
 }
 
 // ---- expected state_dict -------------------
@@ -656,11 +722,30 @@ int run_conv(rvdd_t* h, const Conv3& L, const ConvCall& c, hipStream_t s, Sub su
     return RVDD_OK;
 }
 
-#define RC(expr)               \
-    do {                       \
-        int rc__ = (expr);     \
-        if (rc__) return rc__; \
-    } while (0)
+
+// The composed 5x5 conv of the network input (compose_pre_enc0) into `part`, and its border fix; sequences of `sub`.
+int run_pre5(rvdd_t* h, const float* netin, float* part, hipStream_t s, Sub sub) {
+    if (sub.nb < 0) sub.nb = h->cfg.batch;
+    const int H = h->cfg.height, W = h->cfg.width;
+    const size_t px0 = (size_t)sub.b0 * H * W;
+    ConvArgs a{};
+    a.in = netin + px0 * kNetInC;
+    a.w = h->pre5_w;
+    a.wscale = h->pre5_inv;
+    a.bias = h->pre5_b;
+    a.out = part + px0 * kF;
+    a.B = sub.nb;
+    a.H = a.Hout = H;
+    a.W = a.Wout = W;
+    a.amax_in = h->bfp ? amax_words(h, AMAX_NETIN, sub.b0) : nullptr;
+    const double px = (double)sub.nb * H * W;
+    {
+        Scope sc(h, s, "conv5x5h_kernel<16>", 2.0 * 25.0 * h->cin_real() * 48.0 * px, px * 4.0 * (h->cin_real() + 48.0));
+        HIPCHK(h, launch_conv5x5h_c16(a, s));
+    }
+    HIPCHK(h, launch_pre_border_fix(a.in, h->pre_w1, h->pre_b1, h->pre_w2, a.out, sub.nb, H, W, s));
+    return RVDD_OK;
+}
 
 // What rvdd_step does in front of the net (demosaic, warps): the caller's frame and flow pointers of one step.
 // run_convunet calls it per sequence when the full-resolution stages run depth first; null for rvdd_unet_forward.
@@ -710,7 +795,15 @@ int run_convunet(rvdd_t* h, const float* netin, const float* featw, float* feat_
     for (int k = 0; k < nsub; ++k) {
         const Sub sb = sub_at(k);
         if (prologue) RC(run_prologue(h, *prologue, sb, s));
-        if (feat) {
+        if (feat && h->fuse_pre && h->split16 && h->pre5_w) {
+            // preprocessing_layer (:742, no activation) and the first source of EncoderConvs[0][0] (:743) as ONE 5x5 conv of the
+            // network input (compose_pre_enc0), its border ring put right, then the second source (the old features) as before
+            RC(run_pre5(h, netin, lv[0].part, s, sb));
+            ConvCall c;
+            c.in = featw; c.src = 1; c.acc_in = lv[0].part; c.out = lv[0].t[1]; c.H = lv[0].H; c.W = lv[0].W; c.epi = EPI_RELU;
+            c.amax_in = h->amax_feat_in; c.amax_out = L(CU_ENC0_0);
+            RC(run_conv(h, cu[CU_ENC0_0], c, s, sb));
+        } else if (feat) {
             RC(conv(CU_PRE, netin, AMAX_NETIN, lv[0].t[0], 0, EPI_NONE, sb));               // :742 (no activation)
             RC(conv2(CU_ENC0_0, lv[0].t[0], L(CU_PRE), featw, h->amax_feat_in, lv[0].t[1], 0, sb)); // cat[y, old_features] :743
         } else {
@@ -875,6 +968,7 @@ int rvdd_create(const rvdd_cfg* cfg, rvdd_t** out) {
     if (const char* nf = std::getenv("RVDD_NEXT_FUSED")) h->next_fused = std::atoi(nf) != 0;
     if (const char* w4 = std::getenv("RVDD_WINO4")) h->wino4 = std::atoi(w4);
     if (const char* bf = std::getenv("RVDD_BFP")) h->bfp = std::atoi(bf) != 0;
+    if (const char* fp = std::getenv("RVDD_FUSE_PRE")) h->fuse_pre = std::atoi(fp) != 0;
     if (const char* cg = std::getenv("RVDD_CONV_GROUPS")) conv3x3h_set_groups(std::atoi(cg));      // process-wide A/B switch
     if (const char* np = std::getenv("RVDD_NEXT_POOL")) h->next_pool = std::atoi(np) != 0;
     if (const char* nsp = std::getenv("RVDD_NEXT_SPLIT")) h->next_split = std::atoi(nsp) != 0;
@@ -1023,6 +1117,7 @@ int rvdd_finalize_weights(rvdd_t* h) {
         }
         RC(upload(h, &h->w_out, h->staged.at("PostConvs.1.weight").data));
         RC(upload(h, &h->b_out, h->staged.at("PostConvs.1.bias").data));
+        if (h->has_feat()) RC(compose_pre_enc0(h));
     } else {
         RC(finalize_convnext(h));
     }
@@ -1142,6 +1237,12 @@ int rvdd_set_option(rvdd_t* h, const char* name, int32_t value) {
         h->next_streams = value != 0 && h->stream2 != nullptr;
         return RVDD_OK;
     }
+    if (std::strcmp(name, "fuse_pre") == 0) {
+        // 0 = preprocessing_layer and EncoderConvs[0][0] as the two convs they are, instead of their composition (the A/B
+        // reference: same map up to fp32 rounding of a different summation order)
+        h->fuse_pre = value != 0;
+        return RVDD_OK;
+    }
     if (std::strcmp(name, "conv_groups") == 0) {
         // 2 = the split-f16 conv kernel's eight waves as two groups of four, each with an 8x16-pixel tile and a barrier of its own;
         // 1 (default) = one 16x16-pixel tile per workgroup.  Process-wide; same bits either way.
@@ -1181,7 +1282,7 @@ int rvdd_set_option(rvdd_t* h, const char* name, int32_t value) {
         h->split16 = value == 0;
         return RVDD_OK;
     }
-    return fail(h, RVDD_ERR_ARG, "rvdd_set_option: unknown option '%s' (known: no_warp, warp_raw, prev_noisy_frame, conv_kernel, seq_major, graphs, fuse_upsample, next_fused, next_split, next_pipe, next_pool, next_streams, wino4, block_fp, conv_groups)", name);
+    return fail(h, RVDD_ERR_ARG, "rvdd_set_option: unknown option '%s' (known: no_warp, warp_raw, prev_noisy_frame, conv_kernel, seq_major, graphs, fuse_upsample, next_fused, next_split, next_pipe, next_pool, next_streams, wino4, block_fp, conv_groups, fuse_pre)", name);
 }
 
 int rvdd_reset(rvdd_t* h) {

@@ -155,6 +155,13 @@ size_t wino4x4_weight_floats();
 // UpConv's fused upsample) or 16 (the zero-padded network input): every 3x3 conv of the convunet by default
 hipError_t launch_conv3x3h(const ConvArgs& a, int cin, int epi, hipStream_t s);
 size_t conv3x3h_weight_bytes(int cin);
+// preprocessing_layer composed with the first source of EncoderConvs[0][0]: one 5x5 conv of the 16-channel network input
+// (conv3x3h.hip HGeo KS = 5; runtime.hip compose_pre_enc0), and the fix of its border ring: part -= sum over the 3x3 taps d
+// whose pixel q = p + d - 1 lies OUTSIDE the image of W2[d] (b1 + sum over taps e inside the image of W1[e] x(q + e - 1))
+hipError_t launch_conv5x5h_c16(const ConvArgs& a, hipStream_t s);
+size_t conv5x5h_weight_bytes();
+hipError_t launch_pre_border_fix(const float* netin, const float* w1, const float* b1, const float* w2, float* part, int B, int H, int W,
+                                 hipStream_t s);
 void conv3x3h_set_groups(int g);   // 1 (default) = one 16x16 tile per workgroup; 2 = two groups of four waves with an 8x16 tile each (A/B)
 void conv3x3_set_variant(int v);   // A/B switch used by rvdd_debug_conv_bench only
 

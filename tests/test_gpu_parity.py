@@ -880,6 +880,44 @@ def test_split_path_any_magnitude(arch, stem, fut, mag):
         assert err < 1e-4 * scale, (arch, mag, t, err, scale)
 
 
+def test_composed_first_layer_matches_two_convs():
+    """preprocessing_layer has no activation (networks/unet.py:742), so it and the first source of EncoderConvs[0][0] (:743) are
+    one linear map of the network input: the default path runs them as ONE 5x5 conv with host-composed filters plus a fix of the
+    border ring (the reference zero-pads BETWEEN the two convs).  Against the two convs one after the other (option "fuse_pre"
+    0): the same map in another summation order -- max-abs < 5e-6 on frames and < 3e-5 on the features, over three recurrent
+    steps, with and without a future frame, at sizes with ragged tiles, one-tile images (every pixel within two of the border)
+    and batches; and the border ring itself (rows / columns 0, 1 and the last two) no worse than the interior."""
+    from rvdd_release_amd import synth
+    from rvdd_release_amd.runtime import RvddRuntime
+    for stem, fut in (("recurrent-convunet+feat-iso3200", 0), ("recurrent-convunet+feat-future-iso12800", 1)):
+        sd = load_weights(stem)
+        for B, H, W in ((1, 16, 16), (2, 72, 104), (1, 180, 320), (3, 50, 66)):
+            T = 4 + fut
+            seqs = [synth.make_sequence(T, H, W, iso=3200, seed=1200 + b, device="cuda") for b in range(B)]
+            st = lambda f: torch.stack([f(s) for s in seqs], 0)
+            outs = []
+            for fuse in (1, 0):
+                rt = RvddRuntime("convunet+feat", fut, B, H, W, 0)
+                rt.set_option("fuse_pre", fuse)
+                rt.load_state_dict(sd)
+                o = []
+                for t in range(1, T - fut):
+                    o.append(rt.step(st(lambda s: s.raw[t - 1]) if t == 1 else None, st(lambda s: s.raw[t]),
+                                     st(lambda s: s.raw[t + 1]) if fut else None, st(lambda s: s.flow_prev[t]),
+                                     st(lambda s: s.flow_next[t]) if fut else None).clone())
+                o.append(rt.get_state()[1])
+                outs.append(o)
+                rt.close()
+            for k, (a, b) in enumerate(zip(*outs)):
+                d = (a - b).abs()
+                bar = 3e-5 if k == len(outs[0]) - 1 else 5e-6      # (features reach 8: 3e-5 is 4e-6 of their range)
+                assert float(d.max()) < bar, (stem, B, H, W, k, float(d.max()))
+                ring = torch.ones_like(d, dtype=torch.bool)
+                ring[..., 2:-2, 2:-2] = False
+                if (~ring).any():
+                    assert float(d[ring].max()) <= max(4 * float(d[~ring].max()), 1e-6), (stem, B, H, W, k, float(d[ring].max()), float(d[~ring].max()))
+
+
 def test_conv_two_wave_groups_same_bits():
     """Option "conv_groups" 2: the split-f16 conv kernel's eight waves as two groups of four, each on an 8x16-pixel tile with halo
     planes and an LDS-counter barrier of its own, instead of all eight on one 16x16-pixel tile.  The same sums in the same order:

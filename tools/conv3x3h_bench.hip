@@ -2,7 +2,11 @@
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 -DRVDD_STAMPS -Irvdd-release_amd/csrc tools/conv3x3h_bench.hip -o /tmp/c3hb && /tmp/c3hb [B H W]
 // Prints microseconds per launch (HIP events), shader cycles per tile and phase of wave 0 (s_memtime), and the clock
 // the two imply.
+#ifdef CONV_SRC          // an instrumented copy of the kernel (tools/conv3x3h_xp_patch.py)
+#include CONV_SRC
+#else
 #include "../rvdd-release_amd/csrc/conv3x3h.hip"
+#endif
 
 #include <cmath>
 #include <cstdio>

@@ -1,0 +1,84 @@
+#!/usr/bin/env python3
+"""Writes a copy of rvdd-release_amd/csrc/conv3x3h.hip with the timing-only switches of the round-4 "what bounds a tile"
+experiment (profiles/r04_conv3x3h_tile_loop_parts.txt): -DRVDD_XP=<bits>, 1 no MFMAs, 2 no halo loads / split / staging
+stores in the loop, 4 no result stores, 8 fragment reads for the first two chunks only, 16 no epilogue arithmetic,
+32 no barriers.  The shipping kernel carries none of them.
+    python tools/conv3x3h_xp_patch.py tools/scratch/conv3x3h_xp.hip
+    hipcc -O3 -std=c++17 --offload-arch=gfx950 -DRVDD_STAMPS -DRVDD_XP=3 -DCONV_SRC='"scratch/conv3x3h_xp.hip"' \
+          -Irvdd-release_amd/csrc -Itools tools/conv3x3h_bench.hip -o /tmp/c3hb && /tmp/c3hb 4 720 1280 1
+"""
+import os, sys
+
+src = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "rvdd-release_amd", "csrc", "conv3x3h.hip")
+s = open(src).read()
+
+
+def rep(a, b):
+    global s
+    assert s.count(a) == 1, (s.count(a), a)
+    s = s.replace(a, b)
+
+
+rep('''                        acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Af[cb][mt][ha], Bf[cb][nt][hb], c, 0, 0, 0);''',
+    '''#if RVDD_XP & 1
+                        acc[nt][mt] = c;
+                        asm volatile("" : "+v"(acc[nt][mt]) : "v"(Af[cb][mt][ha]), "v"(Bf[cb][nt][hb]));
+#else
+                        acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Af[cb][mt][ha], Bf[cb][nt][hb], c, 0, 0, 0);
+#endif''')
+rep('''                if (j >= SH && j - SH < G::NR) fetch_round(qn, j - SH);''',
+    '''#if !(RVDD_XP & 2)
+                if (j >= SH && j - SH < G::NR) fetch_round(qn, j - SH);
+#endif''')
+rep('''                        split4<SC>(pre[r0], sc_nxt, shi[r0], slo[r0]);
+                        asm volatile("" : "+v"(shi[r0]), "+v"(slo[r0]));''',
+    '''#if !(RVDD_XP & 2)
+                        split4<SC>(pre[r0], sc_nxt, shi[r0], slo[r0]);
+                        asm volatile("" : "+v"(shi[r0]), "+v"(slo[r0]));
+#endif''')
+i = s.rindex('        write_tile();')
+s = s[:i] + '''#if !(RVDD_XP & 2)
+        write_tile();
+#endif''' + s[i + len('        write_tile();'):]
+rep('''    auto store_prev = [&](int i) {
+        bstore(''', '''    auto store_prev = [&](int i) {
+#if RVDD_XP & 4
+        asm volatile("" : : "v"(outv[i]));
+        return;
+#endif
+        bstore(''')
+rep('''    auto read_frags = [&](int buf, int j) {''', '''    auto read_frags = [&](int buf, int j) {
+#if RVDD_XP & 8
+        if (j >= 2) return;
+#endif''')
+# 16: the epilogue's arithmetic (scale / bias / activation / maxima) replaced by a copy of the accumulators
+rep('''        f32x4 v[2][3];
+        float m3 = 0.f;''', '''#if RVDD_XP & 16
+        {
+            constexpr int NO = EPI == EPI_POOL ? 3 : 6;
+            for (int i = 0; i < NO; ++i) outv[i] = acc[i / 3][i % 3];
+            so_prev[0] = so[0];
+            so_prev[1] = so[1];
+            orr_prev = __builtin_amdgcn_make_buffer_rsrc((void*)(a.out + (size_t)cur.b * a.Hout * a.Wout * kF), 0, out_bytes, 0x00020000);
+            goto after_epilogue;
+        }
+#endif
+        f32x4 v[2][3];
+        float m3 = 0.f;''')
+rep('''        STAMP(4);
+        gsync();               // every wave of the group has read its last fragment''', '''#if RVDD_XP & 16
+    after_epilogue:
+#endif
+        STAMP(4);
+        gsync();               // every wave of the group has read its last fragment''')
+rep('''    auto gsync = [&]() {
+        if constexpr (NGRP == 1) {''', '''    auto gsync = [&]() {
+#if RVDD_XP & 32
+        return;
+#endif
+        if constexpr (NGRP == 1) {''')
+s = s.replace('#include "rvdd_internal.h"', '#ifndef RVDD_XP\n#define RVDD_XP 0\n#endif\n#include "rvdd_internal.h"', 1)
+out = sys.argv[1]
+os.makedirs(os.path.dirname(out) or ".", exist_ok=True)
+open(out, "w").write(s)
+print("wrote", out)

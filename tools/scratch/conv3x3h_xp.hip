@@ -35,6 +35,9 @@
 // beside the first tile's halo fetch.  Wave w owns tile rows 2w, 2w+1 (two B
 // fragments per chunk) and all 48 couts (three A fragments): per chunk 6 + 4 ds_read_b128 (hi and lo) feed 18 MFMAs on
 // six accumulators, the fragments of the next chunk being read while the current one is multiplied.
+#ifndef RVDD_XP
+#define RVDD_XP 0
+#endif
 #include "rvdd_internal.h"
 
 #include <type_traits>
@@ -48,7 +51,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) void lds_void;
 
-constexpr int TW = 16;
+constexpr int TW = 16, IW = TW + 2;
 constexpr int NTHREADS = 512;
 
 // NGRP = 1 (the default): the eight waves of a workgroup share one 16x16-pixel tile.  NGRP = 2 (round 4, option "conv_groups"):
@@ -57,19 +60,13 @@ constexpr int NTHREADS = 512;
 // other group's wave keeps the SIMD's matrix pipe busy.  Same sums in the same order, same bits; 2.6 % faster on its own
 // (tools/conv3x3h_bench.hip), nothing in the net (profiles/r04_conv_two_groups_ab.txt): the tile loop is bound by what it
 // issues besides the MFMAs (profiles/r04_conv3x3h_tile_loop_parts.txt), and the 8-row tile's halo is 1.41x its pixels.
-// KS = 3: the convunet's 3x3 convs.  KS = 5, CIN = 16: preprocessing_layer (3x3, no activation, unet.py:742) composed with the
-// first source of EncoderConvs[0][0] (3x3) into ONE 5x5 conv of the network input -- two linear maps in a row are one linear
-// map (runtime.hip: compose_pre_enc0); what the zero padding BETWEEN the two does at the image border is put right by
-// pre_border_fix_kernel below.
-template <int CIN, int NGRP, int KS = 3>
+template <int CIN, int NGRP>
 struct HGeo {
-    static constexpr int PAD = KS / 2;
-    static constexpr int TH = 16 / NGRP, IH = TH + KS - 1;   // tile rows of a group (two per wave), with halo
-    static constexpr int IW = TW + KS - 1;
+    static constexpr int TH = 16 / NGRP, IH = TH + 2;        // tile rows of a group (two per wave), with halo
     static constexpr int NT = NTHREADS / NGRP;               // threads of a group
     static constexpr int WPG = NT / 64;                      // waves of a group
     static constexpr int GPT = CIN / 8;                      // 8-channel groups per tap
-    static constexpr int NG = KS * KS * GPT;                 // groups of the whole filter
+    static constexpr int NG = 9 * GPT;                       // groups of the whole filter
     static constexpr int NCH = (NG + 3) / 4;                 // K chunks of 32 (one MFMA deep)
     static constexpr int HI = CIN * 2;                       // bytes of one pixel's hi half
     static constexpr int S = HI;                             // LDS bytes per pixel in EACH of the two planes (hi, lo): 96 / 32, an odd multiple of
@@ -151,11 +148,10 @@ __device__ unsigned long long g_stamps[8 * 8];      // [wave][phase 0..6, tiles]
 // bilinear x2 upsample (align_corners=False), interpolated in the halo fetch (2x2 blocks of halo pixels from four source
 // pixels each) with the expressions of upsample2x_kernel (prestage.hip) in the same order: the same bits as "upsample,
 // then conv", the upsampled map is never written.
-template <int CIN, int EPI, bool ACC_IN, bool UPS = false, int NGRP = 2, int KS = 3>
+template <int CIN, int EPI, bool ACC_IN, bool UPS = false, int NGRP = 2>
 __global__ __launch_bounds__(NTHREADS) void conv3x3h_kernel(ConvArgs a) {
-    using G = HGeo<CIN, NGRP, KS>;
-    constexpr int TH = G::TH, IH = G::IH, IW = G::IW, PAD = G::PAD;
-    static_assert(KS == 3 || (!UPS && !ACC_IN), "the 5x5 form exists for the composed first layer only");
+    using G = HGeo<CIN, NGRP>;
+    constexpr int TH = G::TH, IH = G::IH;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     typedef __attribute__((address_space(3))) unsigned char lds_u8;
     typedef __attribute__((address_space(3))) f32x4 lds_f4;
@@ -275,15 +271,15 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3h_kernel(ConvArgs a) {
         const int ih = UPS ? a.H >> 1 : a.H, iw = UPS ? a.W >> 1 : a.W;
         q.r = __builtin_amdgcn_make_buffer_rsrc((void*)(a.in + (size_t)(live ? p.b : 0) * ih * iw * CIN), 0,
                                                 live ? (unsigned)(ih * iw * CIN * 4) : 0, 0x00020000);
-        q.org = ((p.y0 - PAD) * a.W + (p.x0 - PAD)) * (CIN * 4);
-        q.xok = ld_thread && (unsigned)(p.x0 - PAD + hx) < (unsigned)a.W;
+        q.org = ((p.y0 - 1) * a.W + (p.x0 - 1)) * (CIN * 4);
+        q.xok = ld_thread && (unsigned)(p.x0 - 1 + hx) < (unsigned)a.W;
         q.y0 = p.y0;
         q.x0 = p.x0;
         return q;
     };
     auto fetch_round = [&](const Src& q, int r0) {
         const int hy = G::RPR * r0 + rp;
-        const bool ok = q.xok && hy < IH && (unsigned)(q.y0 - PAD + hy) < (unsigned)a.H;
+        const bool ok = q.xok && hy < IH && (unsigned)(q.y0 - 1 + hy) < (unsigned)a.H;
         const int off = g_lane + q.org + r0 * G::RPR * a.W * (CIN * 4);
         pre[r0] = bload(q.r, ok ? (unsigned)off : 0x80000000u);
     };
@@ -378,13 +374,16 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3h_kernel(ConvArgs a) {
         if (Gi >= G::NG) Gi = G::NG - 1;          // the zero-filter groups of the last chunk: any valid address
         const int tap = Gi / G::GPT;
         const int c0 = (Gi - tap * G::GPT) * 8;
-        const int ky = tap / KS, kx = tap - KS * ky;
+        const int ky = tap / 3, kx = tap - 3 * ky;
         boff[j] = plane0 + (unsigned)(((2 * gw + ky) * IW + n + kx) * G::S + c0 * 2);
     }
     unsigned abase[2] = {(unsigned)(lane * 16), (unsigned)(lane * 16 + G::A_SPLIT * 6 * 1024)};
     asm volatile("" : "+v"(abase[0]), "+v"(abase[1]));
     h8 Af[2][3][2], Bf[2][2][2];
     auto read_frags = [&](int buf, int j) {
+#if RVDD_XP & 8
+        if (j >= 2) return;
+#endif
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
@@ -420,6 +419,9 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3h_kernel(ConvArgs a) {
     lds_u32* gbar = (lds_u32*)(lds_u8*)(smem + G::W_BYTES + NGRP * G::I_BYTES + (G::P_FLOATS - 4) * 4) + grp;
     unsigned gcount = 0;
     auto gsync = [&]() {
+#if RVDD_XP & 32
+        return;
+#endif
         if constexpr (NGRP == 1) {
             __syncthreads();
         } else {
@@ -478,6 +480,10 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3h_kernel(ConvArgs a) {
     for (int i = 0; i < NOUT; ++i) outv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     // one 16-B piece of the previous tile's results: they ride between the chunks of the current tile's MFMA loop
     auto store_prev = [&](int i) {
+#if RVDD_XP & 4
+        asm volatile("" : : "v"(outv[i]));
+        return;
+#endif
         bstore(orr_prev, so_prev[EPI == EPI_POOL ? 0 : i / 3] + 64 * (i % 3), outv[i]);
     };
     STAMP_DECL;
@@ -545,12 +551,16 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3h_kernel(ConvArgs a) {
                     }
                 }
             } else {
+#if !(RVDD_XP & 2)
                 if (j >= SH && j - SH < G::NR) fetch_round(qn, j - SH);
+#endif
 #pragma unroll
                 for (int r0 = 0; r0 < G::NR; ++r0)
                     if (j == G::NCH - 1 - (G::NR - 1 - r0) / 3) {
+#if !(RVDD_XP & 2)
                         split4<SC>(pre[r0], sc_nxt, shi[r0], slo[r0]);
-                        asm volatile("" : "+v"(shi[r0]), "+v"(slo[r0]));      // here, not sunk behind the barrier next to its use
+                        asm volatile("" : "+v"(shi[r0]), "+v"(slo[r0]));
+#endif      // here, not sunk behind the barrier next to its use
                     }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -562,7 +572,12 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3h_kernel(ConvArgs a) {
 #pragma unroll
                     for (int mt = 0; mt < 3; ++mt) {
                         const f32x4 c = (j == 0 && p == 0) ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[nt][mt];
+#if RVDD_XP & 1
+                        acc[nt][mt] = c;
+                        asm volatile("" : "+v"(acc[nt][mt]) : "v"(Af[cb][mt][ha]), "v"(Bf[cb][nt][hb]));
+#else
                         acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Af[cb][mt][ha], Bf[cb][nt][hb], c, 0, 0, 0);
+#endif
                     }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -573,6 +588,16 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3h_kernel(ConvArgs a) {
 
         // ---- epilogue: scale back, bias / partial sums, activation; the 48-channel results wait in registers for the
         // next tile's chunks
+#if RVDD_XP & 16
+        {
+            constexpr int NO = EPI == EPI_POOL ? 3 : 6;
+            for (int i = 0; i < NO; ++i) outv[i] = acc[i / 3][i % 3];
+            so_prev[0] = so[0];
+            so_prev[1] = so[1];
+            orr_prev = __builtin_amdgcn_make_buffer_rsrc((void*)(a.out + (size_t)cur.b * a.Hout * a.Wout * kF), 0, out_bytes, 0x00020000);
+            goto after_epilogue;
+        }
+#endif
         f32x4 v[2][3];
         float m3 = 0.f;        // EPI_RELU_OUT3: max |output frame| over this lane's two pixels
         const float ws = SC ? a.wscale * inv_cur : a.wscale;      // the filters' and the map's powers of two, undone together
@@ -670,6 +695,9 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3h_kernel(ConvArgs a) {
         so_prev[0] = so[0];
         so_prev[1] = so[1];
         orr_prev = __builtin_amdgcn_make_buffer_rsrc((void*)(a.out + (size_t)cur.b * a.Hout * a.Wout * kF), 0, out_bytes, 0x00020000);
+#if RVDD_XP & 16
+    after_epilogue:
+#endif
         STAMP(4);
         gsync();               // every wave of the group has read its last fragment of this tile: the next one may be staged
         STAMP(5);
@@ -677,7 +705,9 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3h_kernel(ConvArgs a) {
             if (gw == 0) amax_send(pend_b);
             pend_b = -1;
         }
+#if !(RVDD_XP & 2)
         write_tile();
+#endif
         STAMP(6);
 #ifdef RVDD_STAMPS
         ++st_n;
@@ -701,12 +731,12 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3h_kernel(ConvArgs a) {
     else tile_loop(std::false_type{});
 }
 
-template <int CIN, int EPI, bool ACC_IN, bool UPS, int NGRP, int KS = 3>
+template <int CIN, int EPI, bool ACC_IN, bool UPS, int NGRP>
 hipError_t launch_g(const ConvArgs& a0, hipStream_t s) {
     static std::atomic<uint64_t> attr_done{0};
-    using G = HGeo<CIN, NGRP, KS>;
+    using G = HGeo<CIN, NGRP>;
     constexpr int TH = G::TH;
-    void (*kern)(ConvArgs) = conv3x3h_kernel<CIN, EPI, ACC_IN, UPS, NGRP, KS>;
+    void (*kern)(ConvArgs) = conv3x3h_kernel<CIN, EPI, ACC_IN, UPS, NGRP>;
     if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(kern), G::LDS_BYTES, attr_done); e != hipSuccess) return e;
     ConvArgs a = a0;
     a.tiles_x = (a.W + TW - 1) / TW;
@@ -728,15 +758,6 @@ hipError_t launch_h(const ConvArgs& a, hipStream_t s) {
 }  // namespace
 
 size_t conv3x3h_weight_bytes(int cin) { return cin == 48 ? HGeo<48, 1>::W_BYTES : HGeo<16, 1>::W_BYTES; }
-size_t conv5x5h_weight_bytes() { return HGeo<16, 1, 5>::W_BYTES; }
-
-// the composed 5x5 conv of the 16-channel network input (see HGeo): a.w = the bank arranged by arrange_conv3x3h(.., ks = 5), no
-// activation, a.bias = the composed bias; a.out = the partial sums the second source's pass starts from
-hipError_t launch_conv5x5h_c16(const ConvArgs& a, hipStream_t s) {
-    if (a.B <= 0 || a.H <= 0 || a.W <= 0) return hipSuccess;
-    if ((size_t)a.H * a.W * kF * 4 >= 0x80000000ull || a.acc_in || a.ups) return hipErrorInvalidValue;
-    return launch_g<16, EPI_NONE, false, false, 1, 5>(a, s);
-}
 void conv3x3h_set_groups(int g) { g_conv3x3h_groups = g == 1 ? 1 : 2; }
 
 hipError_t launch_conv3x3h(const ConvArgs& a, int cin, int epi, hipStream_t s) {
