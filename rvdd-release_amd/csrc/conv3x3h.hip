@@ -612,7 +612,7 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3h_kernel(ConvArgs a) {
                     f32x4 x = v[nt][mt];
                     if constexpr (EPI == EPI_RELU || EPI == EPI_RELU_ADD2 || EPI == EPI_RELU_OUT3) {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) x[e] = fmaxf(x[e], 0.f);
+                        for (int e = 0; e < 4; ++e) x[e] = __builtin_amdgcn_fmed3f(x[e], 0.f, __builtin_inff());      // ONE instruction (fmaxf: a canonicalising v_max in front)
                     }
                     if constexpr (EPI == EPI_RELU_ADD2) x = (bload(r1, po[nt], 64 * mt) + bload(r2, po[nt], 64 * mt)) + x;   // e3 + d1 + d2 (unet.py:563-566)
                     outv[nt * 3 + mt] = x;
@@ -658,14 +658,19 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3h_kernel(ConvArgs a) {
                 amx = 0.f;
                 amx_b = cur.b;
             }
+            // (v_max3_f32 with |.| operands, two values per instruction; outv comes from vector instructions, not straight out of
+            // an MFMA, so inline asm is safe here)
             float m0 = 0.f, m1 = 0.f;
 #pragma unroll
             for (int i = 0; i < NOUT; ++i) {
-                const float mi = fmaxf(fmaxf(fabsf(outv[i][0]), fabsf(outv[i][1])), fmaxf(fabsf(outv[i][2]), fabsf(outv[i][3])));
-                if (EPI == EPI_POOL || i < 3) m0 = fmaxf(m0, mi);
-                else m1 = fmaxf(m1, mi);
+                float& m = (EPI == EPI_POOL || i < 3) ? m0 : m1;
+                asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(m) : "v"(outv[i][0]), "v"(outv[i][1]));
+                asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(m) : "v"(outv[i][2]), "v"(outv[i][3]));
             }
-            amx = fmaxf(fmaxf(amx, m3), fmaxf(so[0] == 0x80000000u ? 0.f : m0, so[1] == 0x80000000u ? 0.f : m1));
+            if (so[0] == 0x80000000u) m0 = 0.f;
+            if (so[1] == 0x80000000u) m1 = 0.f;
+            asm("v_max3_f32 %0, %0, %1, %2" : "+v"(amx) : "v"(m0), "v"(m1));
+            amx = fmaxf(amx, m3);
         }
         so_prev[0] = so[0];
         so_prev[1] = so[1];

@@ -287,9 +287,17 @@ __global__ __launch_bounds__(256) void netin_kernel(const float* __restrict__ ra
 // PostConvs wrote in the last step: features and output frame together); grid (blocks, B).
 __global__ __launch_bounds__(256) void netin_bound_kernel(const float* __restrict__ raw_a, const float* __restrict__ raw_b,
                                                           const float* __restrict__ raw_c, int64_t n, int64_t rbs,
-                                                          const unsigned* __restrict__ prev_words, unsigned* __restrict__ words) {
+                                                          const unsigned* __restrict__ prev_words, unsigned* __restrict__ words,
+                                                          unsigned* __restrict__ zero_a, size_t zero_na, unsigned* __restrict__ zero_b,
+                                                          size_t zero_nb) {
     __shared__ unsigned red[4];
     const int b = blockIdx.y;
+    // housekeeping for the step AFTER this one: its set of amax words and its features slot, which nobody touches meanwhile
+    {
+        const size_t me = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 256 + threadIdx.x, all = (size_t)gridDim.x * gridDim.y * 256;
+        if (zero_a) for (size_t i = me; i < zero_na; i += all) zero_a[i] = 0u;
+        if (zero_b) for (size_t i = me; i < zero_nb; i += all) zero_b[i] = 0u;
+    }
     float m = 0.f;
     for (int pass = 0; pass < 3; ++pass) {
         const float* src = pass == 0 ? raw_a : pass == 1 ? raw_b : raw_c;
@@ -656,14 +664,15 @@ hipError_t launch_netin(const float* raw_cur, float* green_scratch, const float*
 }
 
 hipError_t launch_netin_bound(const float* raw_a, const float* raw_b, const float* raw_c, int B, int h, int w, int64_t raw_bstride,
-                              const unsigned* prev_words, unsigned* words, hipStream_t s) {
+                              const unsigned* prev_words, unsigned* words, hipStream_t s, unsigned* zero_a, size_t zero_na,
+                              unsigned* zero_b, size_t zero_nb) {
     const int64_t n = (int64_t)4 * h * w;
     if (B <= 0 || n <= 0) return hipSuccess;
     if ((n & 3) || (raw_bstride & 3)) return hipErrorInvalidValue;      // 16-B loads (n = 4hw: always)
     int nblk = (int)((n / 4 + 256 * 8 - 1) / (256 * 8));
     nblk = nblk < 1 ? 1 : (nblk > 64 ? 64 : nblk);
     hipLaunchKernelGGL(netin_bound_kernel, dim3(nblk, B), dim3(256), 0, s, raw_a, raw_b, raw_c, n, raw_bstride ? raw_bstride : n,
-                       prev_words, words);
+                       prev_words, words, zero_a, zero_na, zero_b, zero_nb);
     return hipGetLastError();
 }
 

@@ -89,14 +89,16 @@ constexpr int cu_down(int i) { return CU_DOWN0 + 3 * i; }
 constexpr int cu_up(int i) { return CU_UP0 + 3 * i; }
 constexpr int cu_dec(int i, int j) { return CU_DEC0_0 + 3 * i + j; }
 // amax words (rvdd_internal.h: block floating point of the split-f16 kernels): one slot of B x kAmaxSeqWords words per map a
-// split kernel reads -- the output of every conv layer (AMAX_LAYER0 + its CuLayer), the network input, the features a caller
-// hands to rvdd_unet_forward, and the RECURRENT features: the map PostConvs[0] writes in one step is the map the next step
-// gathers its warped features from (a bicubic gather never exceeds 1.9 x the map's maximum, far inside the margin of the
-// scaling, so the warped map shares the words), which makes its words the one slot that must survive the zeroing at the
-// start of a step -- two of them, used in turn (rvdd_handle::feat_par), at the two ends of the array so that "everything
-// except the one being read" is one contiguous memset.
-enum { AMAX_FEAT0 = 0, AMAX_LAYER0 = 1, AMAX_NETIN = AMAX_LAYER0 + CU_COUNT, AMAX_FWDFEAT, AMAX_FEAT1, AMAX_SLOTS };
-constexpr int amax_layer(int layer) { return AMAX_LAYER0 + layer; }
+// split kernel reads.  A SET of regular slots -- the output of every conv layer (its CuLayer), the network input, the features
+// a caller hands to rvdd_unet_forward -- is written during one forward and must be zero when it starts.  Three sets: frame-steps
+// use sets 0 and 1 in turn, and the first kernel of a step (netin_bound_kernel) zeroes the OTHER set for the step after it
+// (nobody touches that set during this step; a memset node per step cost 2 % of a 0.3 ms frame); rvdd_unet_forward uses set 2
+// and zeroes it itself.  The RECURRENT features' words cross the step boundary: the map PostConvs[0] writes in step t is the
+// map step t + 1 gathers its warped features from (a bicubic gather never exceeds 1.9 x the map's maximum, far inside the
+// margin of the scaling, so the warped map shares the words) -- three slots in rotation: step t reads (t + 2) % 3, writes
+// t % 3, and its first kernel zeroes (t + 1) % 3.
+enum { AMAX_REL_NETIN = CU_COUNT, AMAX_REL_FWDFEAT, AMAX_NREG };
+enum { AMAX_FEAT0 = 3 * AMAX_NREG, AMAX_SLOTS = AMAX_FEAT0 + 3 };
 
 // The ConvBlocks of the ConvNeXt net by position in the schedule (run_convnext), resolved once like the above.
 enum NxBlock {
@@ -177,8 +179,10 @@ struct rvdd_handle {
     float* featw = nullptr;      // NHWC48 warped features
     float* lastfeat = nullptr;   // NHWC48 recurrent features
     unsigned* amax = nullptr;    // [AMAX_SLOTS][B][kAmaxSeqWords] max |x| per map and sequence, zeroed at the start of every forward
-    int feat_par = 0;            // the recurrent features' words: a step reads AMAX_FEAT[feat_par ^ 1] and writes AMAX_FEAT[feat_par]
-    int amax_feat_in = AMAX_FWDFEAT, amax_post_out = amax_layer(CU_POST);      // what the current forward uses for the two
+    int step_ctr = 0;            // frame-steps enqueued: picks the regular set (& 1) and the recurrent features' slots (% 3)
+    int amax_base = 0;           // first slot of the regular set the current forward uses
+    int amax_feat_in = 0, amax_post_out = 0;      // absolute slots the current forward reads the old features' words from / writes the new ones to
+    bool amax_zero_pending = false;               // the next netin_bound launch zeroes the step-after-next's set and features slot
     double* loss_partial = nullptr;
     double* loss_result = nullptr;
     float* scratch = nullptr;
@@ -607,7 +611,7 @@ const char* conv_name_h(int epi, bool acc) {
 // the amax words (rvdd_internal.h) of map `slot`, from sequence b0 on
 unsigned* amax_words(const rvdd_t* h, int slot, size_t b0 = 0) { return h->amax + ((size_t)slot * h->cfg.batch + b0) * kAmaxSeqWords; }
 constexpr size_t amax_bytes(int B, int nslots) { return (size_t)nslots * B * kAmaxSeqWords * sizeof(unsigned); }
-constexpr int amax_feat_slot(int par) { return par ? AMAX_FEAT1 : AMAX_FEAT0; }
+int amax_layer(const rvdd_t* h, int layer) { return h->amax_base + layer; }
 
 struct ConvCall {
     const float* in = nullptr;
@@ -737,7 +741,7 @@ int run_pre5(rvdd_t* h, const float* netin, float* part, hipStream_t s, Sub sub)
     a.B = sub.nb;
     a.H = a.Hout = H;
     a.W = a.Wout = W;
-    a.amax_in = h->bfp ? amax_words(h, AMAX_NETIN, sub.b0) : nullptr;
+    a.amax_in = h->bfp ? amax_words(h, h->amax_base + AMAX_REL_NETIN, sub.b0) : nullptr;
     const double px = (double)sub.nb * H * W;
     {
         Scope sc(h, s, "conv5x5h_kernel<16>", 2.0 * 25.0 * h->cin_real() * 48.0 * px, px * 4.0 * (h->cin_real() + 48.0));
@@ -770,10 +774,11 @@ int run_convunet(rvdd_t* h, const float* netin, const float* featw, float* feat_
     auto conv = [&](int layer, const float* in, int from, float* out, int lvl, int epi, Sub sub) {
         ConvCall c;
         c.in = in; c.out = out; c.H = lv[lvl].H; c.W = lv[lvl].W; c.epi = epi;
-        c.amax_in = from; c.amax_out = amax_layer(layer);
+        c.amax_in = from; c.amax_out = amax_layer(h, layer);
         return run_conv(h, cu[layer], c, s, sub);
     };
-    const auto L = amax_layer;
+    const auto L = [&](int layer) { return amax_layer(h, layer); };
+    const int AMAX_NETIN = h->amax_base + AMAX_REL_NETIN;
     // two-source (virtual concat) conv: pass 1 leaves bias + sum over source A in `part`
     auto conv2 = [&](int layer, const float* inA, int fromA, const float* inB, int fromB, float* out, int lvl, Sub sub) {
         ConvCall c;
@@ -781,7 +786,7 @@ int run_convunet(rvdd_t* h, const float* netin, const float* featw, float* feat_
         c.amax_in = fromA;
         RC(run_conv(h, cu[layer], c, s, sub));
         c.in = inB; c.src = 1; c.acc_in = lv[lvl].part; c.out = out; c.epi = EPI_RELU;
-        c.amax_in = fromB; c.amax_out = amax_layer(layer);
+        c.amax_in = fromB; c.amax_out = amax_layer(h, layer);
         return run_conv(h, cu[layer], c, s, sub);
     };
     const Sub all{0, B};
@@ -1311,7 +1316,14 @@ int run_prologue(rvdd_t* h, const StepInputs& in, Sub sb, hipStream_t s) {
     float* netin = h->netin + o * img * kNetInC;
     // amax words of the maps the split-f16 convs read first (block floating point, rvdd_internal.h)
     const bool bfp = h->bfp && h->split16 && !h->is_next();
-    unsigned* amax_netin = bfp ? amax_words(h, AMAX_NETIN, o) : nullptr;
+    unsigned* amax_netin = bfp ? amax_words(h, h->amax_base + AMAX_REL_NETIN, o) : nullptr;
+    // the zeroing for the step after this one rides in the first netin_bound launch of the step; a step without one memsets
+    const int t1 = h->step_ctr + 1;
+    unsigned* zero_a = amax_words(h, (t1 & 1) * AMAX_NREG);
+    unsigned* zero_b = amax_words(h, AMAX_FEAT0 + t1 % 3);
+    const size_t zero_na = amax_bytes(h->cfg.batch, AMAX_NREG) / 4, zero_nb = amax_bytes(h->cfg.batch, 1) / 4;
+    const bool zero_now = bfp && h->amax_zero_pending;
+    h->amax_zero_pending = false;
     if (h->warp_raw && !nw) {
         // warp_frame with --warp_raw (models/recurrent_model.py:149-152): HA(warp(remosaick(frame), raw-resolution flow)).
         // remosaick(HA(raw)) is raw itself, so the next frame is warped as it came.  next4 is free in this mode: its
@@ -1337,6 +1349,10 @@ int run_prologue(rvdd_t* h, const StepInputs& in, Sub sb, hipStream_t s) {
             }
         }
         if (amax_netin) HIPCHK(h, launch_amax_reduce(netin, n, (int64_t)img * kNetInC, amax_netin, s));
+        if (zero_now) {
+            HIPCHK(h, hipMemsetAsync(zero_a, 0, zero_na * 4, s));
+            HIPCHK(h, hipMemsetAsync(zero_b, 0, zero_nb * 4, s));
+        }
     } else {
         // the whole NHWC16 input pixel in one pass: warp of the previous output | demosaic of the current frame |
         // warp of the demosaicked next frame
@@ -1351,7 +1367,8 @@ int run_prologue(rvdd_t* h, const StepInputs& in, Sub sb, hipStream_t s) {
             // with --prev_noisy_frame the "previous output" is a demosaicked frame whose raw data is gone: its own maximum
             const float* rp_ = in.raw_prev ? in.raw_prev + o * in.rawf : nullptr;
             HIPCHK(h, launch_netin_bound(rc_, rn_, rp_, n, H / 2, W / 2, (int64_t)in.rawf,
-                                         in.raw_prev ? nullptr : amax_words(h, h->amax_feat_in, o), amax_netin, s));
+                                         in.raw_prev ? nullptr : amax_words(h, h->amax_feat_in, o), amax_netin, s,
+                                         zero_now ? zero_a : nullptr, zero_na, zero_now ? zero_b : nullptr, zero_nb));
             if (h->prev_noisy && !in.raw_prev) HIPCHK(h, launch_amax_reduce(h->lastden4 + o * img * 4, n, (int64_t)img * 4, amax_netin, s, 1));
         }
         HIPCHK(h, launch_netin(rc_, green, h->lastden4 + o * img * 4, fp_, next4, fn_, netin, n, H / 2, W / 2, s, (int64_t)in.rawf,
@@ -1376,11 +1393,13 @@ int enqueue_step(rvdd_t* h, const float* raw_prev, const float* raw_cur, const f
     in.rawf = raw_stride ? (size_t)raw_stride : (size_t)4 * (H / 2) * (W / 2);
     in.flowf = flow_stride ? (size_t)flow_stride : (size_t)2 * (H / 2) * (W / 2);
     // amax words: everything but the recurrent features' words this step reads (zero features at the start of a video: zero words)
-    h->amax_feat_in = amax_feat_slot(h->feat_par ^ 1);
-    h->amax_post_out = amax_feat_slot(h->feat_par);
+    h->amax_base = (h->step_ctr & 1) * AMAX_NREG;
+    h->amax_feat_in = AMAX_FEAT0 + (h->step_ctr + 2) % 3;
+    h->amax_post_out = AMAX_FEAT0 + h->step_ctr % 3;
     if (h->bfp && h->split16 && !h->is_next()) {
+        // the first step of a video starts from zero features: zero words; later steps find their set zeroed by the step before
         if (init) HIPCHK(h, hipMemsetAsync(h->amax, 0, amax_bytes(B, AMAX_SLOTS), s));
-        else HIPCHK(h, hipMemsetAsync(amax_words(h, h->feat_par ? AMAX_LAYER0 : AMAX_FEAT0), 0, amax_bytes(B, AMAX_SLOTS - 1), s));
+        h->amax_zero_pending = true;
     }
     if (init) {
         // lastden = n[:, :3] (demosaiced previous noisy frame), features = 0
@@ -1440,7 +1459,7 @@ int rvdd_step_strided(rvdd_t* h, const float* raw_prev, const float* raw_cur, co
         const int rc = enqueue_step(h, raw_prev, raw_cur, raw_next, flow_prev, flow_next, raw_stride, flow_stride, out_rgb, init, s);
         if (rc == RVDD_OK) {
             h->need_init = false;
-            h->feat_par ^= 1;          // the features' amax words this step wrote are the ones the next step reads
+            h->step_ctr = (h->step_ctr + 1) % 6;      // (the amax words' set and slots follow it: & 1, % 3)
         }
         return rc;
     };
@@ -1449,7 +1468,7 @@ int rvdd_step_strided(rvdd_t* h, const float* raw_prev, const float* raw_cur, co
         return eager();
     }
     rvdd_handle::StepKey key{{init ? raw_prev : nullptr, raw_cur, raw_next, flow_prev, flow_next, out_rgb},
-                             {raw_stride, flow_stride}, (init ? 1 : 0) | (h->serpentine ? 2 : 0) | (h->feat_par ? 4 : 0)};
+                             {raw_stride, flow_stride}, (init ? 1 : 0) | (h->serpentine ? 2 : 0) | (h->step_ctr << 2)};
     auto it = h->graphs.find(key);
     if (it == h->graphs.end()) {
         hipGraph_t g = nullptr;
@@ -1491,7 +1510,7 @@ int rvdd_step_strided(rvdd_t* h, const float* raw_prev, const float* raw_cur, co
     HIPCHK(h, hipEventRecord(h->g_out, h->gstream));
     HIPCHK(h, hipStreamWaitEvent(s, h->g_out, 0));
     h->need_init = false;
-    h->feat_par ^= 1;
+    h->step_ctr = (h->step_ctr + 1) % 6;
     if (seq_major_on(h)) h->serpentine = !h->serpentine;
     return RVDD_OK;
 }
@@ -1522,7 +1541,7 @@ int rvdd_set_state(rvdd_t* h, const float* lastden, const float* lastfeat, void*
         if (!h->has_feat()) return fail(h, RVDD_ERR_ARG, "rvdd_set_state: this architecture has no recurrent features");
         HIPCHK(h, launch_nchw_to_nhwc(lastfeat, h->lastfeat, B, kF, H, W, kF, s));
         if (h->bfp && h->split16 && !h->is_next()) {      // the words the next step reads for these features (block floating point)
-            unsigned* w = amax_words(h, amax_feat_slot(h->feat_par ^ 1));
+            unsigned* w = amax_words(h, AMAX_FEAT0 + (h->step_ctr + 2) % 3);
             HIPCHK(h, hipMemsetAsync(w, 0, amax_bytes(B, 1), s));
             HIPCHK(h, launch_amax_reduce(h->lastfeat, B, (int64_t)H * W * kF, w, s));
         }
@@ -1557,12 +1576,13 @@ int rvdd_unet_forward(rvdd_t* h, const float* x, const float* feat_in, float* ou
     HIPCHK(h, launch_nchw_to_nhwc(x, h->netin, B, h->cin_real(), H, W, kNetInC, s));
     if (h->has_feat()) HIPCHK(h, launch_nchw_to_nhwc(feat_in, h->featw, B, kF, H, W, kF, s));
     // amax words of the caller's maps (block floating point of the split-f16 convs); the recurrent features' words stay as they are
-    h->amax_feat_in = AMAX_FWDFEAT;
-    h->amax_post_out = amax_layer(CU_POST);
+    h->amax_base = 2 * AMAX_NREG;              // the set of its own: the frame-steps' sets and the recurrent slots stay untouched
+    h->amax_feat_in = h->amax_base + AMAX_REL_FWDFEAT;
+    h->amax_post_out = amax_layer(h, CU_POST);
     if (h->bfp && h->split16 && !h->is_next()) {
-        HIPCHK(h, hipMemsetAsync(amax_words(h, AMAX_LAYER0), 0, amax_bytes(B, AMAX_FEAT1 - AMAX_LAYER0), s));
-        HIPCHK(h, launch_amax_reduce(h->netin, B, (int64_t)H * W * kNetInC, amax_words(h, AMAX_NETIN), s));
-        if (h->has_feat()) HIPCHK(h, launch_amax_reduce(h->featw, B, (int64_t)H * W * kF, amax_words(h, AMAX_FWDFEAT), s));
+        HIPCHK(h, hipMemsetAsync(amax_words(h, h->amax_base), 0, amax_bytes(B, AMAX_NREG), s));
+        HIPCHK(h, launch_amax_reduce(h->netin, B, (int64_t)H * W * kNetInC, amax_words(h, h->amax_base + AMAX_REL_NETIN), s));
+        if (h->has_feat()) HIPCHK(h, launch_amax_reduce(h->featw, B, (int64_t)H * W * kF, amax_words(h, h->amax_feat_in), s));
     }
     RC(run_net(h, h->netin, h->featw, h->lv[0].t[2], out, nullptr, s, nullptr));
     if (h->has_feat() && feat_out) HIPCHK(h, launch_nhwc_to_nchw(h->lv[0].t[2], feat_out, B, kF, H, W, kF, s));

@@ -184,8 +184,10 @@ hipError_t launch_netin(const float* raw_cur, float* green_scratch, const float*
                         int64_t raw_bstride = 0, int64_t flow_bstride = 0);
 // amax words of that network input (block floating point of the split-f16 convs, below): an upper bound from the packed raw
 // frames it is made of (up to three, each nullable) and from `prev_words`, words that bound the previous output (nullable)
+// (zero_a / zero_b, nullable: word ranges the kernel also clears -- the next step's amax words, runtime.hip)
 hipError_t launch_netin_bound(const float* raw_a, const float* raw_b, const float* raw_c, int B, int h, int w, int64_t raw_bstride,
-                              const unsigned* prev_words, unsigned* words, hipStream_t s);
+                              const unsigned* prev_words, unsigned* words, hipStream_t s, unsigned* zero_a = nullptr, size_t zero_na = 0,
+                              unsigned* zero_b = nullptr, size_t zero_nb = 0);
 // src NHWC48 -> dst NHWC48.
 hipError_t launch_warp48(const float* src, const float* flow_raw, float* dst, int B, int H, int W,
                          hipStream_t s, int64_t flow_bstride = 0);
