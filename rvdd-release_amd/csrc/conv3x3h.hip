@@ -265,9 +265,11 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3h_kernel(ConvArgs a) {
     f32x4 pre[G::NR];
     u32x2 shi[G::NR], slo[G::NR];
     struct Src {
-        __amdgpu_buffer_rsrc_t r;
-        int org;
-        bool xok;
+        __amdgpu_buffer_rsrc_t r;      // the sequence's image: offsets past its last byte read as zero
+        unsigned base;                 // this thread's byte offset of (halo row rp, column hx, piece) in round 0 -- modulo 2^32: a row
+                                       // above the image is a huge offset (out of range = the zero padding), as is a row below it;
+                                       // 2^31 for a column outside the image or a thread without a piece (it stays out of range
+                                       // through all the rounds: they add a few MB at most)
         int y0, x0;
     };
     auto source = [&](const TilePos& p, bool live) {
@@ -275,18 +277,15 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3h_kernel(ConvArgs a) {
         const int ih = UPS ? a.H >> 1 : a.H, iw = UPS ? a.W >> 1 : a.W;
         q.r = __builtin_amdgcn_make_buffer_rsrc((void*)(a.in + (size_t)(live ? p.b : 0) * ih * iw * CIN), 0,
                                                 live ? (unsigned)(ih * iw * CIN * 4) : 0, 0x00020000);
-        q.org = ((p.y0 - PAD) * a.W + (p.x0 - PAD)) * (CIN * 4);
-        q.xok = ld_thread && (unsigned)(p.x0 - PAD + hx) < (unsigned)a.W;
+        const bool xok = ld_thread && (unsigned)(p.x0 - PAD + hx) < (unsigned)a.W;
+        q.base = xok ? (unsigned)(g_lane + ((p.y0 - PAD) * a.W + (p.x0 - PAD)) * (CIN * 4)) : 0x80000000u;
         q.y0 = p.y0;
         q.x0 = p.x0;
         return q;
     };
-    auto fetch_round = [&](const Src& q, int r0) {
-        const int hy = G::RPR * r0 + rp;
-        const bool ok = q.xok && hy < IH && (unsigned)(q.y0 - PAD + hy) < (unsigned)a.H;
-        const int off = g_lane + q.org + r0 * G::RPR * a.W * (CIN * 4);
-        pre[r0] = bload(q.r, ok ? (unsigned)off : 0x80000000u);
-    };
+    // (one v_add per round; the image's rows above and below come out of the buffer's range check, see Src::base.  Rows of the
+    // last round beyond the halo, CIN = 16, are loaded and not stored.)
+    auto fetch_round = [&](const Src& q, int r0) { pre[r0] = bload(q.r, q.base + (unsigned)(r0 * G::RPR * a.W * (CIN * 4))); };
     // ---- UPS: the halo tile in 2x2 blocks.  Upsampled rows 2i+1, 2i+2 interpolate between the SAME two source rows
     // (i, i+1, clamped as ATen clamps them), columns alike, and a tile's halo starts at an odd row and column: its 18x18
     // pixels are 9x9 such blocks, each from four source pixels.  One work item = one block x one 16-B channel piece: four
@@ -371,7 +370,9 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3h_kernel(ConvArgs a) {
     };
 
     // ---- fragment addresses
-    unsigned boff[G::NCH];           // B: this lane's pixel of tile row 2 wave, at the tap and channel group of chunk j
+    // (kept as LDS POINTERS, the dynamic-LDS base added here once: as byte offsets added to `L` at every use they cost one
+    // v_add_u32 v, 0, v per chunk inside the tile loop -- the base is a link-time zero the compiler cannot fold)
+    lds_u8* boff[G::NCH];            // B: this lane's pixel of tile row 2 wave, at the tap and channel group of chunk j
 #pragma unroll
     for (int j = 0; j < G::NCH; ++j) {
         int Gi = 4 * j + g;
@@ -379,9 +380,9 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3h_kernel(ConvArgs a) {
         const int tap = Gi / G::GPT;
         const int c0 = (Gi - tap * G::GPT) * 8;
         const int ky = tap / KS, kx = tap - KS * ky;
-        boff[j] = plane0 + (unsigned)(((2 * gw + ky) * IW + n + kx) * G::S + c0 * 2);
+        boff[j] = L + (plane0 + (unsigned)(((2 * gw + ky) * IW + n + kx) * G::S + c0 * 2));
     }
-    unsigned abase[2] = {(unsigned)(lane * 16), (unsigned)(lane * 16 + G::A_SPLIT * 6 * 1024)};
+    lds_u8* abase[2] = {L + (unsigned)(lane * 16), L + (unsigned)(lane * 16 + G::A_SPLIT * 6 * 1024)};
     asm volatile("" : "+v"(abase[0]), "+v"(abase[1]));
     h8 Af[2][3][2], Bf[2][2][2];
     auto read_frags = [&](int buf, int j) {
@@ -389,13 +390,13 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3h_kernel(ConvArgs a) {
         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
             for (int hl = 0; hl < 2; ++hl)
-                Bf[buf][nt][hl] = __builtin_bit_cast(h8, *(lds_f4*)(L + boff[j] + nt * IW * G::S + hl * G::PLANE));
+                Bf[buf][nt][hl] = __builtin_bit_cast(h8, *(lds_f4*)(boff[j] + nt * IW * G::S + hl * G::PLANE));
 #pragma unroll
         for (int mt = 0; mt < 3; ++mt)
 #pragma unroll
             for (int hl = 0; hl < 2; ++hl) {
                 const int jj = j < G::A_SPLIT ? j : j - G::A_SPLIT;
-                Af[buf][mt][hl] = __builtin_bit_cast(h8, *(lds_f4*)(L + abase[j < G::A_SPLIT ? 0 : 1] + ((jj * 3 + mt) * 2 + hl) * 1024));
+                Af[buf][mt][hl] = __builtin_bit_cast(h8, *(lds_f4*)(abase[j < G::A_SPLIT ? 0 : 1] + ((jj * 3 + mt) * 2 + hl) * 1024));
             }
     };
 
