@@ -27,6 +27,9 @@ for k in sorted(f):
         continue
     name = k.replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", "")
     name = name.split("(")[0].replace(", 0>", ">") if "conv3x3" in name else name.split("(")[0]
+    if name.startswith("conv3x3h_kernel<"):      # <CIN, EPI, ACC_IN, UPS, groups, taps>: bench.py names the first four; the 5x5 form by itself
+        a = [x.strip() for x in name[len("conv3x3h_kernel<"):-1].split(",")]
+        name = "conv5x5h_kernel<16>" if len(a) > 5 and a[5] == "5" else "conv3x3h_kernel<" + ", ".join(a[:4]) + ">"
     if name.startswith("mlp_kernel"):
         name = "mlp_kernel"                      # one instantiation; bench.py looks it up by its plain name
     if name.startswith("convblock_kernel<false, false") or name.startswith("convblock_pipe_kernel<false, false"):
