@@ -209,6 +209,9 @@ int rvdd_srgb_metrics(rvdd_t* h, const uint8_t* a, const uint8_t* b, int32_t n, 
  *               next_split; same bits either way).
  *   "next_pool": 0 = with next_fused, MaxPool2d(2) in front of a DownConv (new_unet.py:200-204) as its own kernel instead
  *               of the fused block's epilogue (default 1; same bits either way).
+ *   "warp_async": 1 = the bicubic warp of the recurrent features runs on a second stream beside the network-input assembly and
+ *               the net's first launch(es) (it depends on the last step's features and the flow only) instead of in line on the
+ *               caller's stream (default 0: measured, no gain on MI355X; same bits).
  *   "fuse_pre": 0 = preprocessing_layer (3x3, no activation, networks/unet.py:742) and the first source of EncoderConvs[0][0]
  *               (3x3, :743) run as the two convs they are, instead of as their composition -- ONE 5x5 conv of the network
  *               input plus a fix of the border ring, where the zero padding between the two layers matters (default 1, the

@@ -152,6 +152,13 @@ struct rvdd_handle {
     bool next_streams = false;    // ConvNeXt, two-kernel blocks, B >= 2: the two halves of the batch as two chains on two streams (measured: no gain)
     hipStream_t stream2 = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    // The feature warp of a step depends on the last step's features and the flow only; the net reads its result in its second
+    // (convunet) / third (ConvNeXt) launch.  It runs on stream2 beside the network-input assembly and the first launch(es):
+    // a texture-path-bound gather beside kernels that leave that path alone.  Measured (profiles/r04_warp_async_ab.txt): C2 718.7
+    // against 716.5 frames/s, C4 351.8 against 352.7 -- nothing; off by default (RVDD_WARP_ASYNC=1 / option "warp_async" 1).
+    bool warp_async = false;
+    hipEvent_t ev_wfork = nullptr, ev_wjoin = nullptr;
+    bool warp_join_pending = false, warp_async_now = false;
     bool serpentine = false;      // sequence order of the current frame-step (flips every step when seq_major is on)
     std::map<std::string, HostTensor> staged;
     std::vector<void*> allocs;
@@ -608,6 +615,14 @@ const char* conv_name_h(int epi, bool acc) {
     return names[epi][acc];
 }
 
+// Before the first launch that reads the warped features: wait for the warp the prologue started on the second stream.
+int join_warp(rvdd_t* h, hipStream_t s) {
+    if (!h->warp_join_pending) return RVDD_OK;
+    h->warp_join_pending = false;
+    HIPCHK(h, hipStreamWaitEvent(s, h->ev_wjoin, 0));
+    return RVDD_OK;
+}
+
 // the amax words (rvdd_internal.h) of map `slot`, from sequence b0 on
 unsigned* amax_words(const rvdd_t* h, int slot, size_t b0 = 0) { return h->amax + ((size_t)slot * h->cfg.batch + b0) * kAmaxSeqWords; }
 constexpr size_t amax_bytes(int B, int nslots) { return (size_t)nslots * B * kAmaxSeqWords * sizeof(unsigned); }
@@ -804,12 +819,14 @@ int run_convunet(rvdd_t* h, const float* netin, const float* featw, float* feat_
             // preprocessing_layer (:742, no activation) and the first source of EncoderConvs[0][0] (:743) as ONE 5x5 conv of the
             // network input (compose_pre_enc0), its border ring put right, then the second source (the old features) as before
             RC(run_pre5(h, netin, lv[0].part, s, sb));
+            RC(join_warp(h, s));
             ConvCall c;
             c.in = featw; c.src = 1; c.acc_in = lv[0].part; c.out = lv[0].t[1]; c.H = lv[0].H; c.W = lv[0].W; c.epi = EPI_RELU;
             c.amax_in = h->amax_feat_in; c.amax_out = L(CU_ENC0_0);
             RC(run_conv(h, cu[CU_ENC0_0], c, s, sb));
         } else if (feat) {
             RC(conv(CU_PRE, netin, AMAX_NETIN, lv[0].t[0], 0, EPI_NONE, sb));               // :742 (no activation)
+            RC(join_warp(h, s));
             RC(conv2(CU_ENC0_0, lv[0].t[0], L(CU_PRE), featw, h->amax_feat_in, lv[0].t[1], 0, sb)); // cat[y, old_features] :743
         } else {
             RC(conv(CU_ENC0_0, netin, AMAX_NETIN, lv[0].t[1], 0, EPI_RELU, sb));
@@ -917,7 +934,11 @@ int ensure_scratch(rvdd_t* h, size_t bytes) {
 namespace {
 int run_net(rvdd_t* h, const float* netin, const float* featw, float* feat_dst, float* out_nchw,
             float* out_nhwc4, hipStream_t s, const StepInputs* prologue) {
-    if (!h->is_next()) return run_convunet(h, netin, featw, feat_dst, out_nchw, out_nhwc4, s, prologue);
+    if (!h->is_next()) {
+        const int rc = run_convunet(h, netin, featw, feat_dst, out_nchw, out_nhwc4, s, prologue);
+        const int rj = join_warp(h, s);          // (a no-op when the net has read the warped features, as it always has)
+        return rc ? rc : rj;
+    }
     const int B = h->cfg.batch;
     if (prologue) RC(run_prologue(h, *prologue, Sub{0, B}, s));
     if (h->next_streams && !h->next_fused && B >= 2 && h->stream2) {
@@ -1021,12 +1042,16 @@ int rvdd_create(const rvdd_cfg* cfg, rvdd_t** out) {
     }
     (void)hipEventCreate(&h->t0);
     (void)hipEventCreate(&h->t1);
-    if (h->is_next() && (hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking) != hipSuccess ||
-                         hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
-                         hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess)) {
+    if (hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_wfork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_wjoin, hipEventDisableTiming) != hipSuccess) {
         (void)hipGetLastError();
         h->next_streams = false;
     }
+    if (const char* wa = std::getenv("RVDD_WARP_ASYNC")) h->warp_async = std::atoi(wa) != 0;
+    if (!h->stream2 || !h->ev_wfork || !h->ev_wjoin) h->warp_async = false;
     if (const char* gv = std::getenv("RVDD_GRAPH")) h->use_graphs = std::atoi(gv) != 0;
     if (hipStreamCreateWithFlags(&h->gstream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&h->g_in, hipEventDisableTiming) != hipSuccess ||
@@ -1048,6 +1073,8 @@ void rvdd_destroy(rvdd_t* h) {
     if (h->gstream) (void)hipStreamDestroy(h->gstream);
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
+    if (h->ev_wfork) (void)hipEventDestroy(h->ev_wfork);
+    if (h->ev_wjoin) (void)hipEventDestroy(h->ev_wjoin);
     if (h->stream2) (void)hipStreamDestroy(h->stream2);
     for (void* p : h->allocs) (void)hipFree(p);
     if (h->scratch) (void)hipFree(h->scratch);
@@ -1242,6 +1269,12 @@ int rvdd_set_option(rvdd_t* h, const char* name, int32_t value) {
         h->next_streams = value != 0 && h->stream2 != nullptr;
         return RVDD_OK;
     }
+    if (std::strcmp(name, "warp_async") == 0) {
+        // 1 = the feature warp on a second stream beside the network-input assembly and the net's first launch(es), instead of in
+        // line on the caller's stream (measured: no gain; default 0; same bits)
+        h->warp_async = value != 0 && h->stream2 != nullptr && h->ev_wfork != nullptr && h->ev_wjoin != nullptr;
+        return RVDD_OK;
+    }
     if (std::strcmp(name, "fuse_pre") == 0) {
         // 0 = preprocessing_layer and EncoderConvs[0][0] as the two convs they are, instead of their composition (the A/B
         // reference: same map up to fp32 rounding of a different summation order)
@@ -1287,7 +1320,7 @@ int rvdd_set_option(rvdd_t* h, const char* name, int32_t value) {
         h->split16 = value == 0;
         return RVDD_OK;
     }
-    return fail(h, RVDD_ERR_ARG, "rvdd_set_option: unknown option '%s' (known: no_warp, warp_raw, prev_noisy_frame, conv_kernel, seq_major, graphs, fuse_upsample, next_fused, next_split, next_pipe, next_pool, next_streams, wino4, block_fp, conv_groups, fuse_pre)", name);
+    return fail(h, RVDD_ERR_ARG, "rvdd_set_option: unknown option '%s' (known: no_warp, warp_raw, prev_noisy_frame, conv_kernel, seq_major, graphs, fuse_upsample, next_fused, next_split, next_pipe, next_pool, next_streams, wino4, block_fp, conv_groups, fuse_pre, warp_async)", name);
 }
 
 int rvdd_reset(rvdd_t* h) {
@@ -1315,6 +1348,19 @@ int run_prologue(rvdd_t* h, const StepInputs& in, Sub sb, hipStream_t s) {
     float* green = h->green + o * img;
     float* netin = h->netin + o * img * kNetInC;
     // amax words of the maps the split-f16 convs read first (block floating point, rvdd_internal.h)
+    // the feature warp first, on the second stream (see rvdd_handle::warp_async): it waits for what the caller's stream has
+    // done so far (the last step, which wrote the features it gathers from), the net waits for it where it reads `featw`
+    h->warp_async_now = h->warp_async && h->has_feat() && !nw && !h->warp_raw && h->stream2 && sb.b0 == 0 && sb.nb == h->cfg.batch;
+    if (h->warp_async_now) {
+        HIPCHK(h, hipEventRecord(h->ev_wfork, s));
+        HIPCHK(h, hipStreamWaitEvent(h->stream2, h->ev_wfork, 0));
+        {
+            Scope sc(h, h->stream2, "warp48_kernel", 0.0, (double)n * img * (384.0 + 2.0));
+            HIPCHK(h, launch_warp48(h->lastfeat, fp_, h->featw, n, H, W, h->stream2, (int64_t)in.flowf));
+        }
+        HIPCHK(h, hipEventRecord(h->ev_wjoin, h->stream2));
+        h->warp_join_pending = true;
+    }
     const bool bfp = h->bfp && h->split16 && !h->is_next();
     unsigned* amax_netin = bfp ? amax_words(h, h->amax_base + AMAX_REL_NETIN, o) : nullptr;
     // the zeroing for the step after this one rides in the first netin_bound launch of the step; a step without one memsets
@@ -1374,7 +1420,7 @@ int run_prologue(rvdd_t* h, const StepInputs& in, Sub sb, hipStream_t s) {
         HIPCHK(h, launch_netin(rc_, green, h->lastden4 + o * img * 4, fp_, next4, fn_, netin, n, H / 2, W / 2, s, (int64_t)in.rawf,
                                (int64_t)in.flowf));
     }
-    if (h->has_feat() && !nw) {
+    if (h->has_feat() && !nw && !h->warp_async_now) {
         Scope sc(h, s, "warp48_kernel", 0.0, (double)n * img * (384.0 + 2.0));
         HIPCHK(h, launch_warp48(h->lastfeat + o * img * kF, fp_, h->featw + o * img * kF, n, H, W, s, (int64_t)in.flowf));
     }
