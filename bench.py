@@ -46,7 +46,7 @@ CONFIGS = {
     "C1": ("convunet", "recurrent-convunet-iso3200", 0, 3200, 256, 256, 8, 8, 25.50),
     "C2": ("convunet+feat", "recurrent-convunet+feat-iso3200", 0, 3200, 720, 1280, 30, 8, 435.025),
     "C3": ("convunet+feat", "recurrent-convunet+feat-future-iso12800", 1, 12800, 720, 1280, 30, 8, 437.413),
-    "C4": ("next+feat", "recurrent-ConvNeXtUnet+feat-future-iso3200", 1, 3200, 720, 1280, 30, 4, 401.998),
+    "C4": ("next+feat", "recurrent-ConvNeXtUnet+feat-future-iso3200", 1, 3200, 720, 1280, 30, 8, 401.998),
     "C5": ("convunet+feat", "recurrent-convunet+feat-iso3200", 0, 3200, 720, 1280, 90, 8, 435.025),
 }
 DESCR = {
