@@ -489,25 +489,13 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3h_kernel(ConvArgs a) {
         STAMP(1);
         // The first chunk's MFMAs go out at once; the tile's address work (next tile's position, this tile's store and
         // side-load offsets) follows them and runs under them, and everything that needs it starts at chunk SH.
-#ifndef RVDD_SH
-#define RVDD_SH 1
-#endif
-        constexpr int SH = G::NCH >= 12 ? RVDD_SH : 0;
-        // schedule of the memory instructions over the 14 chunks (one of each kind per chunk at most; tuned by A/B, macros for that)
-#ifndef RVDD_ST_PLAIN
-#define RVDD_ST_PLAIN 7
-#endif
-#ifndef RVDD_ST_ACC
-#define RVDD_ST_ACC 1
-#endif
-#ifndef RVDD_SL_ACC
-#define RVDD_SL_ACC 7
-#endif
-#ifndef RVDD_SPLIT_SPREAD
-#define RVDD_SPLIT_SPREAD 0
-#endif
-        // the previous tile's stores: from chunk ST on, one per chunk
-        constexpr int ST = G::NCH >= 14 ? (ACC_IN ? RVDD_ST_ACC : RVDD_ST_PLAIN) : SH;
+        constexpr int SH = G::NCH >= 12 ? 1 : 0;
+        // Where the memory instructions sit in the 14 chunks (profiles/r04_chunk_loop_schedule_ab.txt: +2.5 % on C2 over "everything
+        // from chunk 1 on"): the next tile's halo loads at chunks 1-9, the previous tile's stores at 7-12 (two-pass layers: at 1-6,
+        // and the partial sums' loads at 7-12) -- at most two memory instructions in front of any chunk's MFMAs.  One split per
+        // chunk instead of three in each of the last three, halo loads from chunk 0 or 2, and the chunk's other instructions
+        // dealt out BETWEEN its MFMAs (sched_group_barrier) all measured equal or worse.
+        constexpr int ST = G::NCH >= 14 ? (ACC_IN ? 1 : 7) : SH;
         constexpr int US = NGRP == 1 ? 1 : 3, UL = NGRP == 1 ? 5 : 3, UI = NGRP == 1 ? 2 : 3;      // UPS: load stride, load -> use, use stride
         Src qn;
         const int yy0 = cur.y0 + 2 * gw, xx = cur.x0 + n;
@@ -546,12 +534,11 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3h_kernel(ConvArgs a) {
             if (j >= ST && j - ST < NOUT) store_prev(j - ST);
             if constexpr (ACC_IN) {
                 // (behind the previous tile's stores, which take the first six chunks: one memory instruction of each kind per chunk)
-                constexpr int SL = G::NCH >= 14 ? RVDD_SL_ACC : SH;
+                constexpr int SL = G::NCH >= 14 ? 7 : SH;
                 if (j >= SL && j - SL < 6) side[(j - SL) / 3][(j - SL) % 3] = bload(pr, po[(j - SL) / 3], 64 * ((j - SL) % 3));
             }
             if constexpr (SC) {
-                if (j == (UPS ? SH + UL : (RVDD_SPLIT_SPREAD && G::NCH >= 14 && G::NR == 9) ? SH + 5 : G::NCH - 1 - (G::NR - 1) / 3))
-                    scale_from(ab_nxt, sc_nxt, inv_nxt);      // the chunk of the first split
+                if (j == (UPS ? SH + UL : G::NCH - 1 - (G::NR - 1) / 3)) scale_from(ab_nxt, sc_nxt, inv_nxt);      // the chunk of the first split
             }
             if constexpr (UPS) {
                 // one workgroup-wide tile: the two items' loads at chunks SH, SH + 1, their interpolation and split five chunks
@@ -570,18 +557,12 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3h_kernel(ConvArgs a) {
                 if (j >= SH && j - SH < G::NR) fetch_round(qn, j - SH);
 #pragma unroll
                 for (int r0 = 0; r0 < G::NR; ++r0)
-                    if (j == ((RVDD_SPLIT_SPREAD && G::NCH >= 14 && G::NR == 9) ? (SH + r0 + 5 < G::NCH ? SH + r0 + 5 : G::NCH - 1)
-                                                                                 : G::NCH - 1 - (G::NR - 1 - r0) / 3)) {
+                    if (j == G::NCH - 1 - (G::NR - 1 - r0) / 3) {
                         split4<SC>(pre[r0], sc_nxt, shi[r0], slo[r0]);
                         asm volatile("" : "+v"(shi[r0]), "+v"(slo[r0]));      // here, not sunk behind the barrier next to its use
                     }
             }
-#ifndef RVDD_INTERLEAVE
-#define RVDD_INTERLEAVE 0
-#endif
-#if !RVDD_INTERLEAVE
             __builtin_amdgcn_sched_barrier(0);
-#endif
 #pragma unroll
             for (int p = 0; p < 3; ++p) {
                 const int ha = p == 1 ? 1 : 0, hb = p == 0 ? 1 : 0;      // hi.lo, lo.hi, then hi.hi
@@ -593,17 +574,6 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3h_kernel(ConvArgs a) {
                         acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Af[cb][mt][ha], Bf[cb][nt][hb], c, 0, 0, 0);
                     }
             }
-#if RVDD_INTERLEAVE
-            // the chunk's other instructions dealt out between its MFMAs: two MFMAs, a fragment read, a few vector
-            // instructions, a memory instruction -- nine times
-#pragma unroll
-            for (int q = 0; q < 9; ++q) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);       // MFMA
-                __builtin_amdgcn_sched_group_barrier(0x100, RVDD_INTERLEAVE > 1 ? 2 : 1, 0);       // DS read
-                __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);       // VALU
-                __builtin_amdgcn_sched_group_barrier(0x060, 1, 0);       // VMEM read / write
-            }
-#endif
             __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
