@@ -496,7 +496,7 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3h_kernel(ConvArgs a) {
         // chunk instead of three in each of the last three, halo loads from chunk 0 or 2, and the chunk's other instructions
         // dealt out BETWEEN its MFMAs (sched_group_barrier) all measured equal or worse.
         constexpr int ST = G::NCH >= 14 ? (ACC_IN ? 1 : 7) : SH;
-        constexpr int US = NGRP == 1 ? 1 : 3, UL = NGRP == 1 ? 5 : 3, UI = NGRP == 1 ? 2 : 3;      // UPS: load stride, load -> use, use stride
+        constexpr int US = 3, UL = NGRP == 1 ? 4 : 3, UI = NGRP == 1 ? 5 : 3;      // UPS: load stride, load -> use, use stride (in chunks)
         Src qn;
         const int yy0 = cur.y0 + 2 * gw, xx = cur.x0 + n;
         unsigned po[2], so[2];
@@ -541,9 +541,10 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3h_kernel(ConvArgs a) {
                 if (j == (UPS ? SH + UL : G::NCH - 1 - (G::NR - 1) / 3)) scale_from(ab_nxt, sc_nxt, inv_nxt);      // the chunk of the first split
             }
             if constexpr (UPS) {
-                // one workgroup-wide tile: the two items' loads at chunks SH, SH + 1, their interpolation and split five chunks
-                // later; a group's tile: three items, each loaded when the one before has been interpolated (UL chunks later), so
-                // that only one item's sixteen source registers are alive at a time (all three at once did not fit: scratch)
+                // one workgroup-wide tile: the two items' loads at chunks 1 and 4, their interpolation and split at 5 and 10 (2 % faster
+                // than loads at 1, 2 and interpolation at 6, 8: profiles/r04_chunk_loop_schedule_ab.txt); a group's tile: three items,
+                // each loaded when the one before has been interpolated, so that only one item's sixteen source registers are alive
+                // at a time (all three at once did not fit: scratch)
 #pragma unroll
                 for (int r0 = 0; r0 < UNR; ++r0) {
                     if (j == SH + US * r0) fetch_ups(qn, r0);
