@@ -568,9 +568,9 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3h_kernel(ConvArgs a) {
             for (int p = 0; p < 3; ++p) {
                 const int ha = p == 1 ? 1 : 0, hb = p == 0 ? 1 : 0;      // hi.lo, lo.hi, then hi.hi
 #pragma unroll
-                for (int nt = 0; nt < 2; ++nt)
+                for (int mt = 0; mt < 3; ++mt)      // (filter fragment constant over two MFMAs in a row: 0.3 % over the other nest)
 #pragma unroll
-                    for (int mt = 0; mt < 3; ++mt) {
+                    for (int nt = 0; nt < 2; ++nt) {
                         const f32x4 c = (j == 0 && p == 0) ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[nt][mt];
                         acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Af[cb][mt][ha], Bf[cb][nt][hb], c, 0, 0, 0);
                     }
