@@ -495,7 +495,7 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3h_kernel(ConvArgs a) {
         // and the partial sums' loads at 7-12) -- at most two memory instructions in front of any chunk's MFMAs.  One split per
         // chunk instead of three in each of the last three, halo loads from chunk 0 or 2, and the chunk's other instructions
         // dealt out BETWEEN its MFMAs (sched_group_barrier) all measured equal or worse.
-        constexpr int ST = G::NCH >= 14 ? (ACC_IN ? 1 : 7) : SH;
+        constexpr int ST = G::NCH >= 14 ? (ACC_IN ? 1 : 7) : (G::NCH == 13 ? 6 : SH);      // (13 chunks: the composed 5x5 first layer, -6 %)
         constexpr int US = 3, UL = NGRP == 1 ? 4 : 3, UI = NGRP == 1 ? 5 : 3;      // UPS: load stride, load -> use, use stride (in chunks)
         Src qn;
         const int yy0 = cur.y0 + 2 * gw, xx = cur.x0 + n;
