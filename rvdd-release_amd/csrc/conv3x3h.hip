@@ -701,15 +701,15 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3h_kernel(ConvArgs a) {
         cur = nxt;
         inv_cur = inv_nxt;
     }
+    // the last tile's results, and behind them (the stores are on their way while the waves meet) the last sequence's maximum
+#pragma unroll
+    for (int j = 0; j < NOUT; ++j) store_prev(j);
     if (a.amax_out && amx_b >= 0) {
         const unsigned wm = wave_max_u32(__float_as_uint(amx));
         if (lane == 0) Rl[gw] = wm;
         gsync();
         if (gw == 0) amax_send(amx_b);
     }
-    // the last tile's results
-#pragma unroll
-    for (int j = 0; j < NOUT; ++j) store_prev(j);
     STAMP_FLUSH;
     };      // tile_loop
     if (any_scaled) tile_loop(std::true_type{});
