@@ -880,6 +880,69 @@ def test_split_path_any_magnitude(arch, stem, fut, mag):
         assert err < 1e-4 * scale, (arch, mag, t, err, scale)
 
 
+def test_split_path_mixed_magnitudes_in_one_batch():
+    """Block floating point is per map AND per sequence: three sequences of one batch a factor 1e5 and 2^-10 apart.  Each is
+    within 1e-4 of its own oracle relative to its own max-abs, and bit for bit what it is when it runs alone (a workgroup whose
+    tiles span sequences that need the scaling and sequences that do not takes the scaled form of the tile loop for all of
+    them: a multiplication by 1.0 for the in-domain ones, the same bits as the unscaled form)."""
+    from rvdd_release_amd import synth
+    from rvdd_release_amd.runtime import RvddRuntime
+    sd = load_weights("recurrent-convunet+feat-iso3200")
+    H, W, T = 48, 80, 4
+    mags = (1.0, 1.0e5, 2.0 ** -10)
+    seqs = [synth.make_sequence(T, H, W, iso=3200, seed=60 + b, device="cuda") for b in range(3)]
+    raws = [s.raw * m for s, m in zip(seqs, mags)]
+
+    def run(idx):
+        rt = RvddRuntime("convunet+feat", 0, len(idx), H, W, 0)
+        rt.load_state_dict(sd)
+        st = lambda f: torch.stack([f(b) for b in idx], 0)
+        outs = [rt.step(st(lambda b: raws[b][t - 1]) if t == 1 else None, st(lambda b: raws[b][t]), None,
+                        st(lambda b: seqs[b].flow_prev[t]), None).clone() for t in range(1, T)]
+        rt.close()
+        return outs
+
+    together = run([0, 1, 2])
+    for b in range(3):
+        alone = run([b])
+        want = O.RecurrentOracle(sd, future=0).run_sequence(raws[b].cpu(), seqs[b].flow_prev.cpu(), None)
+        for t in range(T - 1):
+            assert torch.equal(together[t][b], alone[t][0]), (b, t, float((together[t][b] - alone[t][0]).abs().max()))
+            scale = float(want[t].abs().max())
+            assert float((together[t][b].cpu() - want[t]).abs().max()) < 1e-4 * scale, (b, t, mags[b])
+
+
+def test_many_sequences_per_workgroup():
+    """Small frames, a large batch: a workgroup's tiles span more than four sequences (the kernel then takes the scaled form of
+    its tile loop without looking the words up front) -- 40 sequences of 64x64, one of them 1e4 times brighter: every sequence
+    equal, bit for bit, to the same sequence in a batch of its own, the bright one and two others within 1e-4 of the oracle."""
+    from rvdd_release_amd import synth
+    from rvdd_release_amd.runtime import RvddRuntime
+    sd = load_weights("recurrent-convunet+feat-iso3200")
+    B, H, W, T = 40, 64, 64, 3
+    seqs = [synth.make_sequence(T, H, W, iso=3200, seed=300 + (b % 5), device="cuda") for b in range(B)]
+    mag = [1.0e4 if b == 17 else 1.0 for b in range(B)]
+
+    def run(idx):
+        rt = RvddRuntime("convunet+feat", 0, len(idx), H, W, 0)
+        rt.load_state_dict(sd)
+        st = lambda f: torch.stack([f(b) for b in idx], 0)
+        outs = [rt.step(st(lambda b: seqs[b].raw[t - 1] * mag[b]) if t == 1 else None, st(lambda b: seqs[b].raw[t] * mag[b]), None,
+                        st(lambda b: seqs[b].flow_prev[t]), None).clone() for t in range(1, T)]
+        rt.close()
+        return outs
+
+    big = run(list(range(B)))
+    for b in (0, 17, 39):
+        small = run([b])
+        want = O.RecurrentOracle(sd, future=0).run_sequence((seqs[b].raw * mag[b]).cpu(), seqs[b].flow_prev.cpu(), None)
+        for t in range(T - 1):
+            assert torch.equal(big[t][b], small[t][0]), (b, t)
+            assert float((big[t][b].cpu() - want[t]).abs().max()) < 1e-4 * float(want[t].abs().max()), (b, t)
+    # the same frames in different slots: the same bits
+    assert torch.equal(big[1][0], big[1][5]) and torch.equal(big[1][3], big[1][38])
+
+
 def test_composed_first_layer_matches_two_convs():
     """preprocessing_layer has no activation (networks/unet.py:742), so it and the first source of EncoderConvs[0][0] (:743) are
     one linear map of the network input: the default path runs them as ONE 5x5 conv with host-composed filters plus a fix of the
