@@ -701,7 +701,10 @@ hipError_t tvl1_alloc(Tvl1Workspace** out, int nx, int ny) {
 
 // Dual_TVL1_optic_flow_multiscale (tvl1flow_lib.c:343-472) for `np` (1..kMaxLanes) pairs of the same size in one set
 // of launches.  I0, I1: [np][ny][nx]; u: [np][2][ny][nx] = per pair u(ny*nx) then v(ny*nx) as libBridge.cpp:150.
-static hipError_t tvl1_run_lanes(Tvl1Workspace* w, const float* I0, const float* I1, float* u, int np, hipStream_t st, int* iters) {
+// `first` / `finish`: a batch runs several sets back to back on the stream; only the first clears the abort word and only the
+// last (or every one, when the iteration counts are wanted) reads the control words back and synchronises.
+static hipError_t tvl1_run_lanes(Tvl1Workspace* w, const float* I0, const float* I1, float* u, int np, hipStream_t st, int* iters,
+                                 bool first = true, bool finish = true) {
 #define CK(e)                                 \
     do {                                      \
         hipError_t e__ = (e);                 \
@@ -709,14 +712,15 @@ static hipError_t tvl1_run_lanes(Tvl1Workspace* w, const float* I0, const float*
     } while (0)
     const int nx = w->nx, ny = w->ny, n0 = nx * ny;
     while ((int)w->lanes.size() < np) CK(tvl1_add_lane(w));
-    CK(hipMemsetAsync(w->abort_word, 0, sizeof(int), st));
+    if (first) CK(hipMemsetAsync(w->abort_word, 0, sizeof(int), st));
     const double zsigma = (double)(float)(kZoomSigma0 * std::sqrt(1.0 / ((double)kZoom * (double)kZoom) - 1.0));
     for (int q = 0; q < np; ++q) {
         Tvl1LaneBufs& L = w->lanes[q];
         const float *a0 = I0 + (size_t)q * n0, *a1 = I1 + (size_t)q * n0;
         // normalisation to [0,255] and pre-smoothing
-        const int init[2] = {0x7f7fffff, (int)0x80000000};   // order-preserving keys of +FLT_MAX / -FLT_MAX
-        CK(hipMemcpyAsync(L.mm, init, sizeof init, hipMemcpyHostToDevice, st));
+        // order-preserving keys of +FLT_MAX / -FLT_MAX (two fills: a copy from pageable host memory is not asynchronous)
+        CK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(L.mm), 0x7f7fffff, 1, st));
+        CK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(reinterpret_cast<int*>(L.mm) + 1), (int)0x80000000, 1, st));
         CK(hipMemsetAsync(L.ctl, 0, 8 * sizeof(int), st));
         hipLaunchKernelGGL(minmax_kernel, dim3(256), dim3(256), 0, st, a0, a1, n0, L.mm);
         hipLaunchKernelGGL(normalize_kernel, dim3((n0 + 255) / 256), dim3(256), 0, st, a0, a1, L.tmp, L.tmp2, n0, L.mm);
@@ -804,7 +808,7 @@ static hipError_t tvl1_run_lanes(Tvl1Workspace* w, const float* I0, const float*
                                sc.nx, sc.ny, f.nx, f.ny, fx, fy, 1.0f / kZoom);
         }
     }
-    {   // always read the control words back: a grid barrier that gave up must not pass as a flow
+    if (finish) {   // always read the control words back: a grid barrier that gave up must not pass as a flow
         int ab = 0, c[kMaxLanes][8] = {};
         CK(hipMemcpyAsync(&ab, w->abort_word, sizeof ab, hipMemcpyDeviceToHost, st));
         for (int q = 0; q < np; ++q) CK(hipMemcpyAsync(c[q], w->lanes[q].ctl, 4 * sizeof(int), hipMemcpyDeviceToHost, st));
@@ -826,7 +830,8 @@ hipError_t tvl1_run_batch(Tvl1Workspace* w, const float* I0, const float* I1, fl
     const size_t n0 = (size_t)w->nx * w->ny;
     for (int q = 0; q < n; q += kMaxLanes) {
         const int np = n - q < kMaxLanes ? n - q : kMaxLanes;
-        hipError_t e = tvl1_run_lanes(w, I0 + q * n0, I1 + q * n0, u + q * 2 * n0, np, st, iters ? iters + q : nullptr);
+        hipError_t e = tvl1_run_lanes(w, I0 + q * n0, I1 + q * n0, u + q * 2 * n0, np, st, iters ? iters + q : nullptr, q == 0,
+                                      iters != nullptr || q + kMaxLanes >= n);
         if (e != hipSuccess) return e;
     }
     return hipSuccess;
