@@ -506,6 +506,8 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3h_kernel(ConvArgs a) {
             locate(t + t_step, nxt);
             qn = source(nxt, t + t_step < t_end);
             if constexpr (SC) amax_fetch(nxt.b, t + t_step < t_end);
+        };
+        auto addresses2 = [&]() {
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
                 const bool ok = yy0 + nt < a.H && xx < a.W;
@@ -531,6 +533,7 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3h_kernel(ConvArgs a) {
             const int cb = j & 1;
             if (j + 1 < G::NCH) read_frags(cb ^ 1, j + 1);
             if (j == SH) addresses();
+            if (j == (G::NCH >= 14 ? 6 : SH)) addresses2();      // this tile's store / side-load offsets: first needed at chunk 7 (0.4 % over chunk 1)
             if (j >= ST && j - ST < NOUT) store_prev(j - ST);
             if constexpr (ACC_IN) {
                 // (behind the previous tile's stores, which take the first six chunks: one memory instruction of each kind per chunk)
