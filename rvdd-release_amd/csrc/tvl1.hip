@@ -5,16 +5,20 @@
 // (listed in DESIGN.md), fp32 with the reference's double-precision islands (Gaussian,
 // bicubic cell, normalisation, hypot).  Compiled with -ffp-contract=off.
 //
-// All maps are planar fp32 [ny][nx].  One scale of the pyramid = ONE persistent cooperative kernel
-// (scale_kernel): gradient of I1, then 5 x [warp of I1 / I1x / I1y, then <= 300 x (u update | grid
-// barrier | convergence test + p update | grid barrier)].  An iteration touches ~120 B per pixel that
-// stay in L2, so the path is bound by the two grid barriers per iteration, not by HBM; as separate
-// launches (three per iteration, the first version of this file) it was bound by launch gaps, 3x slower.
-// Every block evaluates the convergence test itself from the same per-tile partial sums in the same
-// fixed order, so all blocks leave the loop in the same iteration without a broadcast.
+// All maps are planar fp32 [ny][nx].  One scale of the pyramid = ONE persistent cooperative kernel: gradient of I1,
+// then 5 x [warp of I1 / I1x / I1y, then <= 300 x (u update | exchange | convergence test + p update)].  Three forms,
+// bit-identical (the convergence sum is formed in fixed point, see err_fix):
+//   scale_kernel_patch  the default: a block owns a 64 x PH patch, pixel state in registers, neighbours through LDS, the
+//                       patch's perimeter and the blocks' convergence sums through tagged records that the readers poll --
+//                       no grid barrier in the iteration (6.6 us per iteration of a 640x360 pair);
+//   scale_kernel        interleaved row segments, one grid barrier per iteration (round 3's kernel; RVDD_TVL1_PATCH=0,
+//                       and images whose patches do not fit the CUs);
+//   scale_kernel_mem    pixel state in memory, two grid barriers per iteration (images beyond the register slots).
+// As separate launches (three per iteration, the first version of this file) the path was bound by launch gaps.
 #include "rvdd_internal.h"
 
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <vector>
 
@@ -284,21 +288,60 @@ __device__ __forceinline__ DualStep dual_step(bool last_col, bool last_row, floa
 // one component of the dual update (tvl1flow_lib.c:230-233)
 __device__ __forceinline__ float dual_upd(float p, float grad, float ng) { return (p + (kTau / kTheta) * grad) / ng; }
 
-// the convergence test (tvl1flow_lib.c:236-241): fixed-order sum of the per-tile sums, identical in every block
-__device__ __forceinline__ float error_of(const float* partial, int ntiles, int npix, double* shd) {
+// The convergence test (tvl1flow_lib.c:236-241) sums the squared update of every pixel.  The sum is formed in FIXED
+// POINT: a pixel's term min(e, 128) * 2^s is rounded to an integer once, and integers add in any order to the same
+// bits -- so the three kernels of this file (and any tiling, wave or block that does the adding) stop in the same
+// iteration.  s = 47 - ceil(log2 npix): the whole image's sum stays below 2^55, a term's step is 2^-s (2^-29 at
+// 640x360, against the test's threshold of 1e-4 per pixel).  A term above 128 (an update of more than 11 pixels
+// in one iteration) only has to keep the sum above the threshold, which 128 does.
+__device__ __forceinline__ int err_shift(int npix) { return 47 - (32 - __builtin_clz((unsigned)(npix > 1 ? npix - 1 : 1))); }
+__device__ __forceinline__ unsigned long long err_fix(float e, float mul) {
+    const float c = e < 128.f ? e : 128.f;
+    return (unsigned long long)((double)c * (double)mul + 0.5);
+}
+__device__ __forceinline__ float err_value(unsigned long long sum, int shift, int npix) {
+    return (float)(__builtin_ldexp((double)sum, -shift) / (double)npix);
+}
+__device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+    return v;
+}
+// the same sum without LDS traffic (every lane active): two 32-bit sums on the vector ALU's lane-shift path.  v < 2^55 and
+// the wave's sum too, so bits 24.. of the 64 values sum below 2^31 and bits 0..23 below 2^30.  Wave-uniform result.
+__device__ __forceinline__ unsigned wave_sum_u32_dpp(unsigned v) {
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);      // row_shr:1 (zero shifted in): a scan ...
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);      // row_shr:2
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);      // row_shr:4
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);      // row_shr:8: lane 15 of a row = the row's sum
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, true);      // row_bcast:15 into rows 1, 3
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, true);      // row_bcast:31 into rows 2, 3
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+__device__ __forceinline__ unsigned long long wave_sum_fix(unsigned long long v) {
+    const unsigned lo = wave_sum_u32_dpp((unsigned)v & 0xffffffu), hi = wave_sum_u32_dpp((unsigned)(v >> 24));
+    return ((unsigned long long)hi << 24) + lo;
+}
+__device__ __forceinline__ unsigned long long ldq(const unsigned long long* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void stq(unsigned long long* p, unsigned long long v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float error_of(const unsigned long long* partial, int ntiles, int npix, unsigned long long* shq) {
     const int tid = threadIdx.x;
-    double acc = 0.0;
-    for (int k = tid; k < ntiles; k += 256) acc += (double)ldc(partial + k);
-    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
-    if ((tid & 63) == 0) shd[tid >> 6] = acc;
+    unsigned long long acc = 0;
+    for (int k = tid; k < ntiles; k += 256) acc += ldq(partial + k);
+    acc = wave_sum_u64(acc);
+    if ((tid & 63) == 0) shq[tid >> 6] = acc;
     __syncthreads();
-    return (float)(((shd[0] + shd[1]) + (shd[2] + shd[3])) / (double)npix);
+    return err_value((shq[0] + shq[1]) + (shq[2] + shq[3]), err_shift(npix), npix);
 }
 
 // what crosses workgroups inside a scale: u, double-buffered by iteration parity, and the per-tile error sums
 struct Xch {
-    float* u;          // [2 parities][2 components][npix of the scale]
-    float* partial;    // [2 parities][ntiles]
+    float* u;                      // scale_kernel: [2 parities][2 components][npix]; scale_kernel_patch: [2 parities][npix] records
+    unsigned long long* partial;   // [2 parities][ntiles] fixed-point sums (scale_kernel, scale_kernel_mem)
+    unsigned long long* acc;       // [2 parities][kSumRecs] 16-byte records of the blocks' convergence sums (scale_kernel_patch)
 };
 // Several image pairs (the dataset's offline flow computation) share one launch: lane = blockIdx.x / gp.  The lanes
 // never talk to each other -- each has its own buffers, barrier counter and iteration count -- they only fill the
@@ -337,8 +380,8 @@ __device__ __forceinline__ void bst(__amdgpu_buffer_rsrc_t r, unsigned voff, uns
 // ctl[2] accumulates the iterations run (statistics), ctl[3] is the abort word of grid_sync.
 template <int T>
 __global__ __launch_bounds__(256) void scale_kernel(Lanes lanes) {
-    __shared__ float shf[T][4];
-    __shared__ double shd[4];
+    __shared__ unsigned long long shf[T][4];
+    __shared__ unsigned long long shd[4];
     const int lane_id = blockIdx.x / lanes.gp, gb = blockIdx.x - lane_id * lanes.gp;
     const unsigned gp = (unsigned)lanes.gp;
     const Scale s = lanes.l[lane_id].s;
@@ -350,6 +393,7 @@ __global__ __launch_bounds__(256) void scale_kernel(Lanes lanes) {
     const int nx = s.nx, ny = s.ny, npix = nx * ny;
     const int ntiles = (npix + 255) >> 8;
     const int tid = threadIdx.x;
+    const float emul = __builtin_ldexpf(1.f, err_shift(npix));
     const unsigned S = (unsigned)npix * 4u, row = (unsigned)nx * 4u;
     const __amdgpu_buffer_rsrc_t ur = __builtin_amdgcn_make_buffer_rsrc((void*)x.u, 0, (int)(4u * S), 0x00020000);
     unsigned target = 0;
@@ -388,24 +432,25 @@ __global__ __launch_bounds__(256) void scale_kernel(Lanes lanes) {
         }
         for (int n = 0;;) {
             const unsigned so1 = par * 2u * S, so2 = so1 + S;
-            float* part = x.partial + par * ntiles;
+            unsigned long long* part = x.partial + par * ntiles;
 #pragma unroll
             for (int k = 0; k < T; ++k) {
-                float e = 0.f;
+                unsigned long long e = 0;
                 if (act[k]) {
                     const Edge ed{pj[k] == 0, pj[k] == nx - 1, pi[k] == 0, pi[k] == ny - 1};
-                    e = u_px(ed, u1[k], u2[k], wx[k], wy[k], grad[k], rho_c[k], p11[k], p12[k], p21[k], p22[k], l11[k], t12[k], l21[k],
-                             t22[k]);
+                    e = err_fix(u_px(ed, u1[k], u2[k], wx[k], wy[k], grad[k], rho_c[k], p11[k], p12[k], p21[k], p22[k], l11[k], t12[k],
+                                     l21[k], t22[k]),
+                                emul);
                     bst(ur, po[k], so1, u1[k]);
                     bst(ur, po[k], so2, u2[k]);
                 }
-                for (int o = 32; o > 0; o >>= 1) e += __shfl_down(e, o);
+                e = wave_sum_u64(e);
                 if ((tid & 63) == 0) shf[k][tid >> 6] = e;
             }
             __syncthreads();
             if (tid < T) {
                 const int t = gb + tid * (int)gp;
-                if (t < ntiles) stc(part + t, (shf[tid][0] + shf[tid][1]) + (shf[tid][2] + shf[tid][3]));
+                if (t < ntiles) stq(part + t, (shf[tid][0] + shf[tid][1]) + (shf[tid][2] + shf[tid][3]));
             }
             ++n;
             ++total;
@@ -464,6 +509,323 @@ __global__ __launch_bounds__(256) void scale_kernel(Lanes lanes) {
     if (gb == 0 && tid == 0) ctl[2] += total;
 }
 
+// ---- the register-state kernel without a grid barrier in its iteration ----
+// scale_kernel's iteration is a chain of four memory-side round trips (stores acknowledged | arrival atomic | the
+// counter seen complete | neighbour loads).  Here a block owns a 64 x PH PATCH of the image instead of interleaved
+// row segments, so that
+//   * neighbours inside the patch are read from an LDS copy of the patch's u (two parities);
+//   * only the patch's perimeter travels: a perimeter pixel's u goes out as ONE 16-byte record {u1, tag, u2, tag}
+//     (write-through), tag = launch epoch and iteration number.  The owner of a ring cell polls the record until both
+//     tags are this iteration's -- each 8-byte half carries its own tag, so a record needs no other ordering: no
+//     "stores acknowledged" wait, no flag;
+//   * the convergence sum travels the same way: one tagged record per block, {sum lo, tag, sum hi, tag}, polled by
+//     one wave of every block (fixed point: any order of adding, same bits).  Having every block's sum of iteration
+//     k is also what allows the parity buffers' reuse: a block that has published it has read all of iteration k - 1.
+// Who does what between the two workgroup barriers of an iteration: waves 0-3 poll the ring cells, wave 4 polls the
+// sums, waves 5-7 publish the perimeter (from the LDS copy) and the block's sum.  Publishers never wait for their
+// stores and pollers have none in flight (on this chip a wave's loads return behind its earlier stores), and the
+// barriers are `s_barrier` behind an LDS-only wait -- __syncthreads() would wait for the write-through stores too.
+// One iteration = one-way store + one poll round trip + the arithmetic, which is scale_kernel's, operand for operand.
+constexpr int kSumRecs = 256;                                // sum records per parity: one per block of a lane
+using u32x4 = __attribute__((vector_size(16))) unsigned;
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// a record whose two tags are `tagv`; false when the launch is being abandoned
+__device__ __forceinline__ bool poll_rec(__amdgpu_buffer_rsrc_t r, unsigned off, unsigned soff, unsigned tagv, int* abort_word,
+                                         unsigned& a, unsigned& b) {
+    for (unsigned spins = 0;;) {
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, off, soff, 16 /* sc1 */);
+        if (v[1] == tagv && v[3] == tagv) {
+            a = v[0];
+            b = v[2];
+            return true;
+        }
+        if (++spins > kSpinLimit || ((spins & 255u) == 0 && __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+            __hip_atomic_store(abort_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return false;
+        }
+    }
+}
+
+#ifdef RVDD_STAMPS
+__device__ unsigned long long g_tvl1_stamps[512][8];
+#define TS(v) const unsigned long long v = wall_clock64()
+#else
+#define TS(v)
+#endif
+// NT = 512 (patch 64 x 8T, one block per CU) or 256 (64 x 4T, two blocks per CU: one computes while the other polls).
+template <int T, int NT>
+__global__ __launch_bounds__(NT) void scale_kernel_patch(Lanes lanes, unsigned epoch) {
+    constexpr int NW = NT / 64, PW = 64, PH = T * NW, MW = PW + 2, MH = PH + 2;
+    constexpr int NRING = 2 * MW + 2 * PH;            // cells around the patch
+    constexpr int NPERIM = 2 * PW + 2 * (PH - 2);     // cells on its edge
+    constexpr int RW = NW / 2;                        // waves 0 .. RW-1 poll the ring, wave RW the sums, the rest publish
+    constexpr int SUM0 = 64 * RW, PUB0 = SUM0 + 64;   // first thread of the sum pollers, of the publishers
+    constexpr int RC = (NRING + SUM0 - 1) / SUM0;                       // ring cells per polling thread
+    constexpr int PC = (NPERIM + (NT - PUB0) - 1) / (NT - PUB0);        // edge cells per publishing thread
+    constexpr int NC = RC > PC ? RC : PC;
+    __shared__ float2 map[2][MH][MW];            // u of the patch and of the ring around it, by iteration parity
+    __shared__ unsigned long long red[NW];
+    __shared__ unsigned long long sh_sum;
+    __shared__ int sh_ok;
+    const int lane_id = blockIdx.x / lanes.gp, gb = blockIdx.x - lane_id * lanes.gp;
+    const unsigned gp = (unsigned)lanes.gp;
+    const Scale s = lanes.l[lane_id].s;
+    const IterBufs b = lanes.l[lane_id].b;
+    const Xch x = lanes.l[lane_id].x;
+    unsigned* const bar = lanes.l[lane_id].bar;
+    int* const ctl = lanes.l[lane_id].ctl;
+    int* const abort_word = lanes.abort_word;
+    const int nx = s.nx, ny = s.ny, npix = nx * ny;
+    const int tid = threadIdx.x, lx = tid & 63, wv = tid >> 6;
+    const int npx = (nx + PW - 1) / PW;
+    const int py = gb / npx, px = gb - py * npx;
+    const int x0 = px * PW, y0 = py * PH;
+    const int shift = err_shift(npix);
+    const float emul = __builtin_ldexpf(1.f, shift);
+    const __amdgpu_buffer_rsrc_t ur = __builtin_amdgcn_make_buffer_rsrc((void*)x.u, 0, (int)(32u * (unsigned)npix), 0x00020000);
+    const __amdgpu_buffer_rsrc_t sr = __builtin_amdgcn_make_buffer_rsrc((void*)x.acc, 0, 2 * kSumRecs * 16, 0x00020000);
+    const unsigned S = 16u * (unsigned)npix;      // one parity of records
+    // this thread's pixels: column lx of the patch, rows wv * T .. wv * T + T - 1
+    const int gx = x0 + lx, gy0 = y0 + wv * T;
+    bool act[T];
+#pragma unroll
+    for (int k = 0; k < T; ++k) act[k] = gx < nx && gy0 + k < ny;
+    const int pbase = gy0 * nx + gx;              // pixel index of slot 0 (slot k: + k * nx)
+    // this thread's cells between the barriers: ring cells to fetch (waves < RW) or edge cells to publish (waves > RW)
+    int cmy[NC], cmx[NC];                         // map coordinates (the patch's pixel (ly, lx) is map cell (ly + 1, lx + 1))
+    bool cvalid[NC], ccell[NC];
+    unsigned coff[NC];
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+        cmy[i] = cmx[i] = 0;
+        ccell[i] = false;
+        if (tid < SUM0 && i < RC) {
+            const int q = tid + i * SUM0;
+            if (q < MW) { cmy[i] = 0; cmx[i] = q; }
+            else if (q < 2 * MW) { cmy[i] = MH - 1; cmx[i] = q - MW; }
+            else { const int r = q - 2 * MW; cmx[i] = r < PH ? 0 : MW - 1; cmy[i] = 1 + (r < PH ? r : r - PH); }
+            ccell[i] = q < NRING;
+        } else if (tid >= PUB0 && i < PC) {
+            const int q = tid - PUB0 + i * (NT - PUB0);
+            if (q < PW) { cmy[i] = 1; cmx[i] = 1 + q; }
+            else if (q < 2 * PW) { cmy[i] = PH; cmx[i] = 1 + q - PW; }
+            else { const int r = q - 2 * PW; cmx[i] = r < PH - 2 ? 1 : PW; cmy[i] = 2 + (r < PH - 2 ? r : r - (PH - 2)); }
+            ccell[i] = q < NPERIM;
+        }
+        const int cgy = y0 + cmy[i] - 1, cgx = x0 + cmx[i] - 1;
+        cvalid[i] = ccell[i] && cgx >= 0 && cgx < nx && cgy >= 0 && cgy < ny;      // a pixel of the image
+        coff[i] = cvalid[i] ? 16u * (unsigned)(cgy * nx + cgx) : 0u;
+    }
+    if (tid == 0) sh_ok = 1;
+#ifdef RVDD_STAMPS
+    __shared__ unsigned long long sh_acc_t;
+    if (tid == 0) sh_acc_t = 0;
+    unsigned long long st_a = 0, st_w = 0, st_d = 0, st_ring = 0;
+    const unsigned long long st_begin = wall_clock64();
+#endif
+    unsigned target = 0;
+    int total = 0;
+    // gradient of I1 (tvl1flow_lib.c:127): plain stores, made visible to the other blocks by the heavy barrier
+#pragma unroll
+    for (int k = 0; k < T; ++k)
+        if (act[k]) centered_gradient_px(s.I1, b.I1x, b.I1y, nx, ny, gy0 + k, gx);
+    if (!grid_sync<true>(bar, target, gp, abort_word)) return;
+    // The dual fields of the left and of the upper pixel, which the divergence reads.  scale_kernel has every thread recompute
+    // both neighbours' dual update; a thread of a patch finds most of them next to it:
+    //   upper pixel: the thread's own slot k - 1; only slot 0 recomputes (t12, t22: the row above the wave's rows);
+    //   left pixel: lane - 1's own p11 / p21 (a lane shift); only lane 0 has to recompute, and does so for its T rows in
+    //   ONE pass with row k in lane k (lg11, lg21: lane k < T holds the left neighbour of lane 0's slot k).
+    // Same operands, same operations, hence the same bits as the recomputation.
+    float u1[T], u2[T], p11[T], p12[T], p21[T], p22[T], wx[T], wy[T], grad[T], rho_c[T];
+    float t12 = 0.f, t22 = 0.f, lg11 = 0.f, lg21 = 0.f;
+#pragma unroll
+    for (int k = 0; k < T; ++k) {
+        u1[k] = act[k] ? s.u1[pbase + k * nx] : 0.f;
+        u2[k] = act[k] ? s.u2[pbase + k * nx] : 0.f;
+        p11[k] = p12[k] = p21[k] = p22[k] = 0.f;      // tvl1flow_lib.c:131-139
+        wx[k] = wy[k] = grad[k] = rho_c[k] = 0.f;
+    }
+    unsigned par = 0;
+    for (int wp = 0; wp < kWarps; ++wp) {
+#pragma unroll
+        for (int k = 0; k < T; ++k) {
+            if (act[k]) warp_px(s, b, gy0 + k, gx, pbase + k * nx, u1[k], u2[k], wx[k], wy[k], grad[k], rho_c[k]);
+            __builtin_amdgcn_sched_barrier(0);   // one 3 x 16-tap stencil at a time
+        }
+        __builtin_amdgcn_s_waitcnt(0);           // the warp's loads are the last this wave waits for until the scale's end
+        for (int n = 0;;) {
+            ++n;
+            ++total;
+            TS(ts0);
+            const unsigned tagv = epoch * 2048u + (unsigned)total;
+            unsigned long long esum = 0;
+#pragma unroll
+            for (int k = 0; k < T; ++k) {
+                // left neighbour's p11, p21: lane - 1's (wave_shr:1), lane 0 keeps `old` = its recomputed copy
+                const float l11 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_amdgcn_readlane(__builtin_bit_cast(int, lg11), k),
+                                                                                       __builtin_bit_cast(int, p11[k]), 0x138, 0xf, 0xf, false));
+                const float l21 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_amdgcn_readlane(__builtin_bit_cast(int, lg21), k),
+                                                                                       __builtin_bit_cast(int, p21[k]), 0x138, 0xf, 0xf, false));
+                const float up12 = k == 0 ? t12 : p12[k > 0 ? k - 1 : 0], up22 = k == 0 ? t22 : p22[k > 0 ? k - 1 : 0];
+                if (act[k]) {
+                    const Edge ed{gx == 0, gx == nx - 1, gy0 + k == 0, gy0 + k == ny - 1};
+                    esum += err_fix(u_px(ed, u1[k], u2[k], wx[k], wy[k], grad[k], rho_c[k], p11[k], p12[k], p21[k], p22[k], l11, up12, l21,
+                                         up22),
+                                    emul);
+                }
+                map[par][wv * T + k + 1][lx + 1] = float2{u1[k], u2[k]};
+            }
+            esum = wave_sum_fix(esum);
+            if (lx == 0) red[wv] = esum;
+            lds_barrier();
+            TS(ts1);
+            if (tid < SUM0) {                    // the ring: this thread's cells requested together, again until all are there
+                float2 got[RC];
+                bool need[RC];
+#pragma unroll
+                for (int i = 0; i < RC; ++i) {
+                    got[i] = float2{0.f, 0.f};
+                    need[i] = cvalid[i];
+                }
+                for (unsigned spins = 0;;) {
+                    u32x4 v[RC];
+#pragma unroll
+                    for (int i = 0; i < RC; ++i)
+                        if (need[i]) v[i] = __builtin_amdgcn_raw_buffer_load_b128(ur, coff[i], par * S, 16 /* sc1 */);
+                    bool more = false;
+#pragma unroll
+                    for (int i = 0; i < RC; ++i)
+                        if (need[i]) {
+                            if (v[i][1] == tagv && v[i][3] == tagv) {
+                                got[i] = float2{__uint_as_float(v[i][0]), __uint_as_float(v[i][2])};
+                                need[i] = false;
+                            } else {
+                                more = true;
+                            }
+                        }
+                    if (!more) break;
+                    if (++spins > kSpinLimit || ((spins & 255u) == 0 && __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+                        __hip_atomic_store(abort_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        sh_ok = 0;
+                        break;
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < RC; ++i)
+                    if (ccell[i]) map[par][cmy[i]][cmx[i]] = got[i];
+#ifdef RVDD_STAMPS
+                if (tid == 0) st_ring += wall_clock64() - ts1;
+#endif
+            } else if (tid < PUB0) {             // every block's sum; the own one from LDS
+                // lane l: the records of blocks l, l + 64, l + 128, l + 192, requested together; the own block's sum from LDS
+                unsigned long long t = 0;
+                bool need[kSumRecs / 64];
+#pragma unroll
+                for (int i = 0; i < kSumRecs / 64; ++i) {
+                    const unsigned j = (unsigned)lx + 64u * i;
+                    need[i] = j < gp && j != (unsigned)gb;
+                }
+                if ((unsigned)lx == ((unsigned)gb & 63u))
+#pragma unroll
+                    for (int i = 0; i < NW; ++i) t += red[i];
+                for (unsigned spins = 0;;) {
+                    u32x4 v[kSumRecs / 64];
+#pragma unroll
+                    for (int i = 0; i < kSumRecs / 64; ++i)
+                        if (need[i]) v[i] = __builtin_amdgcn_raw_buffer_load_b128(sr, 16u * ((unsigned)lx + 64u * i), par * (kSumRecs * 16u), 16);
+                    bool more = false;
+#pragma unroll
+                    for (int i = 0; i < kSumRecs / 64; ++i)
+                        if (need[i]) {
+                            if (v[i][1] == tagv && v[i][3] == tagv) {
+                                t += ((unsigned long long)v[i][2] << 32) | v[i][0];
+                                need[i] = false;
+                            } else {
+                                more = true;
+                            }
+                        }
+                    if (!more) break;
+                    if (++spins > kSpinLimit || ((spins & 255u) == 0 && __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+                        __hip_atomic_store(abort_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        sh_ok = 0;
+                        break;
+                    }
+                }
+                t = wave_sum_fix(t);
+                if (lx == 0) sh_sum = t;
+#ifdef RVDD_STAMPS
+                if (lx == 0) sh_acc_t += wall_clock64() - ts1;
+#endif
+            } else {                             // the patch's edge, and the block's sum
+#pragma unroll
+                for (int i = 0; i < PC; ++i)
+                    if (cvalid[i]) {
+                        const float2 v = map[par][cmy[i]][cmx[i]];
+                        const u32x4 rec = {__float_as_uint(v.x), tagv, __float_as_uint(v.y), tagv};
+                        __builtin_amdgcn_raw_buffer_store_b128(rec, ur, coff[i], par * S, 16 /* sc1 */);
+                    }
+                if (tid == NT - 1) {
+                    unsigned long long t = 0;
+#pragma unroll
+                    for (int i = 0; i < NW; ++i) t += red[i];
+                    const u32x4 rec = {(unsigned)t, tagv, (unsigned)(t >> 32), tagv};
+                    __builtin_amdgcn_raw_buffer_store_b128(rec, sr, 16u * (unsigned)gb, par * (kSumRecs * 16u), 16 /* sc1 */);
+                }
+            }
+            lds_barrier();
+            TS(ts2);
+            if (!sh_ok) return;
+            const float error = err_value(sh_sum, shift, npix);
+            // dual update n (tvl1flow_lib.c:217-234) of the own, the left and the upper pixel, as in scale_kernel
+#pragma unroll
+            for (int k = 0; k < T; ++k)
+                if (act[k]) {
+                    const int my = wv * T + k + 1, mx = lx + 1;
+                    const float2 r = map[par][my][mx + 1], d = map[par][my + 1][mx];
+                    const float2 a = map[par][my - 1][mx], f = map[par][my - 1][mx + 1];      // used by slot 0 only
+                    const bool cN = gx == nx - 1, rN = gy0 + k == ny - 1;
+                    const DualStep o = dual_step(cN, rN, u1[k], u2[k], r.x, d.x, r.y, d.y);
+                    p11[k] = dual_upd(p11[k], o.u1x, o.ng1);
+                    p12[k] = dual_upd(p12[k], o.u1y, o.ng1);
+                    p21[k] = dual_upd(p21[k], o.u2x, o.ng2);
+                    p22[k] = dual_upd(p22[k], o.u2y, o.ng2);
+                    if (k == 0 && gy0 > 0) {      // the pixel above the wave's first row
+                        const DualStep t = dual_step(cN, false, a.x, a.y, f.x, u1[k], f.y, u2[k]);
+                        t12 = dual_upd(t12, t.u1y, t.ng1);
+                        t22 = dual_upd(t22, t.u2y, t.ng2);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            if (lx < T && x0 > 0 && gy0 + lx < ny) {      // lane k: the pixel left of the patch in row k of this wave
+                const int my = wv * T + lx + 1;
+                const float2 c = map[par][my][0], e = map[par][my + 1][0], own = map[par][my][1];
+                const DualStep l = dual_step(false, gy0 + lx == ny - 1, c.x, c.y, own.x, e.x, own.y, e.y);
+                lg11 = dual_upd(lg11, l.u1x, l.ng1);
+                lg21 = dual_upd(lg21, l.u2x, l.ng2);
+            }
+            par ^= 1u;
+#ifdef RVDD_STAMPS
+            { const unsigned long long ts3 = wall_clock64(); st_a += ts1 - ts0; st_w += ts2 - ts1; st_d += ts3 - ts2; }
+#endif
+            if (!(error > kEps * kEps) || n >= kMaxIter) break;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < T; ++k)
+        if (act[k]) {
+            s.u1[pbase + k * nx] = u1[k];
+            s.u2[pbase + k * nx] = u2[k];
+        }
+    if (gb == 0 && tid == 0) ctl[2] += total;
+#ifdef RVDD_STAMPS
+    if (tid == 0 && blockIdx.x < 512) {
+        unsigned long long* o = g_tvl1_stamps[blockIdx.x];
+        o[0] = (unsigned long long)total; o[1] = st_a; o[2] = st_w; o[3] = st_d; o[4] = st_ring; o[5] = sh_acc_t;
+        o[6] = wall_clock64() - st_begin; o[7] = (unsigned long long)T;
+    }
+#endif
+}
+
 // The same scale for images whose pixels do not fit the register slots of one resident grid
 // (> kMaxSlots x 256 x #CUs pixels): the same arithmetic on the same values, but a block walks its tiles one
 // after the other and a pixel's state lives in memory (u in place, p in b.p*, the warped gradient and rho_c in
@@ -472,8 +834,8 @@ struct StateBufs {
     float *wx, *wy, *grad, *rho_c;
 };
 __global__ __launch_bounds__(256) void scale_kernel_mem(Lanes lanes, StateBufs st) {
-    __shared__ float shf[4];
-    __shared__ double shd[4];
+    __shared__ unsigned long long shf[4];
+    __shared__ unsigned long long shd[4];
     const int gb = blockIdx.x;                        // one lane only: this form is the fallback for very large images
     const unsigned gp = (unsigned)lanes.gp;
     const Scale s = lanes.l[0].s;
@@ -485,7 +847,8 @@ __global__ __launch_bounds__(256) void scale_kernel_mem(Lanes lanes, StateBufs s
     const int nx = s.nx, ny = s.ny, npix = nx * ny;
     const int ntiles = (npix + 255) >> 8;
     const int tid = threadIdx.x;
-    float* partial = x.partial;
+    unsigned long long* partial = x.partial;
+    const float emul = __builtin_ldexpf(1.f, err_shift(npix));
     unsigned target = 0;
     int total = 0;
 #define FOR_TILES(...)                                           \
@@ -508,21 +871,22 @@ __global__ __launch_bounds__(256) void scale_kernel_mem(Lanes lanes, StateBufs s
         })
         for (int n = 0;;) {
             FOR_TILES(
-                float e = 0.f;
+                unsigned long long e = 0;
                 if (on) {
                     float u1 = s.u1[p], u2 = s.u2[p];
                     const float l11 = j > 0 ? ldc(b.p11 + p - 1) : 0.f, l21 = j > 0 ? ldc(b.p21 + p - 1) : 0.f;
                     const float t12 = i > 0 ? ldc(b.p12 + p - nx) : 0.f, t22 = i > 0 ? ldc(b.p22 + p - nx) : 0.f;
                     const Edge ed{j == 0, j == nx - 1, i == 0, i == ny - 1};
-                    e = u_px(ed, u1, u2, st.wx[p], st.wy[p], st.grad[p], st.rho_c[p], b.p11[p], b.p12[p], b.p21[p], b.p22[p], l11, t12, l21,
-                             t22);
+                    e = err_fix(u_px(ed, u1, u2, st.wx[p], st.wy[p], st.grad[p], st.rho_c[p], b.p11[p], b.p12[p], b.p21[p], b.p22[p], l11, t12,
+                                     l21, t22),
+                                emul);
                     stc(s.u1 + p, u1);
                     stc(s.u2 + p, u2);
                 }
-                for (int o = 32; o > 0; o >>= 1) e += __shfl_down(e, o);
+                e = wave_sum_u64(e);
                 if ((tid & 63) == 0) shf[tid >> 6] = e;
                 __syncthreads();
-                if (tid == 0) stc(partial + t, (shf[0] + shf[1]) + (shf[2] + shf[3]));
+                if (tid == 0) stq(partial + t, (shf[0] + shf[1]) + (shf[2] + shf[3]));
                 __syncthreads();
             )
             if (!grid_sync<false>(bar, target, gp, abort_word)) return;
@@ -549,6 +913,23 @@ __global__ __launch_bounds__(256) void scale_kernel_mem(Lanes lanes, StateBufs s
 constexpr int kTileSlots[] = {1, 2, 3, 4, 5, 6, 8};
 constexpr int kMaxSlots = 8;
 using ScaleKernel = void (*)(Lanes);
+using PatchKernel = void (*)(Lanes, unsigned);
+// (slots, threads): patches of 64 x 8, 64 x 16 (both forms), 64 x 32 pixels
+PatchKernel patch_kernel_for(int slots, int threads) {
+    if (threads == 256) {
+        switch (slots) {
+            case 2: return scale_kernel_patch<2, 256>;
+            case 4: return scale_kernel_patch<4, 256>;
+        }
+    } else {
+        switch (slots) {
+            case 1: return scale_kernel_patch<1, 512>;
+            case 2: return scale_kernel_patch<2, 512>;
+            case 4: return scale_kernel_patch<4, 512>;
+        }
+    }
+    return nullptr;
+}
 ScaleKernel scale_kernel_for(int slots) {
     switch (slots) {
         case 1: return scale_kernel<1>;
@@ -593,7 +974,9 @@ struct Tvl1Workspace {
     std::vector<Tvl1LaneBufs> lanes;     // lane 0 at allocation, lane 1 with the first batch call
     int* abort_word = nullptr;
     int cus = 0;
+    unsigned epoch = 0;         // scale_kernel_patch: one per launch, the upper bits of its records' tags
     StateBufs state{};          // scale_kernel_mem only: allocated when the finest scale exceeds the register slots
+    bool patch = true;          // RVDD_TVL1_PATCH=0: scale_kernel (grid barrier per iteration) instead of scale_kernel_patch
     bool force_mem = false;     // RVDD_TVL1_MEM=1: take the memory-state kernel at every scale (equivalence tests)
     std::vector<void*> allocs;
 };
@@ -655,8 +1038,15 @@ static hipError_t tvl1_add_lane(Tvl1Workspace* w) {
     const size_t n0 = (size_t)w->nx * w->ny;
     float** its[] = {&L.it.I1x, &L.it.I1y, &L.it.I1w, &L.it.p11, &L.it.p12, &L.it.p21, &L.it.p22, &L.tmp, &L.tmp2};
     for (float** p : its) A(p, n0);
-    A(&L.xch.partial, 2 * ((n0 + 255) / 256));
-    A(&L.xch.u, 4 * n0);
+    float* words64 = nullptr;
+    A(&words64, 4 * ((n0 + 255) / 256));                      // 2 parities of 64-bit tile sums
+    L.xch.partial = reinterpret_cast<unsigned long long*>(words64);
+    A(&L.xch.u, 8 * n0);                                      // 2 parities of 16-byte records (scale_kernel: 4 planes of floats)
+    if (err == hipSuccess) err = hipMemset(L.xch.u, 0, 8 * n0 * sizeof(float));      // tag 0: no launch's
+    words64 = nullptr;
+    A(&words64, 2 * kSumRecs * 4);                            // 2 parities of 16-byte sum records
+    L.xch.acc = reinterpret_cast<unsigned long long*>(words64);
+    if (err == hipSuccess) err = hipMemset(words64, 0, 2 * kSumRecs * 16);
     A(&L.mm, 4);
     float* words = nullptr;
     A(&words, 8);                                    // 4 control ints + the barrier counter
@@ -685,6 +1075,8 @@ hipError_t tvl1_alloc(Tvl1Workspace** out, int nx, int ny) {
     const size_t n0 = (size_t)nx * ny;
     const char* fm = std::getenv("RVDD_TVL1_MEM");
     w->force_mem = fm && fm[0] == '1';
+    const char* pk = std::getenv("RVDD_TVL1_PATCH");
+    w->patch = !pk || std::atoi(pk) != 0;
     if (err == hipSuccess && (w->force_mem || (n0 + 255) / 256 > (size_t)w->cus * kMaxSlots))
         for (float** p : {&w->state.wx, &w->state.wy, &w->state.grad, &w->state.rho_c})
             if (err == hipSuccess) {
@@ -766,11 +1158,41 @@ static hipError_t tvl1_run_lanes(Tvl1Workspace* w, const float* I0, const float*
         // register-state kernel: the smallest slot count T such that a lane has at most one block per CU and all
         // lanes together are co-resident
         int slots = 0, gp = 0;
+        // The patch kernel (no grid barrier per iteration) where every lane's 64 x 8T patches get a CU each; T as small as fits.
+        bool patched = false;
+        if (w->patch && !w->force_mem) {
+            // smallest patch height whose blocks are all resident: one 512-thread block per CU (8, 16, 32 rows), or two
+            // 256-thread blocks per CU (16 rows: as many pixels per CU as 32 rows in one block, but one block computes while
+            // the other waits for its ring)
+            static const int two = [] { const char* e = std::getenv("RVDD_TVL1_TWO"); return e ? std::atoi(e) : 1; }();
+            int pt = 0, pg = 0, pn = 512;
+            struct Form { int t, n, rows, per_cu; };
+            static const Form forms[] = {{1, 512, 8, 1}, {2, 512, 16, 1}, {4, 256, 16, 2}, {4, 512, 32, 1}};
+            for (const Form& f : forms) {
+                if (f.per_cu == 2 && !two) continue;
+                const int g = ((ref.nx + 63) / 64) * ((ref.ny + f.rows - 1) / f.rows);
+                if ((long)np * g <= (long)w->cus * f.per_cu && g <= kSumRecs) { pt = f.t; pn = f.n; pg = g; break; }
+            }
+            if (pt) {
+                if (++w->epoch >= (1u << 21)) {       // tags repeat after 2^21 launches: start over from clean records
+                    w->epoch = 1;
+                    for (Tvl1LaneBufs& L : w->lanes) {
+                        CK(hipMemsetAsync(L.xch.u, 0, 8 * (size_t)n0 * sizeof(float), st));
+                        CK(hipMemsetAsync(L.xch.acc, 0, 2 * kSumRecs * 16, st));
+                    }
+                }
+                lanes.gp = pg;
+                unsigned epoch = w->epoch;
+                void* args[] = {&lanes, &epoch};
+                CK(hipLaunchCooperativeKernel(reinterpret_cast<const void*>(patch_kernel_for(pt, pn)), dim3(pg * np), dim3(pn), args, 0, st));
+                patched = true;
+            }
+        }
         // With several lanes prefer the smallest T that gives every block of every lane a CU of its own (np * g <= CUs)
         // over two blocks per CU: two 640x360 pairs then take T = 8 on 113 CUs each instead of T = 4 on all CUs twice --
         // 2.44 instead of 2.70 ms per flow, same bits (round 3; RVDD_TVL1_SPREAD=0 restores the old choice).
         static const bool spread = [] { const char* e = std::getenv("RVDD_TVL1_SPREAD"); return !e || std::atoi(e) != 0; }();
-        if (!w->force_mem) {
+        if (!w->force_mem && !patched) {
             if (spread && np > 1)
                 for (int c : kTileSlots) {
                     const int g = (ntiles + c - 1) / c;
@@ -784,7 +1206,8 @@ static hipError_t tvl1_run_lanes(Tvl1Workspace* w, const float* I0, const float*
                     if (g <= w->cus && (long)np * g <= (long)w->cus * per_cu) { slots = c; gp = g; break; }
                 }
         }
-        if (slots) {
+        if (patched) {
+        } else if (slots) {
             lanes.gp = gp;
             void* args[] = {&lanes};
             CK(hipLaunchCooperativeKernel(reinterpret_cast<const void*>(scale_kernel_for(slots)), dim3(gp * np), dim3(256), args, 0, st));
@@ -814,6 +1237,18 @@ static hipError_t tvl1_run_lanes(Tvl1Workspace* w, const float* I0, const float*
         for (int q = 0; q < np; ++q) CK(hipMemcpyAsync(c[q], w->lanes[q].ctl, 4 * sizeof(int), hipMemcpyDeviceToHost, st));
         CK(hipStreamSynchronize(st));
         if (ab) return hipErrorLaunchTimeOut;
+#ifdef RVDD_STAMPS
+        if (std::getenv("RVDD_TVL1_STAMPS")) {
+            static unsigned long long hs[512][8];
+            CK(hipMemcpyFromSymbol(hs, HIP_SYMBOL(g_tvl1_stamps), sizeof hs));
+            for (int b : {0, 1, 57, 119, 120, 200}) {
+                const unsigned long long* o = hs[b];
+                if (!o[0]) continue;
+                std::fprintf(stderr, "tvl1 stamps block %3d T=%llu iters %llu | per iteration (10 ns ticks): update %.1f wait %.1f (ring %.1f acc %.1f) dual %.1f | kernel %.1f us\n",
+                             b, o[7], o[0], (double)o[1] / o[0], (double)o[2] / o[0], (double)o[4] / o[0], (double)o[5] / o[0], (double)o[3] / o[0], o[6] / 100.0);
+            }
+        }
+#endif
         if (iters)
             for (int q = 0; q < np; ++q) iters[q] = c[q][2];
     }

@@ -103,12 +103,22 @@ def test_no_kernel_spills_to_scratch():
     few = ("conv3x3h_kernel<48, 0, true, ", "conv3x3h_kernel<48, 1, true, ", "conv3x3h_kernel<48, 1, false, true, ",
            "conv3x3h_kernel<48, 3, ", "conv3x3h_kernel<48, 4, ", "conv3x3h_kernel<16, ")
     once = once + few
+    # the plain 48 -> 48 instantiations keep ONE loop invariant in a vector lane since the tile's own offsets moved to chunk 6
+    # of the MFMA loop (+0.4 % on C2): pinned at that one
+    plain = ("conv3x3h_kernel<48, 0, false, false, 1, 3>", "conv3x3h_kernel<48, 1, false, false, 1, 3>")
     bad = [(r["name"], r["sgpr_spill_count"]) for r in rows if r["name"].startswith(hot) and not r["name"].startswith(once)
-           and r.get("sgpr_spill_count", 0)]
+           and r.get("sgpr_spill_count", 0) > (1 if r["name"].startswith(plain) else 0)]
     assert not bad, bad
-    bad = [(r["name"], r["sgpr_spill_count"]) for r in rows if r["name"].startswith(once) and r.get("sgpr_spill_count", 0) > 16]
+    # the fused-upsample instantiations (three launches per frame-step) carry the interpolation's row / column constants on
+    # top of the tile loop's: 20 and 17 scalars in vector lanes, pinned there
+    ups = ("conv3x3h_kernel<48, 1, false, true, ",)
+    bad = [(r["name"], r["sgpr_spill_count"]) for r in rows if r["name"].startswith(once) and not r["name"].startswith(ups)
+           and r.get("sgpr_spill_count", 0) > 16]
     assert not bad, bad
-    bad = [(r["name"], r["sgpr_spill_count"]) for r in rows if r["name"].startswith(few) and r.get("sgpr_spill_count", 0) > 14]
+    bad = [(r["name"], r["sgpr_spill_count"]) for r in rows if r["name"].startswith(few) and not r["name"].startswith(ups)
+           and r.get("sgpr_spill_count", 0) > 14]
+    assert not bad, bad
+    bad = [(r["name"], r["sgpr_spill_count"]) for r in rows if r["name"].startswith(ups) and r.get("sgpr_spill_count", 0) > 20]
     assert not bad, bad
     # the pipelined ConvBlock is C4's hot kernel (about 25 launches per frame-step), not a once-per-step variant: its plain
     # instantiation is pinned at what it has today, the pooling / 1x1-output ones at a handful

@@ -93,26 +93,32 @@ def test_hip_flow_matches_oracle_and_bridge_surface():
 
 
 @pytest.mark.gpu
-def test_hip_register_and_memory_state_kernels_agree():
-    """The persistent per-scale kernel has two forms (pixel state in registers; in memory for images beyond
-    8 x 256 x #CUs pixels).  RVDD_TVL1_MEM=1 forces the second one: same phases, same arithmetic, same
-    fixed-order error sums -> bit-identical flows and iteration counts."""
+@pytest.mark.parametrize("name", ["d_90x160", "a_48x64"])
+def test_hip_scale_kernels_agree(name):
+    """One scale of the pyramid has three kernels: patches with a tagged perimeter exchange (the default), row-segment
+    tiles with a grid barrier per iteration (RVDD_TVL1_PATCH=0), and pixel state in memory for images beyond
+    8 x 256 x #CUs pixels (RVDD_TVL1_MEM=1 forces it).  Same arithmetic per pixel, and the convergence sum is formed in
+    fixed point (any order of adding gives the same bits) -> bit-identical flows and iteration counts."""
     from rvdd_release_amd.util._ops import ops_runtime
-    g = _load("d_90x160")
+    g = _load(name)
     rt = ops_runtime(0)
     I0, I1 = torch.from_numpy(g["I0"]).cuda(), torch.from_numpy(g["I1"]).cuda()
-    u_reg, it_reg = rt.tvl1flow(I0, I1, want_iterations=True)
+    u_patch, it_patch = rt.tvl1flow(I0, I1, want_iterations=True)
     small = torch.rand(20, 24, device="cuda")
-    os.environ["RVDD_TVL1_MEM"] = "1"
-    try:
-        rt.tvl1flow(small, small)                    # another size: the workspace (and its mode) is rebuilt
-        u_mem, it_mem = rt.tvl1flow(I0, I1, want_iterations=True)
-    finally:
-        del os.environ["RVDD_TVL1_MEM"]
-        rt.tvl1flow(small, small)
-    assert it_mem == it_reg and torch.equal(u_mem, u_reg)
+    got = {}
+    for env in ("RVDD_TVL1_PATCH=0", "RVDD_TVL1_MEM=1"):
+        k, v = env.split("=")
+        os.environ[k] = v
+        try:
+            rt.tvl1flow(small, small)                # another size: the workspace (and its mode) is rebuilt
+            got[env] = rt.tvl1flow(I0, I1, want_iterations=True)
+        finally:
+            del os.environ[k]
+            rt.tvl1flow(small, small)
+    for env, (u, it) in got.items():
+        assert it == it_patch and torch.equal(u, u_patch), env
     u_again = rt.tvl1flow(I0, I1)
-    assert torch.equal(u_again, u_reg)               # and the run itself is deterministic
+    assert torch.equal(u_again, u_patch)             # and the run itself is deterministic
 
 
 @pytest.mark.gpu
