@@ -10,7 +10,8 @@
 // bit-identical (the convergence sum is formed in fixed point, see err_fix):
 //   scale_kernel_patch  the default: a block owns a 64 x PH patch, pixel state in registers, neighbours through LDS, the
 //                       patch's perimeter and the blocks' convergence sums through tagged records that the readers poll --
-//                       no grid barrier in the iteration (6.6 us per iteration of a 640x360 pair);
+//                       no grid barrier in the iteration, the convergence test one iteration late (4.4 us per iteration of
+//                       two 640x360 pairs, against 13 with scale_kernel);
 //   scale_kernel        interleaved row segments, one grid barrier per iteration (round 3's kernel; RVDD_TVL1_PATCH=0,
 //                       and images whose patches do not fit the CUs);
 //   scale_kernel_mem    pixel state in memory, two grid barriers per iteration (images beyond the register slots).
@@ -519,14 +520,20 @@ __global__ __launch_bounds__(256) void scale_kernel(Lanes lanes) {
 //     tags are this iteration's -- each 8-byte half carries its own tag, so a record needs no other ordering: no
 //     "stores acknowledged" wait, no flag;
 //   * the convergence sum travels the same way: one tagged record per block, {sum lo, tag, sum hi, tag}, polled by
-//     one wave of every block (fixed point: any order of adding, same bits).  Having every block's sum of iteration
-//     k is also what allows the parity buffers' reuse: a block that has published it has read all of iteration k - 1.
+//     one wave of every block (fixed point: any order of adding, same bits).  It is the one thing of an iteration that
+//     needs EVERY block, so it is read one iteration late: update n + 1 runs before the test of iteration n is known
+//     and is dropped (u restored from a copy) when that test says n was the last -- the state the reference's loop
+//     leaves, reached one discarded update later.  The ring only needs a block's neighbours.
+//   * buffer reuse: ring records have two parities -- a block that publishes P + 1 has read its neighbours' P, so they
+//     have all read its P - 1.  Sum records have four slots -- a block that publishes P has seen every block's P - 2,
+//     so every block is at P - 2 or later and none still polls P - 4.
 // Who does what between the two workgroup barriers of an iteration: waves 0-3 poll the ring cells, wave 4 polls the
 // sums, waves 5-7 publish the perimeter (from the LDS copy) and the block's sum.  Publishers never wait for their
 // stores and pollers have none in flight (on this chip a wave's loads return behind its earlier stores), and the
 // barriers are `s_barrier` behind an LDS-only wait -- __syncthreads() would wait for the write-through stores too.
 // One iteration = one-way store + one poll round trip + the arithmetic, which is scale_kernel's, operand for operand.
-constexpr int kSumRecs = 256;                                // sum records per parity: one per block of a lane
+constexpr int kSumRecs = 256;                                // sum records per slot: one per block of a lane
+constexpr int kSumSlots = 4;                                 // publications whose sums are kept (see the kernel's comment)
 using u32x4 = __attribute__((vector_size(16))) unsigned;
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 // a record whose two tags are `tagv`; false when the launch is being abandoned
@@ -583,7 +590,7 @@ __global__ __launch_bounds__(NT) void scale_kernel_patch(Lanes lanes, unsigned e
     const int shift = err_shift(npix);
     const float emul = __builtin_ldexpf(1.f, shift);
     const __amdgpu_buffer_rsrc_t ur = __builtin_amdgcn_make_buffer_rsrc((void*)x.u, 0, (int)(32u * (unsigned)npix), 0x00020000);
-    const __amdgpu_buffer_rsrc_t sr = __builtin_amdgcn_make_buffer_rsrc((void*)x.acc, 0, 2 * kSumRecs * 16, 0x00020000);
+    const __amdgpu_buffer_rsrc_t sr = __builtin_amdgcn_make_buffer_rsrc((void*)x.acc, 0, kSumSlots * kSumRecs * 16, 0x00020000);
     const unsigned S = 16u * (unsigned)npix;      // one parity of records
     // this thread's pixels: column lx of the patch, rows wv * T .. wv * T + T - 1
     const int gx = x0 + lx, gy0 = y0 + wv * T;
@@ -645,7 +652,7 @@ __global__ __launch_bounds__(NT) void scale_kernel_patch(Lanes lanes, unsigned e
         p11[k] = p12[k] = p21[k] = p22[k] = 0.f;      // tvl1flow_lib.c:131-139
         wx[k] = wy[k] = grad[k] = rho_c[k] = 0.f;
     }
-    unsigned par = 0;
+    unsigned pub = 0;                            // publications of this launch (iterations, the discarded ones included)
     for (int wp = 0; wp < kWarps; ++wp) {
 #pragma unroll
         for (int k = 0; k < T; ++k) {
@@ -656,9 +663,16 @@ __global__ __launch_bounds__(NT) void scale_kernel_patch(Lanes lanes, unsigned e
         for (int n = 0;;) {
             ++n;
             ++total;
+            ++pub;
             TS(ts0);
-            const unsigned tagv = epoch * 2048u + (unsigned)total;
+            const unsigned tagv = epoch * 2048u + pub, par = pub & 1u;
             unsigned long long esum = 0;
+            float u1s[T], u2s[T];                // u of iteration n - 1: this update is undone if that one turns out to have converged
+#pragma unroll
+            for (int k = 0; k < T; ++k) {
+                u1s[k] = u1[k];
+                u2s[k] = u2[k];
+            }
 #pragma unroll
             for (int k = 0; k < T; ++k) {
                 // left neighbour's p11, p21: lane - 1's (wave_shr:1), lane 0 keeps `old` = its recomputed copy
@@ -719,25 +733,24 @@ __global__ __launch_bounds__(NT) void scale_kernel_patch(Lanes lanes, unsigned e
             } else if (tid < PUB0) {             // every block's sum; the own one from LDS
                 // lane l: the records of blocks l, l + 64, l + 128, l + 192, requested together; the own block's sum from LDS
                 unsigned long long t = 0;
+                // (the sums of the PREVIOUS publication: they have had an iteration's time to arrive)
+                const unsigned ptag = tagv - 1u, pslot = ((pub - 1u) & (kSumSlots - 1u)) * (kSumRecs * 16u);
                 bool need[kSumRecs / 64];
 #pragma unroll
                 for (int i = 0; i < kSumRecs / 64; ++i) {
                     const unsigned j = (unsigned)lx + 64u * i;
-                    need[i] = j < gp && j != (unsigned)gb;
+                    need[i] = j < gp && pub > 1u;
                 }
-                if ((unsigned)lx == ((unsigned)gb & 63u))
-#pragma unroll
-                    for (int i = 0; i < NW; ++i) t += red[i];
                 for (unsigned spins = 0;;) {
                     u32x4 v[kSumRecs / 64];
 #pragma unroll
                     for (int i = 0; i < kSumRecs / 64; ++i)
-                        if (need[i]) v[i] = __builtin_amdgcn_raw_buffer_load_b128(sr, 16u * ((unsigned)lx + 64u * i), par * (kSumRecs * 16u), 16);
+                        if (need[i]) v[i] = __builtin_amdgcn_raw_buffer_load_b128(sr, 16u * ((unsigned)lx + 64u * i), pslot, 16);
                     bool more = false;
 #pragma unroll
                     for (int i = 0; i < kSumRecs / 64; ++i)
                         if (need[i]) {
-                            if (v[i][1] == tagv && v[i][3] == tagv) {
+                            if (v[i][1] == ptag && v[i][3] == ptag) {
                                 t += ((unsigned long long)v[i][2] << 32) | v[i][0];
                                 need[i] = false;
                             } else {
@@ -769,13 +782,23 @@ __global__ __launch_bounds__(NT) void scale_kernel_patch(Lanes lanes, unsigned e
 #pragma unroll
                     for (int i = 0; i < NW; ++i) t += red[i];
                     const u32x4 rec = {(unsigned)t, tagv, (unsigned)(t >> 32), tagv};
-                    __builtin_amdgcn_raw_buffer_store_b128(rec, sr, 16u * (unsigned)gb, par * (kSumRecs * 16u), 16 /* sc1 */);
+                    __builtin_amdgcn_raw_buffer_store_b128(rec, sr, 16u * (unsigned)gb, (pub & (kSumSlots - 1u)) * (kSumRecs * 16u), 16 /* sc1 */);
                 }
             }
             lds_barrier();
             TS(ts2);
             if (!sh_ok) return;
-            const float error = err_value(sh_sum, shift, npix);
+            // the convergence test of iteration n - 1 (tvl1flow_lib.c:236-241), one iteration late: its sum needs every block and
+            // is the slowest thing to arrive, so the update above ran ahead of it; if n - 1 was the last, that update is dropped
+            if (n > 1 && !(err_value(sh_sum, shift, npix) > kEps * kEps)) {
+#pragma unroll
+                for (int k = 0; k < T; ++k) {
+                    u1[k] = u1s[k];
+                    u2[k] = u2s[k];
+                }
+                --total;
+                break;
+            }
             // dual update n (tvl1flow_lib.c:217-234) of the own, the left and the upper pixel, as in scale_kernel
 #pragma unroll
             for (int k = 0; k < T; ++k)
@@ -803,11 +826,10 @@ __global__ __launch_bounds__(NT) void scale_kernel_patch(Lanes lanes, unsigned e
                 lg11 = dual_upd(lg11, l.u1x, l.ng1);
                 lg21 = dual_upd(lg21, l.u2x, l.ng2);
             }
-            par ^= 1u;
 #ifdef RVDD_STAMPS
             { const unsigned long long ts3 = wall_clock64(); st_a += ts1 - ts0; st_w += ts2 - ts1; st_d += ts3 - ts2; }
 #endif
-            if (!(error > kEps * kEps) || n >= kMaxIter) break;
+            if (n >= kMaxIter) break;      // the reference's loop ends here whatever the error
         }
     }
 #pragma unroll
@@ -1044,9 +1066,9 @@ static hipError_t tvl1_add_lane(Tvl1Workspace* w) {
     A(&L.xch.u, 8 * n0);                                      // 2 parities of 16-byte records (scale_kernel: 4 planes of floats)
     if (err == hipSuccess) err = hipMemset(L.xch.u, 0, 8 * n0 * sizeof(float));      // tag 0: no launch's
     words64 = nullptr;
-    A(&words64, 2 * kSumRecs * 4);                            // 2 parities of 16-byte sum records
+    A(&words64, kSumSlots * kSumRecs * 4);                    // kSumSlots publications of 16-byte sum records
     L.xch.acc = reinterpret_cast<unsigned long long*>(words64);
-    if (err == hipSuccess) err = hipMemset(words64, 0, 2 * kSumRecs * 16);
+    if (err == hipSuccess) err = hipMemset(words64, 0, kSumSlots * kSumRecs * 16);
     A(&L.mm, 4);
     float* words = nullptr;
     A(&words, 8);                                    // 4 control ints + the barrier counter
@@ -1178,7 +1200,7 @@ static hipError_t tvl1_run_lanes(Tvl1Workspace* w, const float* I0, const float*
                     w->epoch = 1;
                     for (Tvl1LaneBufs& L : w->lanes) {
                         CK(hipMemsetAsync(L.xch.u, 0, 8 * (size_t)n0 * sizeof(float), st));
-                        CK(hipMemsetAsync(L.xch.acc, 0, 2 * kSumRecs * 16, st));
+                        CK(hipMemsetAsync(L.xch.acc, 0, kSumSlots * kSumRecs * 16, st));
                     }
                 }
                 lanes.gp = pg;

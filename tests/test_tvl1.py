@@ -122,6 +122,33 @@ def test_hip_scale_kernels_agree(name):
 
 
 @pytest.mark.gpu
+def test_hip_scale_kernels_agree_at_the_flow_size_of_720p():
+    """640x360 pairs (the raw size of a 1280x720 frame), three of them in one batch call: the launch of two pairs takes
+    the patch kernel's two-blocks-per-CU form (64x16 patches, 460 blocks), the single one its one-block-per-CU form;
+    against the barrier kernel (RVDD_TVL1_PATCH=0): same bits, same iteration counts -- the convergence test that the
+    patch kernel evaluates one iteration late (and whose speculative update it then drops) stops where the reference's does."""
+    from rvdd_release_amd import synth
+    from rvdd_release_amd.util._ops import ops_runtime
+    rt = ops_runtime(0)
+    seq = synth.make_sequence(4, 720, 1280, iso=3200, seed=5, device="cuda")
+    gray = seq.raw.mean(dim=1).contiguous()
+    a, b = gray[1:4].contiguous(), gray[0:3].contiguous()
+    flows, iters = rt.tvl1flow_batch(a, b, want_iterations=True)
+    single = rt.tvl1flow(a[0], b[0], want_iterations=True)
+    assert single[1] == iters[0] and torch.equal(single[0], flows[0])
+    small = torch.rand(20, 24, device="cuda")
+    os.environ["RVDD_TVL1_PATCH"] = "0"
+    try:
+        rt.tvl1flow(small, small)                    # another size: the workspace (and its mode) is rebuilt
+        flows_bar, iters_bar = rt.tvl1flow_batch(a, b, want_iterations=True)
+    finally:
+        del os.environ["RVDD_TVL1_PATCH"]
+        rt.tvl1flow(small, small)
+    assert list(iters) == list(iters_bar) and min(iters) > 100
+    assert torch.equal(flows, flows_bar)
+
+
+@pytest.mark.gpu
 def test_hip_flow_batch_equals_single_flows():
     """rvdd_tvl1flow_batch: two pairs per cooperative launch, an odd count, pairs that converge after different
     numbers of iterations -- every flow bit-identical to the single-pair call."""
