@@ -348,7 +348,8 @@ struct Xch {
 // never talk to each other -- each has its own buffers, barrier counter and iteration count -- they only fill the
 // CUs that a single pair leaves idle between its memory round trips (a second cooperative kernel on another stream
 // does not: cooperative launches are serialised).
-constexpr int kMaxLanes = 2;
+constexpr int kMaxLanes = 8;        // pairs per launch set (the patch kernel; as many of them per scale as are resident together)
+constexpr int kBarrierLanes = 2;    // pairs per launch of the kernels with a grid barrier
 struct Lane {
     Scale s;
     IterBufs b;
@@ -1158,14 +1159,30 @@ static hipError_t tvl1_run_lanes(Tvl1Workspace* w, const float* I0, const float*
         CK(hipMemsetAsync(top.u1, 0, (size_t)top.nx * top.ny * sizeof(float), st));
         CK(hipMemsetAsync(top.u2, 0, (size_t)top.nx * top.ny * sizeof(float), st));
     }
-    for (int s = w->nscales - 1; s >= 0; --s) {
+    // Patch kernel forms: patches of 64 x rows pixels, one 512-thread block per CU (8, 16, 32 rows) or two 256-thread blocks
+    // per CU (16 rows: as many pixels per CU as 32 rows in one block, but one block computes while the other waits for its ring).
+    struct Form { int t, n, rows, per_cu; };
+    static const Form forms[] = {{1, 512, 8, 1}, {2, 512, 16, 1}, {4, 256, 16, 2}, {4, 512, 32, 1}};
+    static const int two = [] { const char* e = std::getenv("RVDD_TVL1_TWO"); return e ? std::atoi(e) : 1; }();
+    // the first form (smallest patches) whose blocks are all resident with `cnt` pairs in the launch; null if none
+    auto patch_form = [&](const Scale& ref, int cnt, int* blocks) -> const Form* {
+        if (!w->patch || w->force_mem) return nullptr;
+        for (const Form& f : forms) {
+            if (f.per_cu == 2 && !two) continue;
+            const int g = ((ref.nx + 63) / 64) * ((ref.ny + f.rows - 1) / f.rows);
+            if ((long)cnt * g <= (long)w->cus * f.per_cu && g <= kSumRecs) { *blocks = g; return &f; }
+        }
+        return nullptr;
+    };
+    // one scale (gradient, 5 warps x <= 300 iterations) of the pairs q0 .. q0 + cnt - 1 in one cooperative launch
+    auto launch_scale = [&](int s, int q0, int cnt) -> hipError_t {
         Lanes lanes{};
         lanes.abort_word = w->abort_word;
-        for (int q = 0; q < np; ++q) {
-            Tvl1LaneBufs& L = w->lanes[q];
+        for (int q = 0; q < cnt; ++q) {
+            Tvl1LaneBufs& L = w->lanes[q0 + q];
             Scale sc = L.sc[s];
             if (s == 0) {        // the finest flow is the caller's buffer
-                float* uq = u + (size_t)q * 2 * n0;
+                float* uq = u + (size_t)(q0 + q) * 2 * n0;
                 CK(hipMemcpyAsync(uq, sc.u1, (size_t)n0 * sizeof(float), hipMemcpyDeviceToDevice, st));
                 CK(hipMemcpyAsync(uq + n0, sc.u2, (size_t)n0 * sizeof(float), hipMemcpyDeviceToDevice, st));
                 sc.u1 = uq;
@@ -1174,74 +1191,68 @@ static hipError_t tvl1_run_lanes(Tvl1Workspace* w, const float* I0, const float*
             lanes.l[q] = Lane{sc, L.it, L.xch, L.bar, L.ctl};
             CK(hipMemsetAsync(L.bar, 0, sizeof(unsigned), st));
         }
-        // the whole scale (gradient, 5 warps x <= 300 iterations) of every lane in one cooperative launch
         const Scale& ref = w->lanes[0].sc[s];
         const int ntiles = (ref.nx * ref.ny + 255) / 256;
-        // register-state kernel: the smallest slot count T such that a lane has at most one block per CU and all
-        // lanes together are co-resident
-        int slots = 0, gp = 0;
-        // The patch kernel (no grid barrier per iteration) where every lane's 64 x 8T patches get a CU each; T as small as fits.
-        bool patched = false;
-        if (w->patch && !w->force_mem) {
-            // smallest patch height whose blocks are all resident: one 512-thread block per CU (8, 16, 32 rows), or two
-            // 256-thread blocks per CU (16 rows: as many pixels per CU as 32 rows in one block, but one block computes while
-            // the other waits for its ring)
-            static const int two = [] { const char* e = std::getenv("RVDD_TVL1_TWO"); return e ? std::atoi(e) : 1; }();
-            int pt = 0, pg = 0, pn = 512;
-            struct Form { int t, n, rows, per_cu; };
-            static const Form forms[] = {{1, 512, 8, 1}, {2, 512, 16, 1}, {4, 256, 16, 2}, {4, 512, 32, 1}};
-            for (const Form& f : forms) {
-                if (f.per_cu == 2 && !two) continue;
-                const int g = ((ref.nx + 63) / 64) * ((ref.ny + f.rows - 1) / f.rows);
-                if ((long)np * g <= (long)w->cus * f.per_cu && g <= kSumRecs) { pt = f.t; pn = f.n; pg = g; break; }
-            }
-            if (pt) {
-                if (++w->epoch >= (1u << 21)) {       // tags repeat after 2^21 launches: start over from clean records
-                    w->epoch = 1;
-                    for (Tvl1LaneBufs& L : w->lanes) {
-                        CK(hipMemsetAsync(L.xch.u, 0, 8 * (size_t)n0 * sizeof(float), st));
-                        CK(hipMemsetAsync(L.xch.acc, 0, kSumSlots * kSumRecs * 16, st));
-                    }
+        int pg = 0;
+        if (const Form* f = patch_form(ref, cnt, &pg)) {
+            if (++w->epoch >= (1u << 21)) {       // tags repeat after 2^21 launches: start over from clean records
+                w->epoch = 1;
+                for (Tvl1LaneBufs& L : w->lanes) {
+                    CK(hipMemsetAsync(L.xch.u, 0, 8 * (size_t)n0 * sizeof(float), st));
+                    CK(hipMemsetAsync(L.xch.acc, 0, kSumSlots * kSumRecs * 16, st));
                 }
-                lanes.gp = pg;
-                unsigned epoch = w->epoch;
-                void* args[] = {&lanes, &epoch};
-                CK(hipLaunchCooperativeKernel(reinterpret_cast<const void*>(patch_kernel_for(pt, pn)), dim3(pg * np), dim3(pn), args, 0, st));
-                patched = true;
             }
+            lanes.gp = pg;
+            unsigned epoch = w->epoch;
+            void* args[] = {&lanes, &epoch};
+            return hipLaunchCooperativeKernel(reinterpret_cast<const void*>(patch_kernel_for(f->t, f->n)), dim3(pg * cnt), dim3(f->n), args, 0, st);
         }
-        // With several lanes prefer the smallest T that gives every block of every lane a CU of its own (np * g <= CUs)
-        // over two blocks per CU: two 640x360 pairs then take T = 8 on 113 CUs each instead of T = 4 on all CUs twice --
-        // 2.44 instead of 2.70 ms per flow, same bits (round 3; RVDD_TVL1_SPREAD=0 restores the old choice).
+        // register-state kernel with a grid barrier per iteration: the smallest slot count T such that a lane has at most one
+        // block per CU and all lanes together are co-resident.  With several lanes prefer the smallest T that gives every block
+        // of every lane a CU of its own (cnt * g <= CUs) over two blocks per CU: two 640x360 pairs then take T = 8 on 113 CUs
+        // each instead of T = 4 on all CUs twice -- 2.44 instead of 2.70 ms per flow, same bits (round 3; RVDD_TVL1_SPREAD=0
+        // restores the old choice).
+        int slots = 0, gp = 0;
         static const bool spread = [] { const char* e = std::getenv("RVDD_TVL1_SPREAD"); return !e || std::atoi(e) != 0; }();
-        if (!w->force_mem && !patched) {
-            if (spread && np > 1)
+        if (!w->force_mem) {
+            if (spread && cnt > 1)
                 for (int c : kTileSlots) {
                     const int g = (ntiles + c - 1) / c;
-                    if ((long)np * g <= (long)w->cus) { slots = c; gp = g; break; }
+                    if ((long)cnt * g <= (long)w->cus) { slots = c; gp = g; break; }
                 }
             if (!slots)
                 for (int c : kTileSlots) {
                     const int g = (ntiles + c - 1) / c;
                     int per_cu = 0;
                     CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, scale_kernel_for(c), 256, 0));
-                    if (g <= w->cus && (long)np * g <= (long)w->cus * per_cu) { slots = c; gp = g; break; }
+                    if (g <= w->cus && (long)cnt * g <= (long)w->cus * per_cu) { slots = c; gp = g; break; }
                 }
         }
-        if (patched) {
-        } else if (slots) {
+        if (slots) {
             lanes.gp = gp;
             void* args[] = {&lanes};
-            CK(hipLaunchCooperativeKernel(reinterpret_cast<const void*>(scale_kernel_for(slots)), dim3(gp * np), dim3(256), args, 0, st));
-        } else {
-            if (!w->state.wx) return hipErrorInvalidValue;       // lanes of this size were not provisioned at allocation
-            lanes.gp = ntiles < w->cus ? ntiles : w->cus;
-            for (int q = 0; q < np; ++q) {                        // one lane per launch
-                Lanes one = lanes;
-                one.l[0] = lanes.l[q];
-                void* args[] = {&one, &w->state};
-                CK(hipLaunchCooperativeKernel(reinterpret_cast<const void*>(scale_kernel_mem), dim3(lanes.gp), dim3(256), args, 0, st));
-            }
+            return hipLaunchCooperativeKernel(reinterpret_cast<const void*>(scale_kernel_for(slots)), dim3(gp * cnt), dim3(256), args, 0, st);
+        }
+        if (!w->state.wx) return hipErrorInvalidValue;       // lanes of this size were not provisioned at allocation
+        lanes.gp = ntiles < w->cus ? ntiles : w->cus;
+        for (int q = 0; q < cnt; ++q) {                        // one lane per launch
+            Lanes one = lanes;
+            one.l[0] = lanes.l[q];
+            void* args[] = {&one, &w->state};
+            CK(hipLaunchCooperativeKernel(reinterpret_cast<const void*>(scale_kernel_mem), dim3(lanes.gp), dim3(256), args, 0, st));
+        }
+        return hipSuccess;
+    };
+    for (int s = w->nscales - 1; s >= 0; --s) {
+        // as many pairs per launch as are resident together: all of them at the coarse scales (an iteration there is the
+        // latency of one exchange whatever the number of pairs), two at 640x360
+        const Scale& ref = w->lanes[0].sc[s];
+        for (int q0 = 0; q0 < np;) {
+            int cnt = np - q0, pg = 0;
+            while (cnt > kBarrierLanes && !patch_form(ref, cnt, &pg)) --cnt;
+            if (cnt > kBarrierLanes && !patch_form(ref, cnt, &pg)) cnt = kBarrierLanes;
+            CK(launch_scale(s, q0, cnt));
+            q0 += cnt;
         }
         if (s == 0) break;
         // zoom_in + rescale by 1/zfactor (zoom.c:85-108, tvl1flow_lib.c:424-433)
