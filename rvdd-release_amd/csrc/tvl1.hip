@@ -27,6 +27,7 @@ namespace {
 
 constexpr float kTau = 0.25f, kLambda = 0.15f, kTheta = 0.3f, kZoom = 0.5f, kEps = 0.01f;
 constexpr int kWarps = 5, kMaxIter = 300, kMaxScales = 100;
+constexpr int kCtlWords = 4 + kMaxScales;      // per pair: control words, then a grid barrier counter per scale
 constexpr double kPresmooth = 0.8, kZoomSigma0 = 0.6;
 constexpr float kGradIsZero = 1e-10f;
 
@@ -71,11 +72,14 @@ struct Bicubic {       // the 4x4 stencil of bicubic_interpolation_at (:133-231)
 
 // zoom_out / zoom_in resampling (zoom.c:63-74, 98-107): out(i1,j1) = in at (j1/fx, i1/fy), times mul
 // The images of a pair (I0/I1, or the two flow components) go through every pre- and post-processing kernel together:
-// blockIdx.z picks the image.
-struct Two {
-    const float* in[2];
-    float* out[2];
+// blockIdx.z picks the image; the pairs of a batch call share the launches too (2 x kMaxLanes images).
+constexpr int kMaxLanes = 8;        // pairs per launch set (the patch kernel; as many of them per scale as are resident together)
+constexpr int kBarrierLanes = 2;    // pairs per launch of the kernels with a grid barrier
+struct Imgs {
+    const float* in[2 * kMaxLanes];
+    float* out[2 * kMaxLanes];
 };
+using Two = Imgs;
 __global__ void resample_kernel(Two io, int nx, int ny, int nxx, int nyy, float fx, float fy, float mul) {
     const float* __restrict__ in = io.in[blockIdx.z];
     float* __restrict__ out = io.out[blockIdx.z];
@@ -119,8 +123,33 @@ __device__ __forceinline__ void centered_gradient_px(const float* __restrict__ I
     dy[p] = 0.5f * (d - u);
 }
 
+// per-pair words of a batch call, pair = blockIdx.y
+struct PairWords {
+    float* mm[kMaxLanes];          // min / max keys
+    int* ctl[kMaxLanes];           // control words, then the grid barrier counters of the scales
+    float* top[2 * kMaxLanes];     // the coarsest scale's flow
+};
+// start of a run: min / max keys at +-FLT_MAX, control words and barrier counters cleared, zero flow at the coarsest scale
+// (tvl1flow_lib.c:388-391) -- one launch instead of five fills per pair
+__global__ void init_kernel(PairWords pw, int nwords, int ntop) {
+    const int q = blockIdx.y;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < ntop; i += gridDim.x * blockDim.x) {
+        pw.top[2 * q][i] = 0.f;
+        pw.top[2 * q + 1][i] = 0.f;
+    }
+    if (blockIdx.x == 0) {
+        if (threadIdx.x < nwords) pw.ctl[q][threadIdx.x] = 0;
+        if (threadIdx.x == 0) {
+            reinterpret_cast<int*>(pw.mm[q])[0] = 0x7f7fffff;       // order-preserving keys of +FLT_MAX / -FLT_MAX
+            reinterpret_cast<int*>(pw.mm[q])[1] = (int)0x80000000;
+        }
+    }
+}
 // min / max of both images (image_normalization, tvl1flow_lib.c:300-333)
-__global__ void minmax_kernel(const float* __restrict__ a, const float* __restrict__ b, int n, float* __restrict__ mm) {
+__global__ void minmax_kernel(Imgs io, int n, PairWords pw) {
+    const float* __restrict__ a = io.in[2 * blockIdx.y];
+    const float* __restrict__ b = io.in[2 * blockIdx.y + 1];
+    float* __restrict__ mm = pw.mm[blockIdx.y];
     float lo = 3.4e38f, hi = -3.4e38f;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         lo = fminf(lo, fminf(a[i], b[i]));
@@ -137,8 +166,12 @@ __global__ void minmax_kernel(const float* __restrict__ a, const float* __restri
         atomicMax(reinterpret_cast<int*>(mm) + 1, key(hi));
     }
 }
-__global__ void normalize_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ an,
-                                 float* __restrict__ bn, int n, const float* __restrict__ mm) {
+__global__ void normalize_kernel(Imgs io, int n, PairWords pw) {
+    const float* __restrict__ a = io.in[2 * blockIdx.y];
+    const float* __restrict__ b = io.in[2 * blockIdx.y + 1];
+    float* __restrict__ an = io.out[2 * blockIdx.y];
+    float* __restrict__ bn = io.out[2 * blockIdx.y + 1];
+    const float* __restrict__ mm = pw.mm[blockIdx.y];
     auto unkey = [](int i) { return __int_as_float(i >= 0 ? i : i ^ 0x7fffffff); };
     const float mn = unkey(reinterpret_cast<const int*>(mm)[0]), mx = unkey(reinterpret_cast<const int*>(mm)[1]);
     const float den = mx - mn;
@@ -296,9 +329,9 @@ __device__ __forceinline__ float dual_upd(float p, float grad, float ng) { retur
 // 640x360, against the test's threshold of 1e-4 per pixel).  A term above 128 (an update of more than 11 pixels
 // in one iteration) only has to keep the sum above the threshold, which 128 does.
 __device__ __forceinline__ int err_shift(int npix) { return 47 - (32 - __builtin_clz((unsigned)(npix > 1 ? npix - 1 : 1))); }
-__device__ __forceinline__ unsigned long long err_fix(float e, float mul) {
+__device__ __forceinline__ unsigned long long err_fix(float e, int shift) {
     const float c = e < 128.f ? e : 128.f;
-    return (unsigned long long)((double)c * (double)mul + 0.5);
+    return (unsigned long long)(__builtin_ldexp((double)c, shift) + 0.5);
 }
 __device__ __forceinline__ float err_value(unsigned long long sum, int shift, int npix) {
     return (float)(__builtin_ldexp((double)sum, -shift) / (double)npix);
@@ -348,8 +381,6 @@ struct Xch {
 // never talk to each other -- each has its own buffers, barrier counter and iteration count -- they only fill the
 // CUs that a single pair leaves idle between its memory round trips (a second cooperative kernel on another stream
 // does not: cooperative launches are serialised).
-constexpr int kMaxLanes = 8;        // pairs per launch set (the patch kernel; as many of them per scale as are resident together)
-constexpr int kBarrierLanes = 2;    // pairs per launch of the kernels with a grid barrier
 struct Lane {
     Scale s;
     IterBufs b;
@@ -395,7 +426,7 @@ __global__ __launch_bounds__(256) void scale_kernel(Lanes lanes) {
     const int nx = s.nx, ny = s.ny, npix = nx * ny;
     const int ntiles = (npix + 255) >> 8;
     const int tid = threadIdx.x;
-    const float emul = __builtin_ldexpf(1.f, err_shift(npix));
+    const int eshift = err_shift(npix);
     const unsigned S = (unsigned)npix * 4u, row = (unsigned)nx * 4u;
     const __amdgpu_buffer_rsrc_t ur = __builtin_amdgcn_make_buffer_rsrc((void*)x.u, 0, (int)(4u * S), 0x00020000);
     unsigned target = 0;
@@ -442,7 +473,7 @@ __global__ __launch_bounds__(256) void scale_kernel(Lanes lanes) {
                     const Edge ed{pj[k] == 0, pj[k] == nx - 1, pi[k] == 0, pi[k] == ny - 1};
                     e = err_fix(u_px(ed, u1[k], u2[k], wx[k], wy[k], grad[k], rho_c[k], p11[k], p12[k], p21[k], p22[k], l11[k], t12[k],
                                      l21[k], t22[k]),
-                                emul);
+                                eshift);
                     bst(ur, po[k], so1, u1[k]);
                     bst(ur, po[k], so2, u2[k]);
                 }
@@ -575,6 +606,9 @@ __global__ __launch_bounds__(NT) void scale_kernel_patch(Lanes lanes, unsigned e
     __shared__ unsigned long long red[NW];
     __shared__ unsigned long long sh_sum;
     __shared__ int sh_ok;
+    // (lanes own consecutive block numbers: dealt out in turn, every lane gets its share of the blocks that came second to
+    // their CU and lose its issue slots to the older block, and every lane runs at their pace -- 6.5 against 4.3 / 5.6 us
+    // per iteration of two 640x360 pairs)
     const int lane_id = blockIdx.x / lanes.gp, gb = blockIdx.x - lane_id * lanes.gp;
     const unsigned gp = (unsigned)lanes.gp;
     const Scale s = lanes.l[lane_id].s;
@@ -589,7 +623,6 @@ __global__ __launch_bounds__(NT) void scale_kernel_patch(Lanes lanes, unsigned e
     const int py = gb / npx, px = gb - py * npx;
     const int x0 = px * PW, y0 = py * PH;
     const int shift = err_shift(npix);
-    const float emul = __builtin_ldexpf(1.f, shift);
     const __amdgpu_buffer_rsrc_t ur = __builtin_amdgcn_make_buffer_rsrc((void*)x.u, 0, (int)(32u * (unsigned)npix), 0x00020000);
     const __amdgpu_buffer_rsrc_t sr = __builtin_amdgcn_make_buffer_rsrc((void*)x.acc, 0, kSumSlots * kSumRecs * 16, 0x00020000);
     const unsigned S = 16u * (unsigned)npix;      // one parity of records
@@ -686,7 +719,7 @@ __global__ __launch_bounds__(NT) void scale_kernel_patch(Lanes lanes, unsigned e
                     const Edge ed{gx == 0, gx == nx - 1, gy0 + k == 0, gy0 + k == ny - 1};
                     esum += err_fix(u_px(ed, u1[k], u2[k], wx[k], wy[k], grad[k], rho_c[k], p11[k], p12[k], p21[k], p22[k], l11, up12, l21,
                                          up22),
-                                    emul);
+                                    shift);
                 }
                 map[par][wv * T + k + 1][lx + 1] = float2{u1[k], u2[k]};
             }
@@ -871,7 +904,7 @@ __global__ __launch_bounds__(256) void scale_kernel_mem(Lanes lanes, StateBufs s
     const int ntiles = (npix + 255) >> 8;
     const int tid = threadIdx.x;
     unsigned long long* partial = x.partial;
-    const float emul = __builtin_ldexpf(1.f, err_shift(npix));
+    const int eshift = err_shift(npix);
     unsigned target = 0;
     int total = 0;
 #define FOR_TILES(...)                                           \
@@ -902,7 +935,7 @@ __global__ __launch_bounds__(256) void scale_kernel_mem(Lanes lanes, StateBufs s
                     const Edge ed{j == 0, j == nx - 1, i == 0, i == ny - 1};
                     e = err_fix(u_px(ed, u1, u2, st.wx[p], st.wy[p], st.grad[p], st.rho_c[p], b.p11[p], b.p12[p], b.p21[p], b.p22[p], l11, t12,
                                      l21, t22),
-                                emul);
+                                eshift);
                     stc(s.u1 + p, u1);
                     stc(s.u2 + p, u2);
                 }
@@ -1072,7 +1105,7 @@ static hipError_t tvl1_add_lane(Tvl1Workspace* w) {
     if (err == hipSuccess) err = hipMemset(words64, 0, kSumSlots * kSumRecs * 16);
     A(&L.mm, 4);
     float* words = nullptr;
-    A(&words, 8);                                    // 4 control ints + the barrier counter
+    A(&words, kCtlWords);                            // 4 control ints + one grid barrier counter per scale
     L.ctl = reinterpret_cast<int*>(words);
     L.bar = reinterpret_cast<unsigned*>(words) + 4;
     if (err == hipSuccess) w->lanes.push_back(L);
@@ -1129,35 +1162,62 @@ static hipError_t tvl1_run_lanes(Tvl1Workspace* w, const float* I0, const float*
     while ((int)w->lanes.size() < np) CK(tvl1_add_lane(w));
     if (first) CK(hipMemsetAsync(w->abort_word, 0, sizeof(int), st));
     const double zsigma = (double)(float)(kZoomSigma0 * std::sqrt(1.0 / ((double)kZoom * (double)kZoom) - 1.0));
-    for (int q = 0; q < np; ++q) {
-        Tvl1LaneBufs& L = w->lanes[q];
-        const float *a0 = I0 + (size_t)q * n0, *a1 = I1 + (size_t)q * n0;
-        // normalisation to [0,255] and pre-smoothing
-        // order-preserving keys of +FLT_MAX / -FLT_MAX (two fills: a copy from pageable host memory is not asynchronous)
-        CK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(L.mm), 0x7f7fffff, 1, st));
-        CK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(reinterpret_cast<int*>(L.mm) + 1), (int)0x80000000, 1, st));
-        CK(hipMemsetAsync(L.ctl, 0, 8 * sizeof(int), st));
-        hipLaunchKernelGGL(minmax_kernel, dim3(256), dim3(256), 0, st, a0, a1, n0, L.mm);
-        hipLaunchKernelGGL(normalize_kernel, dim3((n0 + 255) / 256), dim3(256), 0, st, a0, a1, L.tmp, L.tmp2, n0, L.mm);
-        // both images of the pair per launch; scratch of the separable Gaussian: I1w and I1x (free until the scale kernels)
-        auto grid3 = [](int gx, int gy) { return dim3((gx + 255) / 256, gy, 2); };
-        auto gauss2 = [&](const float* in0, const float* in1, float* out0, float* out1, int gx, int gy, double sigma) {
+    // Pre-processing of all pairs together (blockIdx.z / .y = image / pair): normalisation to [0,255], pre-smoothing, pyramid.
+    // The finest flow is the caller's buffer (fin): u(ny*nx) then v(ny*nx) per pair.
+    auto fin = [&](int q, int c) { return u + ((size_t)q * 2 + c) * n0; };
+    auto u_of = [&](int q, int s, int c) { return s == 0 ? fin(q, c) : (c ? w->lanes[q].sc[s].u2 : w->lanes[q].sc[s].u1); };
+    {
+        PairWords pw{};
+        Imgs raw{};                // the caller's images -> tmp / tmp2 (normalised)
+        const Scale& top = w->lanes[0].sc[w->nscales - 1];
+        for (int q = 0; q < np; ++q) {
+            Tvl1LaneBufs& L = w->lanes[q];
+            pw.mm[q] = L.mm;
+            pw.ctl[q] = L.ctl;
+            pw.top[2 * q] = u_of(q, w->nscales - 1, 0);
+            pw.top[2 * q + 1] = u_of(q, w->nscales - 1, 1);
+            raw.in[2 * q] = I0 + (size_t)q * n0;
+            raw.in[2 * q + 1] = I1 + (size_t)q * n0;
+            raw.out[2 * q] = L.tmp;
+            raw.out[2 * q + 1] = L.tmp2;
+        }
+        const int ntop = top.nx * top.ny;
+        hipLaunchKernelGGL(init_kernel, dim3((ntop + 255) / 256 < 64 ? (ntop + 255) / 256 : 64, np), dim3(256), 0, st, pw, kCtlWords, ntop);
+        hipLaunchKernelGGL(minmax_kernel, dim3(256, np), dim3(256), 0, st, raw, n0, pw);
+        hipLaunchKernelGGL(normalize_kernel, dim3((n0 + 255) / 256, np), dim3(256), 0, st, raw, n0, pw);
+        // separable Gaussian of every image of the batch: in -> scratch (I1w / I1x, free until the scale kernels) -> out
+        auto grid3 = [&](int gx, int gy) { return dim3((gx + 255) / 256, gy, 2 * np); };
+        auto gauss2 = [&](auto in_of, auto out_of, int gx, int gy, double sigma) {
             const GaussK k = make_gauss(sigma);
-            hipLaunchKernelGGL(gauss_kernel, grid3(gx, gy), dim3(256), 0, st, Two{{in0, in1}, {L.it.I1w, L.it.I1x}}, gx, gy, k, 0);
-            hipLaunchKernelGGL(gauss_kernel, grid3(gx, gy), dim3(256), 0, st, Two{{L.it.I1w, L.it.I1x}, {out0, out1}}, gx, gy, k, 1);
+            Imgs h{}, v{};
+            for (int q = 0; q < np; ++q)
+                for (int c = 0; c < 2; ++c) {
+                    Tvl1LaneBufs& L = w->lanes[q];
+                    float* scratch = c ? L.it.I1x : L.it.I1w;
+                    h.in[2 * q + c] = in_of(L, c);
+                    h.out[2 * q + c] = scratch;
+                    v.in[2 * q + c] = scratch;
+                    v.out[2 * q + c] = out_of(L, c);
+                }
+            hipLaunchKernelGGL(gauss_kernel, grid3(gx, gy), dim3(256), 0, st, h, gx, gy, k, 0);
+            hipLaunchKernelGGL(gauss_kernel, grid3(gx, gy), dim3(256), 0, st, v, gx, gy, k, 1);
         };
-        gauss2(L.tmp, L.tmp2, L.sc[0].I0, L.sc[0].I1, nx, ny, kPresmooth);
+        auto tmp_of = [](Tvl1LaneBufs& L, int c) { return c ? L.tmp2 : L.tmp; };
+        gauss2(tmp_of, [](Tvl1LaneBufs& L, int c) { return c ? L.sc[0].I1 : L.sc[0].I0; }, nx, ny, kPresmooth);
         // pyramid (zoom_out, zoom.c:41-78)
         for (int s = 1; s < w->nscales; ++s) {
-            const Scale& a = L.sc[s - 1];
-            const Scale& b = L.sc[s];
-            gauss2(a.I0, a.I1, L.tmp, L.tmp2, a.nx, a.ny, zsigma);
-            hipLaunchKernelGGL(resample_kernel, grid3(b.nx, b.ny), dim3(256), 0, st, Two{{L.tmp, L.tmp2}, {b.I0, b.I1}}, a.nx, a.ny,
-                               b.nx, b.ny, kZoom, kZoom, 1.f);
+            const Scale& a = w->lanes[0].sc[s - 1];
+            const Scale& b = w->lanes[0].sc[s];
+            gauss2([s](Tvl1LaneBufs& L, int c) { return c ? L.sc[s - 1].I1 : L.sc[s - 1].I0; }, tmp_of, a.nx, a.ny, zsigma);
+            Imgs z{};
+            for (int q = 0; q < np; ++q)
+                for (int c = 0; c < 2; ++c) {
+                    Tvl1LaneBufs& L = w->lanes[q];
+                    z.in[2 * q + c] = tmp_of(L, c);
+                    z.out[2 * q + c] = c ? L.sc[s].I1 : L.sc[s].I0;
+                }
+            hipLaunchKernelGGL(resample_kernel, grid3(b.nx, b.ny), dim3(256), 0, st, z, a.nx, a.ny, b.nx, b.ny, kZoom, kZoom, 1.f);
         }
-        const Scale& top = L.sc[w->nscales - 1];
-        CK(hipMemsetAsync(top.u1, 0, (size_t)top.nx * top.ny * sizeof(float), st));
-        CK(hipMemsetAsync(top.u2, 0, (size_t)top.nx * top.ny * sizeof(float), st));
     }
     // Patch kernel forms: patches of 64 x rows pixels, one 512-thread block per CU (8, 16, 32 rows) or two 256-thread blocks
     // per CU (16 rows: as many pixels per CU as 32 rows in one block, but one block computes while the other waits for its ring).
@@ -1181,15 +1241,9 @@ static hipError_t tvl1_run_lanes(Tvl1Workspace* w, const float* I0, const float*
         for (int q = 0; q < cnt; ++q) {
             Tvl1LaneBufs& L = w->lanes[q0 + q];
             Scale sc = L.sc[s];
-            if (s == 0) {        // the finest flow is the caller's buffer
-                float* uq = u + (size_t)(q0 + q) * 2 * n0;
-                CK(hipMemcpyAsync(uq, sc.u1, (size_t)n0 * sizeof(float), hipMemcpyDeviceToDevice, st));
-                CK(hipMemcpyAsync(uq + n0, sc.u2, (size_t)n0 * sizeof(float), hipMemcpyDeviceToDevice, st));
-                sc.u1 = uq;
-                sc.u2 = uq + n0;
-            }
-            lanes.l[q] = Lane{sc, L.it, L.xch, L.bar, L.ctl};
-            CK(hipMemsetAsync(L.bar, 0, sizeof(unsigned), st));
+            sc.u1 = u_of(q0 + q, s, 0);
+            sc.u2 = u_of(q0 + q, s, 1);
+            lanes.l[q] = Lane{sc, L.it, L.xch, L.bar + s, L.ctl};      // a barrier counter per scale, cleared by init_kernel
         }
         const Scale& ref = w->lanes[0].sc[s];
         const int ntiles = (ref.nx * ref.ny + 255) / 256;
@@ -1252,16 +1306,38 @@ static hipError_t tvl1_run_lanes(Tvl1Workspace* w, const float* I0, const float*
             while (cnt > kBarrierLanes && !patch_form(ref, cnt, &pg)) --cnt;
             if (cnt > kBarrierLanes && !patch_form(ref, cnt, &pg)) cnt = kBarrierLanes;
             CK(launch_scale(s, q0, cnt));
+#ifdef RVDD_STAMPS
+            if (const char* e = std::getenv("RVDD_TVL1_STAMPS"); e && e[0] == '2') {      // every launch: first block of each lane
+                static unsigned long long hs[512][8];
+                CK(hipStreamSynchronize(st));
+                CK(hipMemcpyFromSymbol(hs, HIP_SYMBOL(g_tvl1_stamps), sizeof hs));
+                int pgx = 0;
+                const Form* f = patch_form(ref, cnt, &pgx);
+                std::fprintf(stderr, "tvl1 scale %d (%dx%d) lanes %d form T=%d/%d blocks %d:", s, ref.nx, ref.ny, cnt, f ? f->t : 0, f ? f->n : 0, pgx);
+                for (int q = 0; q < cnt && f; ++q) {
+                    const unsigned long long* o = hs[q * pgx < 512 ? q * pgx : 0];
+                    std::fprintf(stderr, " [%llu it, %.1f us/it: u %.1f w %.1f d %.1f, kernel %.0f us]", o[0], o[0] ? (o[1] + o[2] + o[3]) / 100.0 / o[0] : 0.0,
+                                 o[0] ? o[1] / 100.0 / o[0] : 0.0, o[0] ? o[2] / 100.0 / o[0] : 0.0, o[0] ? o[3] / 100.0 / o[0] : 0.0, o[6] / 100.0);
+                }
+                std::fprintf(stderr, "\n");
+            }
+#endif
             q0 += cnt;
         }
         if (s == 0) break;
         // zoom_in + rescale by 1/zfactor (zoom.c:85-108, tvl1flow_lib.c:424-433)
-        for (int q = 0; q < np; ++q) {
-            const Scale& sc = w->lanes[q].sc[s];
-            const Scale& f = w->lanes[q].sc[s - 1];
+        {
+            const Scale& sc = w->lanes[0].sc[s];
+            const Scale& f = w->lanes[0].sc[s - 1];
             const float fx = (float)f.nx / sc.nx, fy = (float)f.ny / sc.ny;
-            hipLaunchKernelGGL(resample_kernel, dim3((f.nx + 255) / 256, f.ny, 2), dim3(256), 0, st, Two{{sc.u1, sc.u2}, {f.u1, f.u2}},
-                               sc.nx, sc.ny, f.nx, f.ny, fx, fy, 1.0f / kZoom);
+            Imgs z{};
+            for (int q = 0; q < np; ++q)
+                for (int c = 0; c < 2; ++c) {
+                    z.in[2 * q + c] = u_of(q, s, c);
+                    z.out[2 * q + c] = u_of(q, s - 1, c);
+                }
+            hipLaunchKernelGGL(resample_kernel, dim3((f.nx + 255) / 256, f.ny, 2 * np), dim3(256), 0, st, z, sc.nx, sc.ny, f.nx, f.ny, fx, fy,
+                               1.0f / kZoom);
         }
     }
     if (finish) {   // always read the control words back: a grid barrier that gave up must not pass as a flow
