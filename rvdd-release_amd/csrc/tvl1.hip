@@ -970,10 +970,11 @@ constexpr int kTileSlots[] = {1, 2, 3, 4, 5, 6, 8};
 constexpr int kMaxSlots = 8;
 using ScaleKernel = void (*)(Lanes);
 using PatchKernel = void (*)(Lanes, unsigned);
-// (slots, threads): patches of 64 x 8, 64 x 16 (both forms), 64 x 32 pixels
+// (slots, threads): patches of 64 x 4 ... 64 x 32 pixels
 PatchKernel patch_kernel_for(int slots, int threads) {
     if (threads == 256) {
         switch (slots) {
+            case 1: return scale_kernel_patch<1, 256>;
             case 2: return scale_kernel_patch<2, 256>;
             case 4: return scale_kernel_patch<4, 256>;
         }
@@ -1222,7 +1223,7 @@ static hipError_t tvl1_run_lanes(Tvl1Workspace* w, const float* I0, const float*
     // Patch kernel forms: patches of 64 x rows pixels, one 512-thread block per CU (8, 16, 32 rows) or two 256-thread blocks
     // per CU (16 rows: as many pixels per CU as 32 rows in one block, but one block computes while the other waits for its ring).
     struct Form { int t, n, rows, per_cu; };
-    static const Form forms[] = {{1, 512, 8, 1}, {2, 512, 16, 1}, {4, 256, 16, 2}, {4, 512, 32, 1}};
+    static const Form forms[] = {{1, 256, 4, 2}, {1, 512, 8, 1}, {2, 256, 8, 2}, {2, 512, 16, 1}, {4, 256, 16, 2}, {4, 512, 32, 1}};
     static const int two = [] { const char* e = std::getenv("RVDD_TVL1_TWO"); return e ? std::atoi(e) : 1; }();
     // the first form (smallest patches) whose blocks are all resident with `cnt` pairs in the launch; null if none
     auto patch_form = [&](const Scale& ref, int cnt, int* blocks) -> const Form* {
