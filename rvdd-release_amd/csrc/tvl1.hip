@@ -700,6 +700,11 @@ __global__ __launch_bounds__(NT) void scale_kernel_patch(Lanes lanes, unsigned e
             ++pub;
             TS(ts0);
             const unsigned tagv = epoch * 2048u + pub, par = pub & 1u;
+            // Two blocks on a CU: the older one wins the issue slots whenever both compute, and the lane that holds the younger
+            // blocks sets the launch's pace.  Every other iteration the younger block is given the higher priority instead.
+            // (launches of two lanes, i.e. 640x360: with more lanes the pace is set by the lane with the most iterations, wherever it sits)
+            if (blockIdx.x >= 256u && par && gridDim.x == 2u * gp) __builtin_amdgcn_s_setprio(1);
+            else __builtin_amdgcn_s_setprio(0);
             unsigned long long esum = 0;
             float u1s[T], u2s[T];                // u of iteration n - 1: this update is undone if that one turns out to have converged
 #pragma unroll
