@@ -26,7 +26,7 @@ region -- `achieved` / `frac` are ALGORITHMIC flops, the executed-MF
 and HBM fractions sit beside them --, `cpu_baseline`: the CPU oracle
 (oracle/rvdd_oracle.py, a torch-CPU restatement of the reference's PyTorch path)
 timed on this host's cores on a bounded sample of the same workload, and
-`other_configs`: a short run of each of BASELINE.json's other configurations
+`other_configs`: a short run of each of BASELINE.json's other configurations (and of C2 with the flow recomputed online by TV-L1)
 (C3, C4, C5's per-GPU share, C1) after the timed region, so that the driver's
 record holds them too.
 """
@@ -206,7 +206,7 @@ def host_cpu_share():
     return info
 
 
-def quick_config(name, steps, dev_index):
+def quick_config(name, steps, dev_index, online_flow=False):
     """A short run of another configuration at its default batch: 1 warm-up step, `steps` timed steps (wall clock between
     device synchronisations), HIP events around every 3rd launch of its dominant kernel.  Inputs synthetic, resident in HBM."""
     import torch
@@ -228,7 +228,11 @@ def quick_config(name, steps, dev_index):
     def one():
         rt.reset()
         for t in range(1, T - fut):
-            rt.step(raw[t - 1] if t == 1 else None, raw[t], raw[t + 1] if fut else None, fprev[t],
+            fp = fprev[t]
+            if online_flow and t > 1:      # validate.py:16-38: TV-L1 from the re-mosaicked previous output to the current raw frame
+                moving = ((out[:, 1, 0::2, 0::2] + out[:, 2, 0::2, 1::2]) + (out[:, 0, 1::2, 0::2] + out[:, 1, 1::2, 1::2])) * 0.125 + 0.5
+                fp = rt.tvl1flow_batch((raw[t].mean(dim=1) * 0.5 + 0.5).contiguous(), moving.contiguous())
+            rt.step(raw[t - 1] if t == 1 else None, raw[t], raw[t + 1] if fut else None, fp,
                     fnext[t] if fut else None, out=out)
 
     one()
@@ -243,7 +247,9 @@ def quick_config(name, steps, dev_index):
     prof = [p for p in rt.profile_read() if p["launches"] and p["name"] == DOMINANT[arch]]
     rt.profile_enable(False)
     rt.close()
-    res = {"workload": f"{name}: {DESCR[name]}", "value": round(steps * n_out * B / el, 2), "unit": "frames/s",
+    res = {"workload": f"{name}: {DESCR[name]}" + (" -- with the flow towards the previous frame recomputed by TV-L1 from every previous "
+                                                  "output inside the timed loop (validate.py --val_flow_from_denoised)" if online_flow else ""),
+           "value": round(steps * n_out * B / el, 2), "unit": "frames/s",
            "ms_per_step": round(1e3 * el / steps, 3), "steps": steps, "warmup": 1, "sequences_in_lockstep": B,
            "output_frames_per_step": n_out * B, "finite": bool(torch.isfinite(out).all())}
     if prof:
@@ -485,6 +491,10 @@ def main():
                 other[name] = quick_config(name, args.other_steps, dev_index)
             except Exception as e:          # a failure here must not take the headline line with it
                 other[name] = {"error": f"{type(e).__name__}: {e}"}
+        try:
+            other["C2_online_flow"] = quick_config("C2", args.other_steps, dev_index, online_flow=True)
+        except Exception as e:
+            other["C2_online_flow"] = {"error": f"{type(e).__name__}: {e}"}
 
     # ---- CPU baseline: the oracle on this host's cores, bounded sample, sequence 0
     cpu = None
