@@ -1233,8 +1233,18 @@ static hipError_t tvl1_run_lanes(Tvl1Workspace* w, const float* I0, const float*
     // the first form (smallest patches) whose blocks are all resident with `cnt` pairs in the launch; null if none
     auto patch_form = [&](const Scale& ref, int cnt, int* blocks) -> const Form* {
         if (!w->patch || w->force_mem) return nullptr;
-        for (const Form& f : forms) {
+        for (size_t i = 0; i < sizeof forms / sizeof forms[0]; ++i) {
+            const Form& f = forms[i];
             if (f.per_cu == 2 && !two) continue;
+            // what the runtime will accept as co-resident (asked once per form): a form planned for two blocks per CU is only
+            // taken where two fit
+            static int occ[sizeof forms / sizeof forms[0]] = {};
+            if (!occ[i]) {
+                int per_cu = 0;
+                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, patch_kernel_for(f.t, f.n), f.n, 0) != hipSuccess) per_cu = 0;
+                occ[i] = per_cu > 0 ? per_cu : -1;
+            }
+            if (occ[i] < f.per_cu) continue;
             const int g = ((ref.nx + 63) / 64) * ((ref.ny + f.rows - 1) / f.rows);
             if ((long)cnt * g <= (long)w->cus * f.per_cu && g <= kSumRecs) { *blocks = g; return &f; }
         }
