@@ -1319,8 +1319,21 @@ static hipError_t tvl1_run_lanes(Tvl1Workspace* w, const float* I0, const float*
         const Scale& ref = w->lanes[0].sc[s];
         for (int q0 = 0; q0 < np;) {
             int cnt = np - q0, pg = 0;
-            while (cnt > kBarrierLanes && !patch_form(ref, cnt, &pg)) --cnt;
-            if (cnt > kBarrierLanes && !patch_form(ref, cnt, &pg)) cnt = kBarrierLanes;
+            while (cnt > 1 && !patch_form(ref, cnt, &pg)) --cnt;
+            // no patch form even for one pair (beyond 960x540): the kernels with a grid barrier, two pairs per launch where the
+            // register-state kernel holds both (launch_scale's search), else one
+            if (!patch_form(ref, cnt, &pg)) {
+                cnt = np - q0 < kBarrierLanes ? np - q0 : kBarrierLanes;
+                const int ntiles = (ref.nx * ref.ny + 255) / 256;
+                bool fits = false;
+                for (int c : kTileSlots) {
+                    const int g = (ntiles + c - 1) / c;
+                    int per_cu = 0;
+                    CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, scale_kernel_for(c), 256, 0));
+                    if (g <= w->cus && (long)cnt * g <= (long)w->cus * per_cu) { fits = true; break; }
+                }
+                if (!fits) cnt = 1;
+            }
             CK(launch_scale(s, q0, cnt));
 #ifdef RVDD_STAMPS
             if (const char* e = std::getenv("RVDD_TVL1_STAMPS"); e && e[0] == '2') {      // every launch: first block of each lane

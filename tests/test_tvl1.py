@@ -122,6 +122,30 @@ def test_hip_scale_kernels_agree(name):
 
 
 @pytest.mark.gpu
+def test_hip_scale_kernels_agree_at_the_flow_size_of_1080p():
+    """960x540 pairs (the raw size of a 1920x1080 frame), two in one batch call: one pair's 64x32 patches just fit the CUs
+    (255 blocks), two do not -- the batch runs its finest scale one pair per launch and the coarse scales together.  Same bits
+    and iteration counts as the barrier kernel."""
+    from rvdd_release_amd import synth
+    from rvdd_release_amd.util._ops import ops_runtime
+    rt = ops_runtime(0)
+    seq = synth.make_sequence(3, 1080, 1920, iso=3200, seed=6, device="cuda")
+    gray = seq.raw.mean(dim=1).contiguous()
+    a, b = gray[1:3].contiguous(), gray[0:2].contiguous()
+    flows, iters = rt.tvl1flow_batch(a, b, want_iterations=True)
+    small = torch.rand(20, 24, device="cuda")
+    os.environ["RVDD_TVL1_PATCH"] = "0"
+    try:
+        rt.tvl1flow(small, small)
+        flows_bar, iters_bar = rt.tvl1flow_batch(a, b, want_iterations=True)
+    finally:
+        del os.environ["RVDD_TVL1_PATCH"]
+        rt.tvl1flow(small, small)
+    assert list(iters) == list(iters_bar) and min(iters) > 100
+    assert torch.equal(flows, flows_bar)
+
+
+@pytest.mark.gpu
 def test_hip_scale_kernels_agree_at_the_flow_size_of_720p():
     """640x360 pairs (the raw size of a 1280x720 frame), three of them in one batch call: the launch of two pairs takes
     the patch kernel's two-blocks-per-CU form (64x16 patches, 460 blocks), the single one its one-block-per-CU form;
