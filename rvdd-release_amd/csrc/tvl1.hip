@@ -1114,6 +1114,9 @@ static hipError_t tvl1_add_lane(Tvl1Workspace* w) {
     A(&words, kCtlWords);                            // 4 control ints + one grid barrier counter per scale
     L.ctl = reinterpret_cast<int*>(words);
     L.bar = reinterpret_cast<unsigned*>(words) + 4;
+    // the fills above ran on the null stream; the caller's stream may not be ordered behind it, and a fill that lands after
+    // the first records were published would erase them (readers would poll for ever): once per lane and image size
+    if (err == hipSuccess) err = hipDeviceSynchronize();
     if (err == hipSuccess) w->lanes.push_back(L);
     return err;
 }
