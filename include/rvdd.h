@@ -141,16 +141,19 @@ int rvdd_upsample_factor_2(rvdd_t* h, const float* t, int32_t n, int32_t c, int3
  * optical flow with the reference's hard-wired parameters (3rdparty/tvl1flow/tvl1flow_lib.c:91-278, 343-472).
  *   I0, I1 [ny,nx] gray images; u [2,ny,nx] = x displacement then y displacement (libBridge.cpp:150) such
  *   that I1(x + u) ~ I0(x).  `iterations` (HOST, nullable) receives the total primal-dual iterations run.
- * One cooperative (grid-synchronising) kernel per pyramid scale; needs a device that can hold one block per
- * CU.  Synchronous: returns after the flow is complete (the control words are read back to catch a grid
- * barrier that timed out -- RVDD_ERR_HIP then, never a half-finished flow). */
+ * One cooperative kernel per pyramid scale, all of its blocks resident (csrc/tvl1.hip: since round 4 a block owns a patch of
+ * the image and exchanges its perimeter and convergence sum through tagged records that the readers poll -- no grid barrier
+ * in the iteration; round 3's barrier kernel is kept, RVDD_TVL1_PATCH=0, and the two are bit-identical, flows and iteration
+ * counts).  Synchronous: returns after the flow is complete (the control words are read back to catch an exchange that
+ * timed out -- RVDD_ERR_HIP then, never a half-finished flow). */
 int rvdd_tvl1flow(rvdd_t* h, const float* I0, const float* I1, float* u, int32_t nx, int32_t ny,
                   int32_t* iterations, void* stream);
 
 /* `n` independent pairs of the same size -- what data/base_dataset.py:134-249 computes one call at a time when it
  * fills the dataset's flow folder.  I0, I1: [n][ny][nx]; u: [n][2][ny][nx]; iterations: HOST [n], nullable.
- * Two pairs share each cooperative launch (the CUs one pair leaves idle between its memory round trips run the
- * other); every flow is bit-identical to the one rvdd_tvl1flow returns for that pair.  Synchronous. */
+ * The pairs of a call share launches: the pre-processing and pyramid of all of them, up to eight pairs per scale kernel at
+ * the coarse scales, two at 640 x 360 (0.76-0.80 ms per 640 x 360 flow in batches of eight, 1.9-2.1 ms one at a time);
+ * every flow is bit-identical to the one rvdd_tvl1flow returns for that pair.  Synchronous. */
 int rvdd_tvl1flow_batch(rvdd_t* h, const float* I0, const float* I1, float* u, int32_t n, int32_t nx, int32_t ny,
                         int32_t* iterations, void* stream);
 
