@@ -44,3 +44,5 @@ if os.path.exists(ref):
     out.update({"cpu_reference_flows_per_s": round(1 / cpu_s, 3), "cpu_threads": int(os.environ["OMP_NUM_THREADS"]), "gpu_over_cpu": round(cpu_s / gpu_s, 1),
                 "gpu_vs_reference_max_abs_px": worst, "gpu_vs_reference_mean_abs_px": mean})
 print(json.dumps(out))
+sys.stdout.flush()
+rt.close()        # before the interpreter tears the HIP runtime down (a profiler's exit handlers run after that)
