@@ -122,6 +122,43 @@ def test_hip_scale_kernels_agree(name):
 
 
 @pytest.mark.gpu
+def test_hip_scale_kernels_agree_over_sizes_and_batch_counts():
+    """The patch kernel against the barrier kernel over image sizes that leave ragged patches in both directions, one patch
+    only, widths of exactly / just over a multiple of 64, and batches of 1, 3 and 9 pairs (nine: a second set of lanes):
+    flows and iteration counts bit for bit."""
+    from rvdd_release_amd.util._ops import ops_runtime
+    rt = ops_runtime(0)
+    rng = np.random.default_rng(11)
+    small = torch.rand(20, 24, device="cuda")
+
+    def pairs(n, h, w):
+        yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
+        out0, out1 = [], []
+        for k in range(n):
+            f = 0.11 + 0.02 * k
+            base = np.sin(f * xx + 0.3 * k) * np.cos(0.07 * yy) + 0.5 * np.sin(0.05 * (xx + 2 * yy))
+            shifted = np.sin(f * (xx - 1.3) + 0.3 * k) * np.cos(0.07 * (yy + 0.6)) + 0.5 * np.sin(0.05 * ((xx - 1.3) + 2 * (yy + 0.6)))
+            noise = 0.05 * rng.standard_normal((2, h, w)).astype(np.float32)
+            out0.append(base + noise[0])
+            out1.append(shifted + noise[1])
+        return (torch.from_numpy(np.stack(out0).astype(np.float32)).cuda(), torch.from_numpy(np.stack(out1).astype(np.float32)).cuda())
+
+    for n, h, w in ((1, 16, 16), (3, 17, 65), (1, 64, 64), (3, 65, 129), (9, 45, 80), (3, 100, 200), (1, 128, 64), (3, 180, 320)):
+        a, b = pairs(n, h, w)
+        flows, iters = rt.tvl1flow_batch(a, b, want_iterations=True)
+        os.environ["RVDD_TVL1_PATCH"] = "0"
+        try:
+            rt.tvl1flow(small, small)                # another size: the workspace (and its mode) is rebuilt
+            flows_bar, iters_bar = rt.tvl1flow_batch(a, b, want_iterations=True)
+        finally:
+            del os.environ["RVDD_TVL1_PATCH"]
+            rt.tvl1flow(small, small)
+        assert list(iters) == list(iters_bar), (n, h, w, list(iters), list(iters_bar))
+        assert torch.equal(flows, flows_bar), (n, h, w)
+        assert torch.isfinite(flows).all() and max(iters) > 5
+
+
+@pytest.mark.gpu
 def test_hip_scale_kernels_agree_at_the_flow_size_of_1080p():
     """960x540 pairs (the raw size of a 1920x1080 frame), two in one batch call: one pair's 64x32 patches just fit the CUs
     (255 blocks), two do not -- the batch runs its finest scale one pair per launch and the coarse scales together.  Same bits
