@@ -547,11 +547,12 @@ __global__ __launch_bounds__(256) void scale_kernel(Lanes lanes) {
 // counter seen complete | neighbour loads).  Here a block owns a 64 x PH PATCH of the image instead of interleaved
 // row segments, so that
 //   * neighbours inside the patch are read from an LDS copy of the patch's u (two parities);
-//   * only the patch's perimeter travels: a perimeter pixel's u goes out as ONE 16-byte record {u1, tag, u2, tag}
-//     (write-through), tag = launch epoch and iteration number.  The owner of a ring cell polls the record until both
-//     tags are this iteration's -- each 8-byte half carries its own tag, so a record needs no other ordering: no
-//     "stores acknowledged" wait, no flag;
-//   * the convergence sum travels the same way: one tagged record per block, {sum lo, tag, sum hi, tag}, polled by
+//   * only the patch's perimeter travels: a perimeter pixel's u goes out as ONE 16-byte record {tag, u1, u2, tag}
+//     (write-through), tag = launch epoch and publication number.  The owner of a ring cell polls the record until both
+//     tags are this publication's -- the tags bracket the data, so whatever order the pieces of a record land in (first
+//     to last or last to first, in one piece or several), two matching tags mean everything between them has landed: a
+//     record needs no other ordering, no "stores acknowledged" wait, no flag;
+//   * the convergence sum travels the same way: one tagged record per block, {tag, sum lo, sum hi, tag}, polled by
 //     one wave of every block (fixed point: any order of adding, same bits).  It is the one thing of an iteration that
 //     needs EVERY block, so it is read one iteration late: update n + 1 runs before the test of iteration n is known
 //     and is dropped (u restored from a copy) when that test says n was the last -- the state the reference's loop
@@ -568,23 +569,6 @@ constexpr int kSumRecs = 256;                                // sum records per 
 constexpr int kSumSlots = 4;                                 // publications whose sums are kept (see the kernel's comment)
 using u32x4 = __attribute__((vector_size(16))) unsigned;
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-// a record whose two tags are `tagv`; false when the launch is being abandoned
-__device__ __forceinline__ bool poll_rec(__amdgpu_buffer_rsrc_t r, unsigned off, unsigned soff, unsigned tagv, int* abort_word,
-                                         unsigned& a, unsigned& b) {
-    for (unsigned spins = 0;;) {
-        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, off, soff, 16 /* sc1 */);
-        if (v[1] == tagv && v[3] == tagv) {
-            a = v[0];
-            b = v[2];
-            return true;
-        }
-        if (++spins > kSpinLimit || ((spins & 255u) == 0 && __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
-            __hip_atomic_store(abort_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            return false;
-        }
-    }
-}
-
 #ifdef RVDD_STAMPS
 __device__ unsigned long long g_tvl1_stamps[512][8];
 #define TS(v) const unsigned long long v = wall_clock64()
@@ -749,8 +733,8 @@ __global__ __launch_bounds__(NT) void scale_kernel_patch(Lanes lanes, unsigned e
 #pragma unroll
                     for (int i = 0; i < RC; ++i)
                         if (need[i]) {
-                            if (v[i][1] == tagv && v[i][3] == tagv) {
-                                got[i] = float2{__uint_as_float(v[i][0]), __uint_as_float(v[i][2])};
+                            if (v[i][0] == tagv && v[i][3] == tagv) {
+                                got[i] = float2{__uint_as_float(v[i][1]), __uint_as_float(v[i][2])};
                                 need[i] = false;
                             } else {
                                 more = true;
@@ -789,8 +773,8 @@ __global__ __launch_bounds__(NT) void scale_kernel_patch(Lanes lanes, unsigned e
 #pragma unroll
                     for (int i = 0; i < kSumRecs / 64; ++i)
                         if (need[i]) {
-                            if (v[i][1] == ptag && v[i][3] == ptag) {
-                                t += ((unsigned long long)v[i][2] << 32) | v[i][0];
+                            if (v[i][0] == ptag && v[i][3] == ptag) {
+                                t += ((unsigned long long)v[i][2] << 32) | v[i][1];
                                 need[i] = false;
                             } else {
                                 more = true;
@@ -813,14 +797,14 @@ __global__ __launch_bounds__(NT) void scale_kernel_patch(Lanes lanes, unsigned e
                 for (int i = 0; i < PC; ++i)
                     if (cvalid[i]) {
                         const float2 v = map[par][cmy[i]][cmx[i]];
-                        const u32x4 rec = {__float_as_uint(v.x), tagv, __float_as_uint(v.y), tagv};
+                        const u32x4 rec = {tagv, __float_as_uint(v.x), __float_as_uint(v.y), tagv};
                         __builtin_amdgcn_raw_buffer_store_b128(rec, ur, coff[i], par * S, 16 /* sc1 */);
                     }
                 if (tid == NT - 1) {
                     unsigned long long t = 0;
 #pragma unroll
                     for (int i = 0; i < NW; ++i) t += red[i];
-                    const u32x4 rec = {(unsigned)t, tagv, (unsigned)(t >> 32), tagv};
+                    const u32x4 rec = {tagv, (unsigned)t, (unsigned)(t >> 32), tagv};
                     __builtin_amdgcn_raw_buffer_store_b128(rec, sr, 16u * (unsigned)gb, (pub & (kSumSlots - 1u)) * (kSumRecs * 16u), 16 /* sc1 */);
                 }
             }
