@@ -271,20 +271,18 @@ __device__ __forceinline__ float u_px(Edge e, float& u1, float& u2, float wx, fl
     const float l_t = kLambda * kTheta;
     const float u1k = u1, u2k = u2;
     const float rho = rho_c + (wx * u1k + wy * u2k);
-    float d1, d2;
-    if (rho < -l_t * g) {
-        d1 = l_t * wx;
-        d2 = l_t * wy;
-    } else if (rho > l_t * g) {
-        d1 = -l_t * wx;
-        d2 = -l_t * wy;
-    } else if (g < kGradIsZero) {
-        d1 = d2 = 0.f;
-    } else {
-        const float fi = -rho / g;
-        d1 = fi * wx;
-        d2 = fi * wy;
-    }
+    // The reference's four-way branch (tvl1flow_lib.c:179-204) as selects in its order of precedence -- the same values
+    // from the same operations, without the divergent branches (the quotient of the last case is formed everywhere and
+    // dropped where another case applies: g = 0 gives an infinity or a NaN that the `g < kGradIsZero` select replaces).
+    const float th = l_t * g, a1 = l_t * wx, a2 = l_t * wy, fi = -rho / g;
+    float d1 = fi * wx, d2 = fi * wy;
+    const bool flat = g < kGradIsZero, above = rho > th, below = rho < -th;
+    d1 = flat ? 0.f : d1;
+    d2 = flat ? 0.f : d2;
+    d1 = above ? -a1 : d1;
+    d2 = above ? -a2 : d2;
+    d1 = below ? a1 : d1;
+    d2 = below ? a2 : d2;
     const float v1 = u1k + d1, v2 = u2k + d2;
     // divergence (mask.c:40-90)
     const float ax1 = e.c0 ? p11 : (e.cN ? -l11 : p11 - l11);
