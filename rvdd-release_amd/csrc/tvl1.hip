@@ -293,6 +293,22 @@ __device__ __forceinline__ float u_px(Edge e, float& u1, float& u2, float wx, fl
     u2 = v2 + kTheta * (ax2 + cy2);
     return (u1 - u1k) * (u1 - u1k) + (u2 - u2k) * (u2 - u2k);
 }
+// sqrt(S) in double for S = a sum of two squares of floats: the compiler's expansion of the double-precision root (reciprocal
+// square root, two coupled Newton steps, two residual corrections) WITHOUT its range scaling (for S < 2^-767; the smallest
+// non-zero sum of squares of floats is 2^-298) and without its infinity test -- the same instructions on the same values,
+// hence the same bits (tools/sqrt64_check.hip: 16.7 M pairs over every exponent, denormals and zeros included, none differ),
+// a quarter fewer of them.
+__device__ __forceinline__ double sqrt_sumsq(double S) {
+    const double y = __builtin_amdgcn_rsq(S);
+    const double g0 = S * y, h0 = y * 0.5;
+    const double r0 = __builtin_fma(-h0, g0, 0.5);
+    const double g1 = __builtin_fma(g0, r0, g0), h1 = __builtin_fma(h0, r0, h0);
+    const double d0 = __builtin_fma(-g1, g1, S);
+    const double g2 = __builtin_fma(d0, h1, g1);
+    const double d1 = __builtin_fma(-g2, g2, S);
+    const double r = __builtin_fma(d1, h1, g2);
+    return S == 0.0 ? 0.0 : r;
+}
 // forward gradient of u at one pixel and the two denominators of the dual update (tvl1flow_lib.c:217-228).
 // a, c: u1, u2 at the pixel; r*: at its right neighbour; d*: at its lower neighbour
 struct DualStep {
@@ -311,8 +327,8 @@ __device__ __forceinline__ DualStep dual_step(bool last_col, bool last_row, floa
     // of the instructions of the library hypot (no scaling, no special cases: |x|,|y| < 2^60 here).  1 + t in
     // double then float equals the float sum for t >= 0 (a sum of two floats rounds once either way).
     const double x1 = (double)o.u1x, y1 = (double)o.u1y, x2 = (double)o.u2x, y2 = (double)o.u2y;
-    const float g1 = (float)__builtin_sqrt(x1 * x1 + y1 * y1);
-    const float g2 = (float)__builtin_sqrt(x2 * x2 + y2 * y2);
+    const float g1 = (float)sqrt_sumsq(x1 * x1 + y1 * y1);
+    const float g2 = (float)sqrt_sumsq(x2 * x2 + y2 * y2);
     o.ng1 = 1.0f + taut * g1;
     o.ng2 = 1.0f + taut * g2;
     return o;
