@@ -152,7 +152,7 @@ int rvdd_tvl1flow(rvdd_t* h, const float* I0, const float* I1, float* u, int32_t
 /* `n` independent pairs of the same size -- what data/base_dataset.py:134-249 computes one call at a time when it
  * fills the dataset's flow folder.  I0, I1: [n][ny][nx]; u: [n][2][ny][nx]; iterations: HOST [n], nullable.
  * The pairs of a call share launches: the pre-processing and pyramid of all of them, up to eight pairs per scale kernel at
- * the coarse scales, two at 640 x 360 (0.76-0.80 ms per 640 x 360 flow in batches of eight, 1.9-2.1 ms one at a time);
+ * the coarse scales, two at 640 x 360 (0.76-0.80 ms per 640 x 360 flow in batches of eight, 1.8-1.9 ms one at a time);
  * every flow is bit-identical to the one rvdd_tvl1flow returns for that pair.  Synchronous. */
 int rvdd_tvl1flow_batch(rvdd_t* h, const float* I0, const float* I1, float* u, int32_t n, int32_t nx, int32_t ny,
                         int32_t* iterations, void* stream);
