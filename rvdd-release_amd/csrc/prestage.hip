@@ -255,12 +255,8 @@ __global__ __launch_bounds__(256) void netin_kernel(const float* __restrict__ ra
     // Workgroups go to the eight XCDs in turn; a pixel's stencils and bicubic taps reach two rows up and down, and a row is
     // several workgroups long: numbered as they come, vertically adjacent workgroups sit on different XCDs and every L2
     // fetches the same rows again.  Each XCD takes a contiguous eighth of the pixels instead.
-#ifdef RVDD_NETIN_LINEAR
-    const unsigned blk = blockIdx.x;
-#else
     const unsigned per = gridDim.x >> 3;
     const unsigned blk = blockIdx.x < 8u * per ? (blockIdx.x & 7u) * per + (blockIdx.x >> 3) : blockIdx.x;
-#endif
     const size_t idx = (size_t)blk * blockDim.x + threadIdx.x;
     if (idx >= (size_t)B * H * W) return;
     const int x = idx % W;
