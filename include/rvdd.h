@@ -212,6 +212,10 @@ int rvdd_srgb_metrics(rvdd_t* h, const uint8_t* a, const uint8_t* b, int32_t n, 
  *               next_split; same bits either way).
  *   "next_pool": 0 = with next_fused, MaxPool2d(2) in front of a DownConv (new_unet.py:200-204) as its own kernel instead
  *               of the fused block's epilogue (default 1; same bits either way).
+ *   "next_projfuse": 0 = the 96 -> 48 projection of the ConvBlock behind a concat (new_unet.py:85-88, 321-329) as its own
+ *               kernel, instead of as two 48 -> 48 halves in the epilogues of the blocks that form the two concatenated maps
+ *               (default 1 with the pipelined split-f16 block; the A/B reference: the same linear map, summed in another
+ *               order).
  *   "warp_async": 1 = the bicubic warp of the recurrent features runs on a second stream beside the network-input assembly and
  *               the net's first launch(es) (it depends on the last step's features and the flow only) instead of in line on the
  *               caller's stream (default 0: measured, no gain on MI355X; same bits).

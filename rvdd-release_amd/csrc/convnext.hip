@@ -627,6 +627,7 @@ constexpr int F_W1H_BYTES = 12 * 3072, F_W2H_BYTES = 6 * 3 * 2 * 1024;
 constexpr int F_SPLIT_SHIFT = (F_W1H_BYTES + F_W2H_BYTES) / 4 - 2 * M_W_FLOATS;      // floats the regions behind the filters move by
 constexpr size_t F_LDS_BYTES_SPLIT = F_LDS_BYTES + (size_t)F_SPLIT_SHIFT * 4;           // the same 153,040 B
 static_assert(F_LDS_BYTES_SPLIT <= 160 * 1024 && (F_SPLIT_SHIFT % 4) == 0 && F_SPLIT_SHIFT >= 0, "LDS plan (split)");
+constexpr int P_W_BYTES = 3 * 3072;           // convblock_pipe_kernel PROJ: a 48 x 48 projection's fragments, fc1's arrangement with three row blocks
 typedef _Float16 h8v __attribute__((ext_vector_type(8)));
 typedef _Float16 h4v __attribute__((ext_vector_type(4)));
 typedef _Float16 h2v __attribute__((ext_vector_type(2)));
@@ -1107,10 +1108,19 @@ __global__ __launch_bounds__(512, 2) void convblock_kernel(const float* __restri
 //     front requests the first two halo chunks of the next tile.  Two s_barrier per tile for every wave.
 //   * the halo chunks are requested and awaited by the front waves alone; "all four front waves are past this point" is
 //     an LDS counter each of them adds one to and polls (fsync), since s_barrier counts all eight.
-template <bool OUT3, bool POOL>
+//
+// PROJ: the 1x1 projection 96 -> 48 of the ConvBlock BEHIND a concat (new_unet.py:85-88, 321-329) is linear in the two
+// concatenated maps, proj(cat(a, b)) = Wa a + Wb b + bias, and each of the two has the concat as its only reader: the block
+// that forms a map applies that map's half of the projection to its own output in its epilogue -- the 12 values a lane holds
+// are B operands as they stand -- and stores Wa a + bias, or Wa a + the other block's map (Wb b + bias, read at the same
+// pixels: `pj.add`), in place of a.  The 96 -> 48 projection kernel (a pass of 4 S over maps of S bytes) is gone.  The output of a block has no
+// a-priori bound (the MLP's operands have the LayerNorm's), so the split works in block floating point per PIXEL: a column
+// of the product is W times one pixel's channels, any power of two per pixel factors out exactly.  POOL + PROJ: the pooled
+// map is taken from the unprojected values.
+template <bool OUT3, bool POOL, bool PROJ = false>
 __global__ __launch_bounds__(512, 2) void convblock_pipe_kernel(const float* __restrict__ x, NextBlockW wt, float* __restrict__ out,
                                                                int B, int H, int W, int tiles_x, int tiles_y, int ntiles, Out3 o3,
-                                                               float* __restrict__ pool) {
+                                                               float* __restrict__ pool, NextProj pj) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int SH = F_SPLIT_SHIFT;
     float* W1 = smem;
@@ -1120,6 +1130,8 @@ __global__ __launch_bounds__(512, 2) void convblock_pipe_kernel(const float* __r
     float* Pl = smem + F_OFF_PAR + SH;      // dw_b | ln_w | ln_b
     float* Tl = smem + F_OFF_T + SH;        // two chunk buffers; the LayerNorm exchange between the stages
     unsigned* Fs = reinterpret_cast<unsigned*>(smem + F_OFF_T + SH + 2 * E_BUF_FLOATS);       // the front's counter
+    float* PW = smem + F_OFF_T + SH + 2 * E_BUF_FLOATS + 16;      // PROJ: the projection's fragments (9 KiB), then its bias
+    float* PB = PW + P_W_BYTES / 4;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1157,6 +1169,11 @@ __global__ __launch_bounds__(512, 2) void convblock_pipe_kernel(const float* __r
             reinterpret_cast<f32x4*>(Wl)[q] = reinterpret_cast<const f32x4*>(wt.dw_w)[q];
         if (tid < E_PAR_FLOATS) Pl[tid] = tid < kF ? wt.dw_b[tid] : (tid < 2 * kF ? wt.ln_w[tid - kF] : wt.ln_b[tid - 2 * kF]);
         if (tid == 0) Fs[0] = 0;
+        if constexpr (PROJ) {
+            __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc((void*)pj.frag, 0, P_W_BYTES, 0x00020000);
+            for (int k = wave; k < P_W_BYTES / 1024; k += 8) dma16(rp, PW + k * 256, (unsigned)(k * 1024 + lane * 16));
+            if (tid < kF) PB[tid] = pj.bias ? pj.bias[tid] : 0.f;
+        }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -1340,7 +1357,7 @@ __global__ __launch_bounds__(512, 2) void convblock_pipe_kernel(const float* __r
             // are independent, which is what hides each other's latencies now that the SIMD partner is in another phase
 #pragma unroll
             for (int n2 = 0; n2 < 4; n2 += 2) {
-                __amdgpu_buffer_rsrc_t rx[2], ro[2];
+                __amdgpu_buffer_rsrc_t rx[2], ro[2], ra[2];
                 int yrow[2], valid[2];
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
@@ -1349,8 +1366,11 @@ __global__ __launch_bounds__(512, 2) void convblock_pipe_kernel(const float* __r
                     const size_t first = ((size_t)cur.b * H + min(yrow[q], H - 1)) * W + cur.x0;
                     rx[q] = __builtin_amdgcn_make_buffer_rsrc((void*)(x + first * kF), 0, valid[q] * (kF * 4), 0x00020000);
                     ro[q] = __builtin_amdgcn_make_buffer_rsrc((void*)(out + first * kF), 0, valid[q] * (kF * 4), 0x00020000);
+                    if constexpr (PROJ)      // a null `add` has no records: the loads return zeros
+                        ra[q] = __builtin_amdgcn_make_buffer_rsrc((void*)(pj.add ? pj.add + first * kF : x), 0,
+                                                                  pj.add ? valid[q] * (kF * 4) : 0, 0x00020000);
                 }
-                f32x4 a2[2][3], xr[2][3], lv[3];
+                f32x4 a2[2][3], xr[2][3], lv[3], av[2][3];
                 const char* w1b = reinterpret_cast<const char*>(W1) + lane_o * 16;
                 const char* w2b = reinterpret_cast<const char*>(W2) + lane_o * 16;
                 auto FA = [&](int m, int f) { return __builtin_bit_cast(h8v, *reinterpret_cast<const f32x4*>(w1b + m * 3072 + f * 1024)); };
@@ -1391,6 +1411,16 @@ __global__ __launch_bounds__(512, 2) void convblock_pipe_kernel(const float* __r
 #pragma unroll
                         for (int k = 0; k < 2; ++k) hq[q][k] = bvp[4 * (2 * p + k)];
                     if (p + 1 < 6) load_fc1(p + 1, cb ^ 1);
+                    if constexpr (PROJ) {
+                        // the other half of the projection, one pair of hidden blocks ahead of its use (the registers of the
+                        // fc1 prefetch, which has nothing left to fetch, are free)
+                        if (p == 5) {
+#pragma unroll
+                            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                                for (int mo = 0; mo < 3; ++mo) av[q][mo] = bload(ra[q], lane_off + 64 * mo);
+                        }
+                    }
                     h8v gh[3], gl[3];
 #pragma unroll
                     for (int mo = 0; mo < 3; ++mo) {
@@ -1449,8 +1479,74 @@ __global__ __launch_bounds__(512, 2) void convblock_pipe_kernel(const float* __r
 #pragma unroll
                     for (int mo = 0; mo < 3; ++mo) {
                         v[q][mo] = xr[q][mo] + lv[mo] * a2[q][mo];
-                        bstore(ro[q], lane_off + 64 * mo, v[q][mo]);
+                        if constexpr (!PROJ) bstore(ro[q], lane_off + 64 * mo, v[q][mo]);
                     }
+                if constexpr (PROJ) {
+                    const char* pwb = reinterpret_cast<const char*>(PW) + lane_o * 16;
+                    auto PF = [&](int m, int f) { return __builtin_bit_cast(h8v, *reinterpret_cast<const f32x4*>(pwb + m * 3072 + f * 1024)); };
+                    h8v pa[3], pb[3], pc[3];
+#pragma unroll
+                    for (int m = 0; m < 3; ++m) {
+                        pa[m] = PF(m, 0);
+                        pb[m] = PF(m, 1);
+                        pc[m] = PF(m, 2);
+                    }
+                    lds_frag_t* pbv = (lds_frag_t*)PB + kk;
+                    h8v P1[2], P2[2], P3[2], P4[2];
+                    float back[2];
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        // max |.| over the pixel's 48 channels: 12 in this lane, the rest in the lanes 16, 32, 48 away.  The bits of
+                        // non-negative floats order like unsigned integers
+                        float mx = 0.f;
+#pragma unroll
+                        for (int mo = 0; mo < 3; ++mo)
+                            mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v[q][mo][0]), fabsf(v[q][mo][1]))), fmaxf(fabsf(v[q][mo][2]), fabsf(v[q][mo][3])));
+                        unsigned mb = __float_as_uint(mx);
+                        auto s32 = __builtin_amdgcn_permlane32_swap(mb, mb, false, false);
+                        mb = max(s32[0], s32[1]);
+                        auto s16 = __builtin_amdgcn_permlane16_swap(mb, mb, false, false);
+                        mb = max(s16[0], s16[1]);
+                        // 2^(126 - e) puts the pixel's maximum into [1/2, 1); its inverse times the filters' 2^-s scales the sums
+                        // back (exponent arithmetic on the bits; an absurd e -- zero, denormal, beyond 2^110 -- stays finite)
+                        const int e = min((int)(mb >> 23) & 0xff, 252);
+                        const float fwd = __uint_as_float((unsigned)(253 - e) << 23);
+                        back[q] = __uint_as_float((unsigned)min(max(e + 1 + pj.inv_e, 1), 254) << 23);
+                        u32x2v xh[3], xl[3];
+#pragma unroll
+                        for (int j = 0; j < 3; ++j) split4h(v[q][j] * fwd, xh[j], xl[j]);
+                        P1[q] = cat8(xh[0], xh[1]);
+                        P2[q] = cat8(xl[0], xl[1]);
+                        P3[q] = cat8(xh[2], xh[2]);
+                        P4[q] = cat8(xl[2], xl[2]);
+                    }
+                    f32x4 pr[2][3];
+                    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int q = 0; q < 2; ++q)
+#pragma unroll
+                        for (int m = 0; m < 3; ++m) pr[q][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pa[m], P2[q], zero4, 0, 0, 0);
+#pragma unroll
+                    for (int q = 0; q < 2; ++q)
+#pragma unroll
+                        for (int m = 0; m < 3; ++m) pr[q][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pb[m], P1[q], pr[q][m], 0, 0, 0);
+#pragma unroll
+                    for (int q = 0; q < 2; ++q)
+#pragma unroll
+                        for (int m = 0; m < 3; ++m) pr[q][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pc[m], P4[q], pr[q][m], 0, 0, 0);
+#pragma unroll
+                    for (int q = 0; q < 2; ++q)
+#pragma unroll
+                        for (int m = 0; m < 3; ++m) pr[q][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pc[m], P3[q], pr[q][m], 0, 0, 0);
+#pragma unroll
+                    for (int q = 0; q < 2; ++q)
+#pragma unroll
+                        for (int m = 0; m < 3; ++m) pr[q][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pa[m], P1[q], pr[q][m], 0, 0, 0);
+#pragma unroll
+                    for (int q = 0; q < 2; ++q)
+#pragma unroll
+                        for (int m = 0; m < 3; ++m) bstore(ro[q], lane_off + 64 * m, pr[q][m] * back[q] + (pj.add ? av[q][m] : pbv[4 * m]));
+                }
                 if constexpr (POOL) {
                     // the two rows are one pooling row pair, pixels lr and lr ^ 1; floor semantics of MaxPool2d(2) fall out of
                     // the descriptor (pooled rows / columns that do not exist have no records)
@@ -1616,19 +1712,21 @@ static hipError_t launch_block_t(const float* x, float* out, const NextBlockW& w
     hipLaunchKernelGGL((convblock_kernel<OUT3, POOL, SPLIT>), dim3(grid), dim3(512), LDS, s, x, w, out, B, H, W, tx, ty, ntiles, o3, pool);
     return hipGetLastError();
 }
-template <bool OUT3, bool POOL>
+template <bool OUT3, bool POOL, bool PROJ = false>
 static hipError_t launch_block_pipe(const float* x, float* out, const NextBlockW& w, int B, int H, int W, Out3 o3, hipStream_t s,
-                                    float* pool) {
+                                    float* pool, NextProj pj = NextProj{}) {
     if ((size_t)H * W * kF * 4 >= 0x80000000ull) return hipErrorInvalidValue;
     static std::atomic<uint64_t> attr{0};
-    constexpr size_t LDS = F_LDS_BYTES_SPLIT + 64;
-    if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(convblock_pipe_kernel<OUT3, POOL>), LDS, attr); e != hipSuccess)
+    constexpr size_t LDS = F_LDS_BYTES_SPLIT + 64 + (PROJ ? P_W_BYTES + kF * 4 : 0);
+    static_assert(LDS <= 160 * 1024, "LDS plan (pipe)");
+    if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(convblock_pipe_kernel<OUT3, POOL, PROJ>), LDS, attr); e != hipSuccess)
         return e;
     const int tx = (W + E_TW - 1) / E_TW, ty = (H + E_TH - 1) / E_TH;
     const int ntiles = B * tx * ty;
     if (ntiles <= 0) return hipSuccess;
     const int grid = ((std::min(ntiles, num_cus()) + 7) / 8) * 8;
-    hipLaunchKernelGGL((convblock_pipe_kernel<OUT3, POOL>), dim3(grid), dim3(512), LDS, s, x, w, out, B, H, W, tx, ty, ntiles, o3, pool);
+    hipLaunchKernelGGL((convblock_pipe_kernel<OUT3, POOL, PROJ>), dim3(grid), dim3(512), LDS, s, x, w, out, B, H, W, tx, ty, ntiles, o3,
+                       pool, pj);
     return hipGetLastError();
 }
 // w.fc1_h set = the split-f16 MLP (the default; w.pipe: as a two-stage pipeline over tiles); null = the f32-MFMA form
@@ -1647,6 +1745,13 @@ hipError_t launch_next_block(const float* x, float* out, const NextBlockW& w, in
 
 hipError_t launch_next_block_pool(const float* x, float* out, float* pooled, const NextBlockW& w, int B, int H, int W, hipStream_t s) {
     return launch_block<false, true>(x, out, w, B, H, W, Out3{}, s, pooled);
+}
+
+hipError_t launch_next_block_proj(const float* x, float* out, float* pooled, const NextBlockW& w, const NextProj& pj, int B, int H,
+                                  int W, hipStream_t s) {
+    if (!w.fc1_h || !w.pipe || !pj.frag) return hipErrorInvalidValue;
+    return pooled ? launch_block_pipe<false, true, true>(x, out, w, B, H, W, Out3{}, s, pooled, pj)
+                  : launch_block_pipe<false, false, true>(x, out, w, B, H, W, Out3{}, s, nullptr, pj);
 }
 
 hipError_t launch_next_block_out3(const float* x, float* out, const NextBlockW& w, int B, int H, int W, const float* w3x48,

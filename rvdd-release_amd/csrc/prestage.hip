@@ -405,6 +405,109 @@ __global__ __launch_bounds__(192) void warp48_kernel(const float* __restrict__ s
     if (has_b) o[12] = accb;
 }
 
+// warp48_kernel with a 48 -> 48 projection of the warped pixel on its way out: dst = W warp(src) + bias.  ConvNeXtUnet's first
+// encoder block projects cat[y, warped features] 96 -> 48 (networks/new_unet.py:381-382, 85-88); the projection is linear
+// in the two maps and the warped features have no other reader, so their half of it rides here (f32 MFMA 16x16x4, exact
+// f32 products: the gather leaves the matrix pipe idle) and the other half in the epilogue of the block that forms y
+// (convnext.hip PROJ) -- the projection kernel and its 4 S of traffic are gone.  The 32 warped pixels of the workgroup
+// change lanes through LDS (pixel pitch 52 floats: the 16 lanes of a ds_read_b128 group on 16 distinct bank quads):
+// wave m forms output channels 16 m .. 16 m + 15 of both 16-pixel groups.
+// pw: the projection arranged as proj1x1_kernel's, [j 6][m 3][lr 16][g 4][i 4] = W[16m+lr][16j+4g+i]; the features are
+// input channels 48..95 (j = 3..5).
+__global__ __launch_bounds__(192) void warp48_proj_kernel(const float* __restrict__ src, const float* __restrict__ flow_raw,
+                                                          float* __restrict__ dst, int B, int H, int W, int64_t fbs,
+                                                          const float* __restrict__ pw, const float* __restrict__ bias) {
+    __shared__ int s_i[32][8];      // xi[4], yi[4] * W
+    __shared__ float s_w[32][8];    // wx[4], wy[4]
+    __shared__ __attribute__((aligned(16))) float s_t[32][52];
+    const int y = blockIdx.y, b = blockIdx.z, x0 = blockIdx.x * 32;
+    const int lane = threadIdx.x & 63, m = threadIdx.x >> 6, lr = lane & 15, g = lane >> 4;
+    f32x4 wa[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) wa[j] = *reinterpret_cast<const f32x4*>(pw + ((((size_t)(3 + j) * 3 + m) * 16 + lr) * 4 + g) * 4);
+    const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + 16 * m + 4 * g);
+    if (threadIdx.x < 32) {
+        const int x = x0 + threadIdx.x;
+        if (x < W) {
+            const int h = H / 2, w = W / 2;
+            float fx, fy;
+            flow_at(flow_raw + (size_t)b * fbs, h, w, H, W, y, x, fx, fy);
+            Taps t;
+            make_taps(fx, fy, x, y, H, W, t);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                s_i[threadIdx.x][k] = t.xi[k];
+                s_i[threadIdx.x][4 + k] = t.yi[k] * W;
+                s_w[threadIdx.x][k] = t.wx[k];
+                s_w[threadIdx.x][4 + k] = t.wy[k];
+            }
+        }
+    }
+    __syncthreads();
+    const int p = threadIdx.x / 12;
+    const int c4 = threadIdx.x - p * 12;
+    const int pa = 2 * p, pb = 2 * p + 1, xa = x0 + pa;
+    f32x4 acca = {0.f, 0.f, 0.f, 0.f}, accb = {0.f, 0.f, 0.f, 0.f};
+    if (xa < W) {
+        const bool has_b = xa + 1 < W;
+        const f32x4* s = reinterpret_cast<const f32x4*>(src) + (size_t)b * H * W * 12 + c4;
+        int xia[4], yia[4], xib[4], yib[4];
+        float wxa[4], wya[4], wxb[4], wyb[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            xia[k] = s_i[pa][k]; yia[k] = s_i[pa][4 + k]; wxa[k] = s_w[pa][k]; wya[k] = s_w[pa][4 + k];
+            xib[k] = s_i[pb][k]; yib[k] = s_i[pb][4 + k]; wxb[k] = s_w[pb][k]; wyb[k] = s_w[pb][4 + k];
+        }
+        const bool lined_up = has_b && yib[0] == yia[0] && yib[1] == yia[1] && yib[2] == yia[2] && yib[3] == yia[3] &&
+                              xib[0] == xia[1] && xib[1] == xia[2] && xib[2] == xia[3];
+        if (lined_up) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const f32x4 v0 = s[(yia[j] + xia[0]) * 12], v1 = s[(yia[j] + xia[1]) * 12], v2 = s[(yia[j] + xia[2]) * 12];
+                const f32x4 v3 = s[(yia[j] + xia[3]) * 12], v4 = s[(yia[j] + xib[3]) * 12];
+                f32x4 ra = {0.f, 0.f, 0.f, 0.f}, rb = {0.f, 0.f, 0.f, 0.f};
+                ra = ra + v0 * wxa[0]; ra = ra + v1 * wxa[1]; ra = ra + v2 * wxa[2]; ra = ra + v3 * wxa[3];
+                rb = rb + v1 * wxb[0]; rb = rb + v2 * wxb[1]; rb = rb + v3 * wxb[2]; rb = rb + v4 * wxb[3];
+                acca = acca + ra * wya[j];
+                accb = accb + rb * wyb[j];
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                f32x4 ra = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) ra = ra + s[(yia[j] + xia[i]) * 12] * wxa[i];
+                acca = acca + ra * wya[j];
+            }
+            if (has_b) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    f32x4 rb = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) rb = rb + s[(yib[j] + xib[i]) * 12] * wxb[i];
+                    accb = accb + rb * wyb[j];
+                }
+            }
+        }
+    }
+    *reinterpret_cast<f32x4*>(&s_t[pa][4 * c4]) = acca;
+    *reinterpret_cast<f32x4*>(&s_t[pb][4 * c4]) = accb;
+    __syncthreads();
+#pragma unroll
+    for (int gq = 0; gq < 2; ++gq) {
+        f32x4 xb[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) xb[j] = *reinterpret_cast<const f32x4*>(&s_t[16 * gq + lr][16 * j + 4 * g]);
+        f32x4 acc = bv;
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[j][i], xb[j][i], acc, 0, 0, 0);
+        const int x = x0 + 16 * gq + lr;
+        if (x < W) *reinterpret_cast<f32x4*>(dst + (((size_t)b * H + y) * W + x) * kF + 16 * m + 4 * g) = acc;
+    }
+}
+
 __global__ void warp_nchw_kernel(const float* __restrict__ xin, const float* __restrict__ flow,
                                  float* __restrict__ yout, int n, int c, int H, int W) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -686,6 +789,14 @@ hipError_t launch_warp48(const float* src, const float* flow_raw, float* dst, in
     if (!B || !H || !W) return hipSuccess;
     hipLaunchKernelGGL(warp48_kernel, dim3((W + 31) / 32, H, B), dim3(192), 0, s, src, flow_raw, dst, B, H, W,
                        flow_bstride ? flow_bstride : (int64_t)2 * (H / 2) * (W / 2));
+    return hipGetLastError();
+}
+
+hipError_t launch_warp48_proj(const float* src, const float* flow_raw, float* dst, int B, int H, int W, const float* proj_w96,
+                              const float* bias, hipStream_t s, int64_t flow_bstride) {
+    if (!B || !H || !W) return hipSuccess;
+    const int64_t fbs = flow_bstride ? flow_bstride : (int64_t)2 * (H / 2) * (W / 2);
+    hipLaunchKernelGGL(warp48_proj_kernel, dim3((W + 31) / 32, H, B), dim3(192), 0, s, src, flow_raw, dst, B, H, W, fbs, proj_w96, bias);
     return hipGetLastError();
 }
 

@@ -48,6 +48,9 @@ struct ProfPending {
 struct NextBlk {          // one ConvBlock of the ConvNeXt net (networks/new_unet.py:74-103)
     NextBlockW w{};
     int c1 = 0, c2 = 0;   // projection sources (0,0 = identity)
+    // a 96 -> 48 projection as two halves for the epilogues of the blocks that form its two sources (convnext.hip PROJ):
+    // half[0] over the first 48 input channels (frag, inv_e set; bias = proj_b), half[1] over the last 48 (no bias)
+    NextProj half[2] = {};
 };
 
 // Every entry point acts on the handle's device, whatever the caller's current device is, and leaves
@@ -149,6 +152,8 @@ struct rvdd_handle {
     bool next_split = true;       // ConvNeXt, fused blocks: the two 1x1 convs on the F16 matrix pipe with split f32 operands (RVDD_NEXT_SPLIT=0: f32 MFMA)
     bool next_pipe = true;        // ConvNeXt, fused split-f16 blocks as a front / back pipeline over tiles (convblock_pipe_kernel; RVDD_NEXT_PIPE=0: convblock_kernel's phases)
     bool next_pool = true;        // ConvNeXt, fused blocks: MaxPool2d(2) from the epilogue of the block in front of a DownConv
+    bool next_projfuse = true;    // ConvNeXt, pipelined split-f16 blocks: the 96 -> 48 projection behind a concat as two halves in the epilogues of
+                                  // the blocks that form the concatenated maps (RVDD_NEXT_PROJFUSE=0 / option "next_projfuse" 0: proj1x1_kernel)
     bool next_streams = false;    // ConvNeXt, two-kernel blocks, B >= 2: the two halves of the batch as two chains on two streams (measured: no gain)
     hipStream_t stream2 = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -159,6 +164,7 @@ struct rvdd_handle {
     bool warp_async = false;
     hipEvent_t ev_wfork = nullptr, ev_wjoin = nullptr;
     bool warp_join_pending = false, warp_async_now = false;
+    bool featw_proj = false;      // `featw` of the running step holds W_f warp(features) + bias (run_prologue, next_pf_pre), not the warped features
     bool serpentine = false;      // sequence order of the current frame-step (flips every step when seq_major is on)
     std::map<std::string, HostTensor> staged;
     std::vector<void*> allocs;
@@ -940,6 +946,7 @@ int run_net(rvdd_t* h, const float* netin, const float* featw, float* feat_dst, 
         return rc ? rc : rj;
     }
     const int B = h->cfg.batch;
+    h->featw_proj = false;          // a caller's own features (rvdd_unet_forward) come as they are
     if (prologue) RC(run_prologue(h, *prologue, Sub{0, B}, s));
     if (h->next_streams && !h->next_fused && B >= 2 && h->stream2) {
         // Two chains, one per half of the batch, on two streams.  The MLP kernel is bound by the matrix cores, the
@@ -999,6 +1006,7 @@ int rvdd_create(const rvdd_cfg* cfg, rvdd_t** out) {
     if (const char* np = std::getenv("RVDD_NEXT_POOL")) h->next_pool = std::atoi(np) != 0;
     if (const char* nsp = std::getenv("RVDD_NEXT_SPLIT")) h->next_split = std::atoi(nsp) != 0;
     if (const char* npp = std::getenv("RVDD_NEXT_PIPE")) h->next_pipe = std::atoi(npp) != 0;
+    if (const char* npf = std::getenv("RVDD_NEXT_PROJFUSE")) h->next_projfuse = std::atoi(npf) != 0;
     if (const char* ns = std::getenv("RVDD_NEXT_STREAMS")) h->next_streams = std::atoi(ns) != 0;
     if (const char* cv = std::getenv("RVDD_CONV")) {
         // f32 (the f32-MFMA kernels, direct or Winograd by launch size) | direct | winograd (that f32 kernel at every size) |
@@ -1264,6 +1272,12 @@ int rvdd_set_option(rvdd_t* h, const char* name, int32_t value) {
         h->next_pool = value != 0;
         return RVDD_OK;
     }
+    if (std::strcmp(name, "next_projfuse") == 0) {
+        // 0 = the 96 -> 48 projection behind a concat as its own kernel (A/B reference of the projection halves in the epilogues of
+        // the blocks that form the two concatenated maps)
+        h->next_projfuse = value != 0;
+        return RVDD_OK;
+    }
     if (std::strcmp(name, "next_streams") == 0) {
         // 0 = ConvNeXt's two-kernel blocks on the caller's stream only (A/B reference of the two half-batch chains)
         h->next_streams = value != 0 && h->stream2 != nullptr;
@@ -1320,7 +1334,7 @@ int rvdd_set_option(rvdd_t* h, const char* name, int32_t value) {
         h->split16 = value == 0;
         return RVDD_OK;
     }
-    return fail(h, RVDD_ERR_ARG, "rvdd_set_option: unknown option '%s' (known: no_warp, warp_raw, prev_noisy_frame, conv_kernel, seq_major, graphs, fuse_upsample, next_fused, next_split, next_pipe, next_pool, next_streams, wino4, block_fp, conv_groups, fuse_pre, warp_async)", name);
+    return fail(h, RVDD_ERR_ARG, "rvdd_set_option: unknown option '%s' (known: no_warp, warp_raw, prev_noisy_frame, conv_kernel, seq_major, graphs, fuse_upsample, next_fused, next_split, next_pipe, next_pool, next_projfuse, next_streams, wino4, block_fp, conv_groups, fuse_pre, warp_async)", name);
 }
 
 int rvdd_reset(rvdd_t* h) {
@@ -1356,7 +1370,12 @@ int run_prologue(rvdd_t* h, const StepInputs& in, Sub sb, hipStream_t s) {
         HIPCHK(h, hipStreamWaitEvent(h->stream2, h->ev_wfork, 0));
         {
             Scope sc(h, h->stream2, "warp48_kernel", 0.0, (double)n * img * (384.0 + 2.0));
-            HIPCHK(h, launch_warp48(h->lastfeat, fp_, h->featw, n, H, W, h->stream2, (int64_t)in.flowf));
+            h->featw_proj = next_pf_pre(h);
+            if (h->featw_proj)
+                HIPCHK(h, launch_warp48_proj(h->lastfeat, fp_, h->featw, n, H, W, h->nx[NX_ENC0_0].w.proj_w, h->nx[NX_ENC0_0].w.proj_b,
+                                             h->stream2, (int64_t)in.flowf));
+            else
+                HIPCHK(h, launch_warp48(h->lastfeat, fp_, h->featw, n, H, W, h->stream2, (int64_t)in.flowf));
         }
         HIPCHK(h, hipEventRecord(h->ev_wjoin, h->stream2));
         h->warp_join_pending = true;
@@ -1421,8 +1440,13 @@ int run_prologue(rvdd_t* h, const StepInputs& in, Sub sb, hipStream_t s) {
                                (int64_t)in.flowf));
     }
     if (h->has_feat() && !nw && !h->warp_async_now) {
-        Scope sc(h, s, "warp48_kernel", 0.0, (double)n * img * (384.0 + 2.0));
-        HIPCHK(h, launch_warp48(h->lastfeat + o * img * kF, fp_, h->featw + o * img * kF, n, H, W, s, (int64_t)in.flowf));
+        h->featw_proj = next_pf_pre(h);
+        Scope sc(h, s, "warp48_kernel", h->featw_proj ? 2.0 * 48 * 48 * n * img : 0.0, (double)n * img * (384.0 + 2.0));
+        if (h->featw_proj)
+            HIPCHK(h, launch_warp48_proj(h->lastfeat + o * img * kF, fp_, h->featw + o * img * kF, n, H, W, h->nx[NX_ENC0_0].w.proj_w,
+                                         h->nx[NX_ENC0_0].w.proj_b, s, (int64_t)in.flowf));
+        else
+            HIPCHK(h, launch_warp48(h->lastfeat + o * img * kF, fp_, h->featw + o * img * kF, n, H, W, s, (int64_t)in.flowf));
     }
     return RVDD_OK;
 }

@@ -191,6 +191,10 @@ hipError_t launch_netin_bound(const float* raw_a, const float* raw_b, const floa
 // src NHWC48 -> dst NHWC48.
 hipError_t launch_warp48(const float* src, const float* flow_raw, float* dst, int B, int H, int W,
                          hipStream_t s, int64_t flow_bstride = 0);
+// the same, and a 48 -> 48 projection of every warped pixel: dst = W warp(src) + bias; proj_w96 = a 96 -> 48 projection arranged
+// as launch_proj1x1's (runtime_next.inc), of which input channels 48..95 are applied (prestage.hip warp48_proj_kernel)
+hipError_t launch_warp48_proj(const float* src, const float* flow_raw, float* dst, int B, int H, int W, const float* proj_w96,
+                              const float* bias, hipStream_t s, int64_t flow_bstride = 0);
 // generic NCHW warp with a full-resolution flow (util.flow_utils.warp).
 hipError_t launch_remosaick4(const float* rgb4, float* raw, int B, int H, int W, hipStream_t s);
 hipError_t launch_warp_nchw(const float* x, const float* flow, float* y, int n, int c, int H, int W,
@@ -239,6 +243,14 @@ struct NextBlockW {          // device pointers, one ConvBlock (networks/new_une
                              // into the pair that starts at it, i.e. (c_i, c_i+1): wrong numbers, found the hard way)
     int pipe;                // 1 = convblock_pipe_kernel (front / back waves pipelined over tiles) instead of convblock_kernel
 };
+// A 48 -> 48 projection applied to a fused block's OUTPUT in its epilogue (convblock_pipe_kernel PROJ): one half of the
+// 96 -> 48 projection behind a concat, proj(cat(a, b)) = Wa a + Wb b + bias (networks/new_unet.py:85-88, 321-329)
+struct NextProj {
+    const float* frag;       // split-f16 fragments of 2^s W [48][48] (runtime_next.inc arrange_proj_half), 9 KiB
+    const float* bias;       // [48] or null; used when `add` is null
+    const float* add;        // NHWC48 map of the block's output size added to the projection (the other half, with the bias), or null
+    int inv_e;               // -s: added to a float's exponent field it multiplies by 2^-s
+};
 // one ConvBlock = dwln (x -> LayerNorm(dwconv7x7(x))) then mlp (ln, x -> x + ls * MLP(ln)); x NHWC48
 // co = the launch shares the CUs with a kernel of the other half-batch chain (runtime_next.inc): dwln one workgroup per
 // CU instead of two, mlp one wave per SIMD instead of two
@@ -259,6 +271,10 @@ hipError_t launch_next_block(const float* x, float* out, const NextBlockW& w, in
 hipError_t launch_next_block_pool(const float* x, float* out, float* pooled, const NextBlockW& w, int B, int H, int W, hipStream_t s);
 hipError_t launch_next_block_out3(const float* x, float* out, const NextBlockW& w, int B, int H, int W, const float* w3x48,
                                   const float* b3, float* out_nchw, float* out_nhwc4, hipStream_t s);
+// the fused block (pipelined split-f16 form only: w.fc1_h set) storing pj's projection of its output (+ pj.bias + pj.add) in
+// place of the output; pooled (nullable): MaxPool2d(2) of the UNPROJECTED output, as launch_next_block_pool
+hipError_t launch_next_block_proj(const float* x, float* out, float* pooled, const NextBlockW& w, const NextProj& pj, int B, int H,
+                                  int W, hipStream_t s);
 // 1x1 projection on MFMA: in1 NHWC[c1] (+ in2 NHWC[c2]) -> out NHWC48; (c1,c2) = (16,0) or (48,48)
 hipError_t launch_proj1x1(const float* in1, int c1, const float* in2, int c2, const float* w,
                           const float* b, float* out, int64_t npix, hipStream_t s);

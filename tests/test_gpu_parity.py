@@ -1037,6 +1037,7 @@ def test_pipelined_convblock_equals_phased():
         for pipe in (1, 0):
             rt = RvddRuntime(arch, fut, B, H, W, 0)
             rt.set_option("next_pipe", pipe)
+            rt.set_option("next_projfuse", 0)        # the projection halves exist in the pipelined kernel only: same schedule on both sides
             rt.load_state_dict(sd)
             o = []
             for t in range(1, T - fut):
@@ -1047,6 +1048,38 @@ def test_pipelined_convblock_equals_phased():
         for a, b in zip(outs[0][0], outs[1][0]):
             assert torch.equal(a, b), (B, H, W, float((a - b).abs().max()))
         assert torch.equal(outs[0][1], outs[1][1]), (B, H, W)
+
+
+def test_projection_halves_equal_projection_kernel():
+    """The 96 -> 48 projection behind cat((x_dec, x_enc)) (networks/new_unet.py:321-329, 85-88) as two 48 -> 48 halves in the
+    epilogues of the blocks that form x_enc and x_dec (the default) against proj1x1_kernel on the concatenated maps (option
+    next_projfuse = 0): the same linear map, the halves on the F16 matrix pipe with operands split per pixel in block floating
+    point, summed in another order -- frames and recurrent features within 5e-6 of each other's maximum (observed: 2.2e-6 after two
+    recurrent steps; the split-f16 and the f32-MFMA blocks differ by as much).  Sizes where every
+    decoder level fuses, where zero_pad_features keeps some levels on the kernel (odd level sizes), ragged tiles, batches."""
+    from rvdd_release_amd import synth
+    from rvdd_release_amd.runtime import RvddRuntime
+    if "next-feat-future-iso3200" not in BUILT:
+        pytest.skip("ConvNeXt path not built")
+    arch, fut = "next+feat", 1
+    sd = load_weights(VARIANTS["next-feat-future-iso3200"][0])
+    for B, H, W in ((1, 16, 16), (3, 24, 136), (2, 130, 22), (1, 50, 66), (2, 72, 104), (1, 256, 256), (2, 360, 640)):
+        T = 4
+        seqs = [synth.make_sequence(T, H, W, iso=3200, seed=670 + b, device="cuda") for b in range(B)]
+        st = lambda f: torch.stack([f(s) for s in seqs], 0)
+        outs = []
+        for fuse in (1, 0):
+            rt = RvddRuntime(arch, fut, B, H, W, 0)
+            rt.set_option("next_projfuse", fuse)
+            rt.load_state_dict(sd)
+            o = []
+            for t in range(1, T - fut):
+                o.append(rt.step(st(lambda s: s.raw[t - 1]) if t == 1 else None, st(lambda s: s.raw[t]),
+                                 st(lambda s: s.raw[t + 1]), st(lambda s: s.flow_prev[t]), st(lambda s: s.flow_next[t])).clone())
+            outs.append((o, rt.get_state()[1].clone()))
+            rt.close()
+        for a, b in zip(outs[0][0] + [outs[0][1]], outs[1][0] + [outs[1][1]]):
+            assert float((a - b).abs().max()) <= 5e-6 * max(1.0, float(b.abs().max())), (B, H, W, float((a - b).abs().max()))
 
 
 def test_pooling_epilogue_equals_maxpool_kernel():
@@ -1068,6 +1101,7 @@ def test_pooling_epilogue_equals_maxpool_kernel():
         for pool in (1, 0):
             rt = RvddRuntime(arch, fut, B, H, W, 0)
             rt.set_option("next_pool", pool)
+            rt.set_option("next_projfuse", 0)        # (they ride in the pooling blocks' epilogues: same schedule on both sides)
             rt.load_state_dict(sd)
             o = []
             for t in range(1, T - fut):
