@@ -343,15 +343,20 @@ __device__ __forceinline__ f32x4 gelu_phi4(f32x4 v) {
 // gc[6] = cap / s (NextBlockW::gelu_c, computed on the host; every constant twice, see there).
 __device__ __forceinline__ f32x4 gelu_phi4_scaled(f32x4 h, const float (&gc)[7][2]) {
     const float zero = 0.0f, cap = gc[6][0];
-    f32x2 t[2], p[2], q[2];
-    f32x4 relu, o;
+    f32x2 t[2], p[2], q[2], relu[2], e[2];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         // v_med3_f32 through the intrinsic, NOT gelu_phi4's inline-asm v_min / v_max: h comes straight out of an MFMA here,
         // and the wait states a vector read of an MFMA result needs are only inserted in front of instructions the compiler
         // can see (inline asm reading the accumulator two cycles behind the MFMA read garbage)
         t[k >> 1][k & 1] = __builtin_amdgcn_fmed3f(__builtin_fabsf(h[k]), zero, cap);
-        relu[k] = __builtin_amdgcn_fmed3f(h[k], zero, __builtin_inff());
+    }
+    {   // max(h, 0) on the BITS as signed integers: a float below zero (or -0) is a negative integer.  One v_max_i32; the float
+        // forms (fmaxf, fmed3f with an infinity) cost a second instruction each, a canonicalising v_max_f32 h, h in front
+        typedef int i32x4 __attribute__((ext_vector_type(4)));
+        const f32x4 r4 = __builtin_bit_cast(f32x4, __builtin_elementwise_max(__builtin_bit_cast(i32x4, h), i32x4{0, 0, 0, 0}));
+        relu[0] = f32x2{r4[0], r4[1]};
+        relu[1] = f32x2{r4[2], r4[3]};
     }
     auto K = [&](int i) { return f32x2{gc[i][0], gc[i][1]}; };
     p[0] = p[1] = K(0);
@@ -363,8 +368,10 @@ __device__ __forceinline__ f32x4 gelu_phi4_scaled(f32x4 h, const float (&gc)[7][
     q[0] = __builtin_elementwise_fma(t[0], p[0], f32x2{-1.0f, -1.0f});
     q[1] = __builtin_elementwise_fma(t[1], p[1], f32x2{-1.0f, -1.0f});
 #pragma unroll
-    for (int k = 0; k < 4; ++k) o[k] = fmaf(-fabsf(h[k]), __builtin_amdgcn_exp2f(q[k >> 1][k & 1]), relu[k]);
-    return o;
+    for (int k = 0; k < 4; ++k) e[k >> 1][k & 1] = __builtin_amdgcn_exp2f(q[k >> 1][k & 1]);
+    // max(h, 0) - t Phi(-t) with the capped t: beyond the cap the product is below 1e-9 either way; packed
+    const f32x2 o0 = __builtin_elementwise_fma(-t[0], e[0], relu[0]), o1 = __builtin_elementwise_fma(-t[1], e[1], relu[1]);
+    return f32x4{o0[0], o0[1], o1[0], o1[1]};
 }
 
 // OUT3: the network's last block also applies the 1x1 conv 48 -> 3 of the post-processing (new_unet.py:414-430) to the
