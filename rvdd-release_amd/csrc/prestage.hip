@@ -246,37 +246,88 @@ __device__ __forceinline__ f32x4 warp3_at(const f32x4* __restrict__ s, const flo
     return acc;
 }
 
-__global__ __launch_bounds__(256) void netin_kernel(const float* __restrict__ raw_cur, const float* __restrict__ green,
-                                                    const float* __restrict__ prev4, const float* __restrict__ flow_prev,
-                                                    const float* __restrict__ next4, const float* __restrict__ flow_next,
-                                                    float* __restrict__ netin, int B, int h, int w, int64_t rbs,
-                                                    int64_t fbs) {
-    const int H = 2 * h, W = 2 * w;
-    // Workgroups go to the eight XCDs in turn; a pixel's stencils and bicubic taps reach two rows up and down, and a row is
-    // several workgroups long: numbered as they come, vertically adjacent workgroups sit on different XCDs and every L2
-    // fetches the same rows again.  Each XCD takes a contiguous eighth of the pixels instead.
-    const unsigned per = gridDim.x >> 3;
-    const unsigned blk = blockIdx.x < 8u * per ? (blockIdx.x & 7u) * per + (blockIdx.x >> 3) : blockIdx.x;
-    const size_t idx = (size_t)blk * blockDim.x + threadIdx.x;
-    if (idx >= (size_t)B * H * W) return;
+// The 16 channels of one network-input pixel: warp3 of prev4 | demosaic of raw_cur | warp3 of next4 (zeros without one) | 0..
+struct NetinArgs {
+    const float *raw_cur, *green, *prev4, *flow_prev, *next4, *flow_next;
+    int B, h, w;
+    int64_t rbs, fbs;
+};
+__device__ __forceinline__ void netin_pixel(const NetinArgs& a, size_t idx, f32x4 (&o)[3]) {
+    const int H = 2 * a.h, W = 2 * a.w;
     const int x = idx % W;
     const int y = (idx / W) % H;
     const int b = idx / ((size_t)W * H);
-    Cfa c{raw_cur + (size_t)b * rbs, h, w, H, W};
-    const float* gp = green + (size_t)b * H * W;
+    Cfa c{a.raw_cur + (size_t)b * a.rbs, a.h, a.w, H, W};
+    const float* gp = a.green + (size_t)b * H * W;
     const float g0 = gp[(size_t)y * W + x];
     float rb[2];
     ha_red_blue(c, gp, H, W, y, x, g0, rb);
-    const f32x4 p = warp3_at(reinterpret_cast<const f32x4*>(prev4) + (size_t)b * H * W,
-                             flow_prev ? flow_prev + (size_t)b * fbs : nullptr, h, w, H, W, y, x);
+    const f32x4 p = warp3_at(reinterpret_cast<const f32x4*>(a.prev4) + (size_t)b * H * W,
+                             a.flow_prev ? a.flow_prev + (size_t)b * a.fbs : nullptr, a.h, a.w, H, W, y, x);
     f32x4 n = {0.f, 0.f, 0.f, 0.f};
-    if (next4)
-        n = warp3_at(reinterpret_cast<const f32x4*>(next4) + (size_t)b * H * W,
-                     flow_next ? flow_next + (size_t)b * fbs : nullptr, h, w, H, W, y, x);
-    f32x4* o = reinterpret_cast<f32x4*>(netin) + idx * 4;
+    if (a.next4)
+        n = warp3_at(reinterpret_cast<const f32x4*>(a.next4) + (size_t)b * H * W,
+                     a.flow_next ? a.flow_next + (size_t)b * a.fbs : nullptr, a.h, a.w, H, W, y, x);
     o[0] = f32x4{p[0], p[1], p[2], rb[0]};
     o[1] = f32x4{g0, rb[1], n[0], n[1]};
     o[2] = f32x4{n[2], 0.f, 0.f, 0.f};
+}
+// Workgroups go to the eight XCDs in turn; a pixel's stencils and bicubic taps reach two rows up and down, and a row is
+// several workgroups long: numbered as they come, vertically adjacent workgroups sit on different XCDs and every L2
+// fetches the same rows again.  Each XCD takes a contiguous eighth of the pixels instead.
+__device__ __forceinline__ unsigned xcd_contiguous_block() {
+    const unsigned per = gridDim.x >> 3;
+    return blockIdx.x < 8u * per ? (blockIdx.x & 7u) * per + (blockIdx.x >> 3) : blockIdx.x;
+}
+
+__global__ __launch_bounds__(256) void netin_kernel(NetinArgs a, float* __restrict__ netin) {
+    const size_t idx = (size_t)xcd_contiguous_block() * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)a.B * 4 * a.h * a.w) return;
+    f32x4 v[3];
+    netin_pixel(a, idx, v);
+    f32x4* o = reinterpret_cast<f32x4*>(netin) + idx * 4;
+    o[0] = v[0];
+    o[1] = v[1];
+    o[2] = v[2];
+}
+
+// netin_kernel for ConvNeXtUnet: the network input has exactly one reader there, the 1x1 projection 9 | 6 -> 48 of the first
+// ConvBlock (networks/new_unet.py:85-88), so the 16-channel map is never written: the 256 pixels of a workgroup change lanes
+// through LDS (pixel pitch 24 floats: the 16 lanes of a ds_read_b128 group on 16 distinct bank quads) and each wave projects
+// four 16-pixel groups on the f32 matrix pipe (16x16x4, exact f32 products).  pw as proj1x1_kernel<16, 0>'s:
+// [m 3][lr 16][g 4][i 4] = W[16m+lr][4g+i] (zero for channels the input does not have).
+__global__ __launch_bounds__(256) void netin_proj_kernel(NetinArgs a, const float* __restrict__ pw, const float* __restrict__ bias,
+                                                         float* __restrict__ out) {
+    __shared__ __attribute__((aligned(16))) float s_t[256][24];
+    const size_t total = (size_t)a.B * 4 * a.h * a.w;
+    const size_t base = (size_t)xcd_contiguous_block() * 256;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, lr = lane & 15, g = lane >> 4;
+    f32x4 wa[3], bv[3];
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {
+        wa[m] = *reinterpret_cast<const f32x4*>(pw + (((size_t)m * 16 + lr) * 4 + g) * 4);
+        bv[m] = *reinterpret_cast<const f32x4*>(bias + 16 * m + 4 * g);
+    }
+    f32x4 v[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    if (base + threadIdx.x < total) netin_pixel(a, base + threadIdx.x, v);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) *reinterpret_cast<f32x4*>(&s_t[threadIdx.x][4 * k]) = v[k];
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int px = 64 * wv + 16 * q + lr;
+        f32x4 xb = *reinterpret_cast<const f32x4*>(&s_t[px][4 * (g < 3 ? g : 0)]);
+        if (g == 3) xb = f32x4{0.f, 0.f, 0.f, 0.f};           // channels 12..15 do not exist
+        f32x4 acc[3] = {bv[0], bv[1], bv[2]};
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int m = 0; m < 3; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[m][i], xb[i], acc[m], 0, 0, 0);
+        if (base + px < total) {
+#pragma unroll
+            for (int m = 0; m < 3; ++m) *reinterpret_cast<f32x4*>(out + (base + px) * kF + 16 * m + 4 * g) = acc[m];
+        }
+    }
 }
 
 // An upper bound of max |network input| per sequence, for the block floating point of the conv behind it (rvdd_internal.h),
@@ -761,13 +812,16 @@ hipError_t launch_warp3(const float* src4, const float* flow_raw, float* dst, in
 
 hipError_t launch_netin(const float* raw_cur, float* green_scratch, const float* prev4, const float* flow_prev,
                         const float* next4, const float* flow_next, float* netin, int B, int h, int w, hipStream_t s,
-                        int64_t raw_bstride, int64_t flow_bstride) {
+                        int64_t raw_bstride, int64_t flow_bstride, const float* proj_w16, const float* proj_b, float* proj_out) {
     const size_t n = (size_t)B * 4 * h * w;
     if (!n) return hipSuccess;
     const int64_t rbs = raw_bstride ? raw_bstride : (int64_t)4 * h * w, fbs = flow_bstride ? flow_bstride : (int64_t)2 * h * w;
     hipLaunchKernelGGL(ha_green_kernel, dim3(nblocks(n, 256)), dim3(256), 0, s, raw_cur, green_scratch, B, h, w, rbs);
-    hipLaunchKernelGGL(netin_kernel, dim3(nblocks(n, 256)), dim3(256), 0, s, raw_cur, green_scratch, prev4, flow_prev, next4,
-                       flow_next, netin, B, h, w, rbs, fbs);
+    const NetinArgs a{raw_cur, green_scratch, prev4, flow_prev, next4, flow_next, B, h, w, rbs, fbs};
+    if (proj_w16)
+        hipLaunchKernelGGL(netin_proj_kernel, dim3(nblocks(n, 256)), dim3(256), 0, s, a, proj_w16, proj_b, proj_out);
+    else
+        hipLaunchKernelGGL(netin_kernel, dim3(nblocks(n, 256)), dim3(256), 0, s, a, netin);
     return hipGetLastError();
 }
 

@@ -164,6 +164,7 @@ struct rvdd_handle {
     bool warp_async = false;
     hipEvent_t ev_wfork = nullptr, ev_wjoin = nullptr;
     bool warp_join_pending = false, warp_async_now = false;
+    bool netin_proj = false;      // lv[0].t[0] of the running step already holds the first ConvBlock's projection of the network input (run_prologue)
     bool featw_proj = false;      // `featw` of the running step holds W_f warp(features) + bias (run_prologue, next_pf_pre), not the warped features
     bool serpentine = false;      // sequence order of the current frame-step (flips every step when seq_major is on)
     std::map<std::string, HostTensor> staged;
@@ -947,6 +948,7 @@ int run_net(rvdd_t* h, const float* netin, const float* featw, float* feat_dst, 
     }
     const int B = h->cfg.batch;
     h->featw_proj = false;          // a caller's own features (rvdd_unet_forward) come as they are
+    h->netin_proj = false;          // and so does a caller's own network input
     if (prologue) RC(run_prologue(h, *prologue, Sub{0, B}, s));
     if (h->next_streams && !h->next_fused && B >= 2 && h->stream2) {
         // Two chains, one per half of the batch, on two streams.  The MLP kernel is bound by the matrix cores, the
@@ -1436,8 +1438,12 @@ int run_prologue(rvdd_t* h, const StepInputs& in, Sub sb, hipStream_t s) {
                                          zero_now ? zero_a : nullptr, zero_na, zero_now ? zero_b : nullptr, zero_nb));
             if (h->prev_noisy && !in.raw_prev) HIPCHK(h, launch_amax_reduce(h->lastden4 + o * img * 4, n, (int64_t)img * 4, amax_netin, s, 1));
         }
+        // ConvNeXtUnet: the input's only reader is the 1x1 projection of the first ConvBlock, which rides in the same kernel
+        const NextBlk* first = h->is_next() && h->next_projfuse ? &h->nx[h->has_feat() ? NX_PRE : NX_ENC0_0] : nullptr;
+        h->netin_proj = first != nullptr;
         HIPCHK(h, launch_netin(rc_, green, h->lastden4 + o * img * 4, fp_, next4, fn_, netin, n, H / 2, W / 2, s, (int64_t)in.rawf,
-                               (int64_t)in.flowf));
+                               (int64_t)in.flowf, first ? first->w.proj_w : nullptr, first ? first->w.proj_b : nullptr,
+                               first ? h->lv[0].t[0] + o * img * kF : nullptr));
     }
     if (h->has_feat() && !nw && !h->warp_async_now) {
         h->featw_proj = next_pf_pre(h);

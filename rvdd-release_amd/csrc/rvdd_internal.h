@@ -179,9 +179,12 @@ hipError_t launch_warp3(const float* src4, const float* flow_raw, float* dst, in
 // The NHWC16 network input of a step in one pass: warp3 of prev4 | demosaic of raw_cur | warp3 of next4 (or zeros when
 // next4 == nullptr); flows nullptr = --no_warp.  [B][4][h][w] raw, [B][2][h][w] flows, dense inside a sequence, with
 // raw_bstride / flow_bstride floats from one sequence to the next (0 = dense); green_scratch [B][2h][2w].
+// proj_w16 set (ConvNeXtUnet): the 16-channel map is not written; `proj_out` NHWC48 receives its 1x1 projection
+// proj_w16 / proj_b (launch_proj1x1's (16, 0) arrangement) instead (prestage.hip netin_proj_kernel)
 hipError_t launch_netin(const float* raw_cur, float* green_scratch, const float* prev4, const float* flow_prev,
                         const float* next4, const float* flow_next, float* netin, int B, int h, int w, hipStream_t s,
-                        int64_t raw_bstride = 0, int64_t flow_bstride = 0);
+                        int64_t raw_bstride = 0, int64_t flow_bstride = 0, const float* proj_w16 = nullptr,
+                        const float* proj_b = nullptr, float* proj_out = nullptr);
 // amax words of that network input (block floating point of the split-f16 convs, below): an upper bound from the packed raw
 // frames it is made of (up to three, each nullable) and from `prev_words`, words that bound the previous output (nullable)
 // (zero_a / zero_b, nullable: word ranges the kernel also clears -- the next step's amax words, runtime.hip)
