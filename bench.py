@@ -206,57 +206,129 @@ def host_cpu_share():
     return info
 
 
-def quick_config(name, steps, dev_index, online_flow=False):
-    """A short run of another configuration at its default batch: 1 warm-up step, `steps` timed steps (wall clock between
-    device synchronisations), HIP events around every 3rd launch of its dominant kernel.  Inputs synthetic, resident in HBM."""
+def flow_from_denoised(rt, den, raw_cur):
+    """validate.py:16-38 for B sequences: moving = channel mean of remosaick(previous output), target = channel mean of
+    the current packed raw frame, both mapped to [0,1] (library.py:67-68, :165-167) -> TV-L1 on the device."""
+    moving = ((den[:, 1, 0::2, 0::2] + den[:, 2, 0::2, 1::2]) + (den[:, 0, 1::2, 0::2] + den[:, 1, 1::2, 1::2])) * 0.125 + 0.5
+    target = raw_cur.mean(dim=1) * 0.5 + 0.5
+    return rt.tvl1flow_batch(target.contiguous(), moving.contiguous())
+
+
+def advance(rt, raw, fprev, fnext, outs, T, fut, online_flow):
+    """One group of B sequences in lockstep through all its frames: the loop of validate.py:73-88 (FirstOfVideo reset, then
+    set_input / test per frame), output frame t - 1 into outs[t - 1].  THE step of every run of this file, timed region or not."""
+    rt.reset()
+    for t in range(1, T - fut):
+        fp = fprev[t]
+        if online_flow and t > 1:
+            fp = flow_from_denoised(rt, outs[t - 2], raw[t])
+        rt.step(raw[t - 1] if t == 1 else None, raw[t], raw[t + 1] if fut else None, fp, fnext[t] if fut else None, out=outs[t - 1])
+
+
+def roofline_of(dom, k, config, arch, events_note):
+    """The `roofline` object of a kernel class from its event-timed launches (k: launches, avg_us, tflops, gbps, bytes_per_launch)."""
+    # HBM bytes per launch from the PMC passes of the same command (tools/gpu_profile.sh + tools/pmc_summary.py:
+    # average over ALL launches of the kernel in a frame-step, like the event sample); counters cannot be read
+    # from inside this process, so the last committed measurement is quoted together with its source file
+    traffic, traffic_src = None, None
+    try:
+        tj = json.load(open(os.path.join(REPO, "profiles", "traffic.json")))
+        ent = tj.get(config) or tj.get("C2" if config in ("C5", "C3") else config)      # C3 / C5: C2's maps and launch mix
+        traffic, traffic_src = ent["kernels"].get(dom), ent.get("source")
+    except Exception:
+        pass
+    factor = next((f for pre, f in EXECUTED_PER_ALGORITHMIC.items() if dom.startswith(pre)), 1.0)
+    executed = k["tflops"] * factor
+    split = dom.startswith("conv3x3h") or (dom == "convblock_kernel" and os.environ.get("RVDD_NEXT_SPLIT") != "0")
+    if dom == "convblock_kernel" and not split:
+        factor, executed = 1.0, k["tflops"]
+    peak = F16_PEAK_TFLOPS if split else FP32_PEAK_TFLOPS
+    # `achieved` / `frac`: ALGORITHMIC flops of the layer (SURVEY 8d: the direct conv's 2*9*Cin*Cout per pixel) over the
+    # measured launch time -- the contract's convention; `frac_executed_mfma` counts the MFMA flops the kernel issues
+    # (split products, K padding; Winograd executes fewer than algorithmic) and is the matrix pipe's utilisation;
+    # `frac_hbm` is the same launch against the 8 TB/s HBM roof
+    return {"bound": "mfma", "kernel": dom, "achieved": round(k["tflops"], 2), "peak": peak,
+            "unit": "TFLOP/s", "frac": round(k["tflops"] / peak, 4),
+            "frac_algorithmic": round(k["tflops"] / peak, 4),
+            "executed_mfma_tflops": round(executed, 2), "frac_executed_mfma": round(executed / peak, 4),
+            "frac_hbm": round(k["gbps"] / 8000.0, 4), "hbm_peak_gbps": 8000.0,
+            "traffic": traffic, "traffic_source": traffic_src,
+            "algorithmic_bytes_per_launch": round(k["bytes_per_launch"]),
+            "mfma_dtype": "f16 (f32 operands split hi + lo, f32 accumulation)" if split else "f32",
+            "hbm_gbps_algorithmic": round(k["gbps"], 1),
+            "what_is_executed": ("F16 MFMA flops the kernel executes in its two 1x1 convs (114 MFMAs per 16 pixels; the depth-wise 7x7, "
+                                 "LayerNorm and GELU run on the vector ALU and bound the kernel: DESIGN.md 4.3c)")
+                                if split and dom == "convblock_kernel" else
+                                "F16 MFMA flops the kernel executes: 3 MFMAs per product (hi.hi, hi.lo, lo.hi), K 432 padded to 448"
+                                if split else
+                                "MFMA flops the kernel executes (Winograd F(2x2,3x3): 16/36 of the direct conv's)"
+                                if factor != 1.0 else "the kernel's algorithmic flops (all executed on MFMA)",
+            "algorithmic_equiv_tflops": round(k["tflops"], 2),
+            "launches": k["launches"], "avg_launch_us": round(k["avg_us"], 2),
+            "events": events_note}
+
+
+def kernel_table(prof):
+    kernels = {}
+    for p in prof:
+        if p["launches"]:
+            kernels[p["name"]] = dict(launches=p["launches"], avg_us=1e3 * p["ms"] / p["launches"],
+                                      total_ms=p["ms"], tflops=(p["flops"] / (p["ms"] * 1e9)) if p["ms"] else 0.0,
+                                      gbps=(p["bytes"] / (p["ms"] * 1e6)) if p["ms"] else 0.0,
+                                      bytes_per_launch=p["bytes"] / p["launches"])
+    return kernels
+
+
+def quick_config(name, steps, dev_index, online_flow=False, batch=None):
+    """A short run of another configuration (default: at its default batch): 1 warm-up step, `steps` timed steps (wall clock
+    between device synchronisations) of the SAME loop the headline run times (advance), HIP events around every 3rd launch of
+    its dominant kernel and that kernel's `roofline`.  Inputs synthetic, resident in HBM."""
     import torch
     from safetensors.torch import load_file
     from rvdd_release_amd import synth
     from rvdd_release_amd.runtime import RvddRuntime
     arch, stem, fut, iso, H, W, T, B, gflop = CONFIGS[name]
+    B = batch or B
     dev = torch.device("cuda", dev_index)
     rt = RvddRuntime(arch, fut, B, H, W, dev_index)
     rt.load_state_dict(load_file(os.path.join(REPO, "weights", stem + ".safetensors")))
+    if online_flow:
+        rt.set_option("tvl1_async", 1)       # the flow batch stays on the stream: no host round trip per frame
     seqs = [synth.make_sequence(T, H, W, iso=iso, seed=1000 * int(name[1]) + b, device=str(dev)) for b in range(B)]
     raw = torch.stack([s.raw for s in seqs], 1).contiguous()
     fprev = torch.stack([s.flow_prev for s in seqs], 1).contiguous()
     fnext = torch.stack([s.flow_next for s in seqs], 1).contiguous() if fut else None
+    gt_last = torch.stack([s.gt[T - 1 - fut] for s in seqs], 0).contiguous()
     del seqs
     n_out = T - 1 - fut
-    out = torch.empty(B, 3, H, W, dtype=torch.float32, device=dev)
+    outs = torch.empty(n_out, B, 3, H, W, dtype=torch.float32, device=dev)
 
-    def one():
-        rt.reset()
-        for t in range(1, T - fut):
-            fp = fprev[t]
-            if online_flow and t > 1:      # validate.py:16-38: TV-L1 from the re-mosaicked previous output to the current raw frame
-                moving = ((out[:, 1, 0::2, 0::2] + out[:, 2, 0::2, 1::2]) + (out[:, 0, 1::2, 0::2] + out[:, 1, 1::2, 1::2])) * 0.125 + 0.5
-                fp = rt.tvl1flow_batch((raw[t].mean(dim=1) * 0.5 + 0.5).contiguous(), moving.contiguous())
-            rt.step(raw[t - 1] if t == 1 else None, raw[t], raw[t + 1] if fut else None, fp,
-                    fnext[t] if fut else None, out=out)
-
-    one()
+    advance(rt, raw, fprev, fnext, outs, T, fut, online_flow)
     torch.cuda.synchronize()
     rt.profile_select(DOMINANT[arch], EVENT_STRIDE)
     rt.profile_enable(True)
     t0 = time.perf_counter()
     for _ in range(steps):
-        one()
+        advance(rt, raw, fprev, fnext, outs, T, fut, online_flow)
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
-    prof = [p for p in rt.profile_read() if p["launches"] and p["name"] == DOMINANT[arch]]
+    kernels = kernel_table(rt.profile_read())
     rt.profile_enable(False)
+    psnr_last = rt.psnr_l1(outs[n_out - 1], gt_last)[1]      # (also the call that reads an asynchronous flow batch's control word)
+    finite = bool(torch.isfinite(outs).all())
     rt.close()
     res = {"workload": f"{name}: {DESCR[name]}" + (" -- with the flow towards the previous frame recomputed by TV-L1 from every previous "
                                                   "output inside the timed loop (validate.py --val_flow_from_denoised)" if online_flow else ""),
            "value": round(steps * n_out * B / el, 2), "unit": "frames/s",
            "ms_per_step": round(1e3 * el / steps, 3), "steps": steps, "warmup": 1, "sequences_in_lockstep": B,
-           "output_frames_per_step": n_out * B, "finite": bool(torch.isfinite(out).all())}
-    if prof:
-        res["dominant_kernel"] = prof[0]["name"]
-        res["avg_launch_us"] = round(1e3 * prof[0]["ms"] / prof[0]["launches"], 2)
-        res["launches_sampled"] = prof[0]["launches"]
-    del raw, fprev, fnext, out
+           "output_frames_per_step": n_out * B, "finite": finite, "task_psnr_db_last_frame": round(psnr_last, 3)}
+    dom = DOMINANT[arch]
+    if dom in kernels:
+        res["dominant_kernel"] = dom
+        res["avg_launch_us"] = round(kernels[dom]["avg_us"], 2)
+        res["launches_sampled"] = kernels[dom]["launches"]
+        res["roofline"] = roofline_of(dom, kernels[dom], name, arch, f"every {EVENT_STRIDE}rd launch (uniform over the launches of a frame-step)")
+    del raw, fprev, fnext, outs
     torch.cuda.empty_cache()
     return res
 
@@ -331,22 +403,12 @@ def main():
         del seqs
     outs = torch.empty(n_out, B, 3, H, W, dtype=torch.float32, device=dev)   # outputs of the group being advanced
 
-    def flow_from_denoised(den, raw_cur, rt=rt):
-        """validate.py:16-38 for B sequences: moving = channel mean of remosaick(previous output), target = channel mean of
-        the current packed raw frame, both mapped to [0,1] (library.py:67-68, :165-167) -> TV-L1 on the device."""
-        moving = ((den[:, 1, 0::2, 0::2] + den[:, 2, 0::2, 1::2]) + (den[:, 0, 1::2, 0::2] + den[:, 1, 1::2, 1::2])) * 0.125 + 0.5
-        target = raw_cur.mean(dim=1) * 0.5 + 0.5
-        return rt.tvl1flow_batch(target.contiguous(), moving.contiguous())
+    if args.online_flow and not stub:
+        rt.set_option("tvl1_async", 1)       # the flow batch stays on the stream: no host round trip per frame
 
     def one_step(rt=rt, outs=outs):
         for raw, fprev, fnext in inputs:
-            rt.reset()                                        # FirstOfVideo
-            for t in range(1, T - fut):
-                fp = fprev[t]
-                if args.online_flow and t > 1:
-                    fp = flow_from_denoised(outs[t - 2], raw[t], rt)
-                rt.step(raw[t - 1] if t == 1 else None, raw[t], raw[t + 1] if fut else None, fp,
-                        fnext[t] if fut else None, out=outs[t - 1])
+            advance(rt, raw, fprev, fnext, outs, T, fut, args.online_flow)
 
     def barrier():
         shard.barrier(dist, None if on_host else dev)
@@ -407,56 +469,11 @@ def main():
 
     # ---- roofline of the dominant kernel (HIP events around a uniform sample of its launches, this rank)
     roofline = None
-    kernels = {}
-    for p in prof:
-        if p["launches"]:
-            kernels[p["name"]] = dict(launches=p["launches"], avg_us=1e3 * p["ms"] / p["launches"],
-                                      total_ms=p["ms"], tflops=(p["flops"] / (p["ms"] * 1e9)) if p["ms"] else 0.0,
-                                      gbps=(p["bytes"] / (p["ms"] * 1e6)) if p["ms"] else 0.0,
-                                      bytes_per_launch=p["bytes"] / p["launches"])
+    kernels = kernel_table(prof)
     dom = DOMINANT[arch]
     if dom in kernels:
-        k = kernels[dom]
-        # HBM bytes per launch from the PMC passes of the same command (tools/gpu_profile.sh + tools/pmc_summary.py:
-        # average over ALL launches of the kernel in a frame-step, like the event sample); counters cannot be read
-        # from inside this process, so the last committed measurement is quoted together with its source file
-        traffic, traffic_src = None, None
-        try:
-            tj = json.load(open(os.path.join(REPO, "profiles", "traffic.json")))
-            ent = tj.get(config) or tj.get("C2" if config in ("C5", "C3") else config)      # C3 / C5: C2's maps and launch mix
-            traffic, traffic_src = ent["kernels"].get(dom), ent.get("source")
-        except Exception:
-            pass
-        factor = next((f for pre, f in EXECUTED_PER_ALGORITHMIC.items() if dom.startswith(pre)), 1.0)
-        executed = k["tflops"] * factor
-        split = dom.startswith("conv3x3h") or (dom == "convblock_kernel" and os.environ.get("RVDD_NEXT_SPLIT") != "0")
-        if dom == "convblock_kernel" and not split:
-            factor, executed = 1.0, k["tflops"]
-        peak = F16_PEAK_TFLOPS if split else FP32_PEAK_TFLOPS
-        # `achieved` / `frac`: ALGORITHMIC flops of the layer (the direct conv's 2*9*Cin*Cout per pixel) over the
-        # measured launch time -- the contract's convention; `frac_executed_mfma` counts the MFMA flops the kernel issues
-        # (split products, K padding; Winograd executes fewer than algorithmic) and is the matrix pipe's utilisation;
-        # `frac_hbm` is the same launch against the 8 TB/s HBM roof
-        roofline = {"bound": "mfma", "kernel": dom, "achieved": round(k["tflops"], 2), "peak": peak,
-                    "unit": "TFLOP/s", "frac": round(k["tflops"] / peak, 4),
-                    "frac_algorithmic": round(k["tflops"] / peak, 4),
-                    "executed_mfma_tflops": round(executed, 2), "frac_executed_mfma": round(executed / peak, 4),
-                    "frac_hbm": round(k["gbps"] / 8000.0, 4), "hbm_peak_gbps": 8000.0,
-                    "traffic": traffic, "traffic_source": traffic_src,
-                    "algorithmic_bytes_per_launch": round(k["bytes_per_launch"]),
-                    "mfma_dtype": "f16 (f32 operands split hi + lo, f32 accumulation)" if split else "f32",
-                    "hbm_gbps_algorithmic": round(k["gbps"], 1),
-                    "what_is_executed": ("F16 MFMA flops the kernel executes in its two 1x1 convs (114 MFMAs per 16 pixels; the depth-wise 7x7, "
-                                        "LayerNorm and GELU run on the vector ALU and bound the kernel: DESIGN.md 4.3c)")
-                                       if split and dom == "convblock_kernel" else
-                                       "F16 MFMA flops the kernel executes: 3 MFMAs per product (hi.hi, hi.lo, lo.hi), K 432 padded to 448"
-                                       if split else
-                                       "MFMA flops the kernel executes (Winograd F(2x2,3x3): 16/36 of the direct conv's)"
-                                       if factor != 1.0 else "the kernel's algorithmic flops (all executed on MFMA)",
-                    "algorithmic_equiv_tflops": round(k["tflops"], 2),
-                    "launches": k["launches"], "avg_launch_us": round(k["avg_us"], 2),
-                    "events": "every launch" if args.all_kernel_events else
-                              f"every {EVENT_STRIDE}rd launch (uniform over the launches of a frame-step)"}
+        roofline = roofline_of(dom, kernels[dom], config, arch, "every launch" if args.all_kernel_events else
+                               f"every {EVENT_STRIDE}rd launch (uniform over the launches of a frame-step)")
 
     # ---- the same workload on the kernels that multiply f32 operands directly (f32 MFMA): what the split-f16 matrix path
     # buys, and how far apart the two paths' frames are.  One GPU only, outside the timed region.
@@ -491,10 +508,12 @@ def main():
                 other[name] = quick_config(name, args.other_steps, dev_index)
             except Exception as e:          # a failure here must not take the headline line with it
                 other[name] = {"error": f"{type(e).__name__}: {e}"}
-        try:
-            other["C2_online_flow"] = quick_config("C2", args.other_steps, dev_index, online_flow=True)
-        except Exception as e:
-            other["C2_online_flow"] = {"error": f"{type(e).__name__}: {e}"}
+        # C1 as BASELINE.json states it: ONE sequence of 8 frames (the default batch above runs eight in lockstep)
+        for key, kw in (("C1_one_sequence", dict(name="C1", batch=1)), ("C2_online_flow", dict(name="C2", online_flow=True))):
+            try:
+                other[key] = quick_config(steps=args.other_steps * (8 if key.startswith("C1") else 1), dev_index=dev_index, **kw)
+            except Exception as e:
+                other[key] = {"error": f"{type(e).__name__}: {e}"}
 
     # ---- CPU baseline: the oracle on this host's cores, bounded sample, sequence 0
     cpu = None

@@ -212,6 +212,13 @@ int rvdd_srgb_metrics(rvdd_t* h, const uint8_t* a, const uint8_t* b, int32_t n, 
  *               next_split; same bits either way).
  *   "next_pool": 0 = with next_fused, MaxPool2d(2) in front of a DownConv (new_unet.py:200-204) as its own kernel instead
  *               of the fused block's epilogue (default 1; same bits either way).
+ *   "tvl1_async": 1 = rvdd_tvl1flow_batch called without iteration counts enqueues its launches on the stream and returns
+ *               (the flows are ready in stream order; nothing is read back, the stream is not synchronised): the form for a
+ *               caller that feeds the flows straight into rvdd_step on the same stream (validate.py's --val_flow_from_denoised loop
+ *               on the device).  The batch's control word -- set only if a grid barrier of the TV-L1 kernels gave up -- is then
+ *               read by the next call that synchronises anyway: rvdd_psnr_l1, a TV-L1 call that returns iteration counts or runs
+ *               with the option off, or this option set back to 0 (each reports RVDD_ERR_HIP then).  Default 0: the reference
+ *               bridge's behaviour (library.py:150-175 returns finished host arrays).
  *   "next_projfuse": 0 = the 96 -> 48 projection of the ConvBlock behind a concat (new_unet.py:85-88, 321-329) as its own
  *               kernel, instead of as two 48 -> 48 halves in the epilogues of the blocks that form the two concatenated maps
  *               (default 1 with the pipelined split-f16 block; the A/B reference: the same linear map, summed in another

@@ -202,6 +202,7 @@ struct rvdd_handle {
     float* scratch = nullptr;
     size_t scratch_bytes = 0;
     Tvl1Workspace* tvl1 = nullptr;   // cached for the last (nx, ny)
+    bool tvl1_async = false;         // option "tvl1_async": rvdd_tvl1flow_batch without iteration counts enqueues and returns (see rvdd.h)
 
     // hipGraph replay of a frame-step (see rvdd_step)
     struct StepKey {
@@ -1280,6 +1281,17 @@ int rvdd_set_option(rvdd_t* h, const char* name, int32_t value) {
         h->next_projfuse = value != 0;
         return RVDD_OK;
     }
+    if (std::strcmp(name, "tvl1_async") == 0) {
+        // 1 = rvdd_tvl1flow_batch without iteration counts enqueues its launches and returns; its control word is read by the next
+        // synchronising call.  0 switches back and reports what is pending now.
+        if (!value && h->tvl1) {
+            HIPCHK(h, hipDeviceSynchronize());
+            if (hipError_t e = tvl1_check(h->tvl1, nullptr); e != hipSuccess)
+                return fail(h, RVDD_ERR_HIP, "rvdd_set_option(tvl1_async, 0): a pending asynchronous flow batch failed: %s", hipGetErrorString(e));
+        }
+        h->tvl1_async = value != 0;
+        return RVDD_OK;
+    }
     if (std::strcmp(name, "next_streams") == 0) {
         // 0 = ConvNeXt's two-kernel blocks on the caller's stream only (A/B reference of the two half-batch chains)
         h->next_streams = value != 0 && h->stream2 != nullptr;
@@ -1336,7 +1348,7 @@ int rvdd_set_option(rvdd_t* h, const char* name, int32_t value) {
         h->split16 = value == 0;
         return RVDD_OK;
     }
-    return fail(h, RVDD_ERR_ARG, "rvdd_set_option: unknown option '%s' (known: no_warp, warp_raw, prev_noisy_frame, conv_kernel, seq_major, graphs, fuse_upsample, next_fused, next_split, next_pipe, next_pool, next_projfuse, next_streams, wino4, block_fp, conv_groups, fuse_pre, warp_async)", name);
+    return fail(h, RVDD_ERR_ARG, "rvdd_set_option: unknown option '%s' (known: no_warp, warp_raw, prev_noisy_frame, conv_kernel, seq_major, graphs, fuse_upsample, next_fused, next_split, next_pipe, next_pool, next_projfuse, next_streams, tvl1_async, wino4, block_fp, conv_groups, fuse_pre, warp_async)", name);
 }
 
 int rvdd_reset(rvdd_t* h) {
@@ -1635,6 +1647,8 @@ int rvdd_psnr_l1(rvdd_t* h, const float* den, const float* gt, int64_t count, fl
     double r[2];
     HIPCHK(h, hipMemcpyAsync(r, h->loss_result, sizeof r, hipMemcpyDeviceToHost, s));
     HIPCHK(h, hipStreamSynchronize(s));
+    if (hipError_t e = tvl1_check(h->tvl1, s); e != hipSuccess)       // an asynchronous flow batch in front of the frames just measured
+        return fail(h, RVDD_ERR_HIP, "rvdd_psnr_l1: an asynchronous rvdd_tvl1flow_batch before this call failed: %s", hipGetErrorString(e));
     out2[0] = (float)(100.0 * r[0] / (double)count);
     out2[1] = (float)(10.0 * std::log10(4.0 / (r[1] / (double)count)));
     return RVDD_OK;
@@ -1702,6 +1716,7 @@ int rvdd_tvl1flow(rvdd_t* h, const float* I0, const float* I1, float* u, int32_t
         return fail(h, RVDD_ERR_ARG, "rvdd_tvl1flow: image too skinny for its pyramid (the reference reads out of bounds at this size)");
     if (!h->tvl1 || tvl1_ws_nx(h->tvl1) != nx || tvl1_ws_ny(h->tvl1) != ny) {
         HIPCHK(h, hipDeviceSynchronize());
+        HIPCHK(h, tvl1_check(h->tvl1, static_cast<hipStream_t>(stream)));      // what an asynchronous batch on the old workspace left unread
         tvl1_free(h->tvl1);
         h->tvl1 = nullptr;
         HIPCHK(h, tvl1_alloc(&h->tvl1, nx, ny));
@@ -1756,12 +1771,13 @@ int rvdd_tvl1flow_batch(rvdd_t* h, const float* I0, const float* I1, float* u, i
         return fail(h, RVDD_ERR_ARG, "rvdd_tvl1flow_batch: image too skinny for its pyramid (the reference reads out of bounds at this size)");
     if (!h->tvl1 || tvl1_ws_nx(h->tvl1) != nx || tvl1_ws_ny(h->tvl1) != ny) {
         HIPCHK(h, hipDeviceSynchronize());
+        HIPCHK(h, tvl1_check(h->tvl1, static_cast<hipStream_t>(stream)));      // what an asynchronous batch on the old workspace left unread
         tvl1_free(h->tvl1);
         h->tvl1 = nullptr;
         HIPCHK(h, tvl1_alloc(&h->tvl1, nx, ny));
     }
     std::vector<int> it((size_t)n, 0);
-    HIPCHK(h, tvl1_run_batch(h->tvl1, I0, I1, u, n, static_cast<hipStream_t>(stream), iterations ? it.data() : nullptr));
+    HIPCHK(h, tvl1_run_batch(h->tvl1, I0, I1, u, n, static_cast<hipStream_t>(stream), iterations ? it.data() : nullptr, h->tvl1_async));
     if (iterations)
         for (int i = 0; i < n; ++i) iterations[i] = it[(size_t)i];
     return RVDD_OK;

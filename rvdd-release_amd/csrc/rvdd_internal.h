@@ -299,6 +299,7 @@ int tvl1_num_scales(int nx, int ny);
 bool tvl1_size_ok(int nx, int ny);   // false where the reference's own pyramid reads out of bounds (very skinny images)
 // I0, I1 [ny][nx] -> u [2][ny][nx]; synchronises the stream every few iterations (convergence peek)
 hipError_t tvl1_run(Tvl1Workspace* w, const float* I0, const float* I1, float* u, hipStream_t st, int* total_iters);
-hipError_t tvl1_run_batch(Tvl1Workspace* w, const float* I0, const float* I1, float* u, int n, hipStream_t st, int* iters);
+hipError_t tvl1_run_batch(Tvl1Workspace* w, const float* I0, const float* I1, float* u, int n, hipStream_t st, int* iters, bool async = false);
+hipError_t tvl1_check(Tvl1Workspace* w, hipStream_t st);      // what an asynchronous batch left unread (synchronises when something is pending)
 int tvl1_ws_nx(const Tvl1Workspace* w);
 int tvl1_ws_ny(const Tvl1Workspace* w);

@@ -1033,6 +1033,7 @@ struct Tvl1Workspace {
     int nx = 0, ny = 0, nscales = 0;
     std::vector<Tvl1LaneBufs> lanes;     // lane 0 at allocation, lane 1 with the first batch call
     int* abort_word = nullptr;
+    bool unchecked = false;              // launches of an asynchronous batch are in flight / done whose abort word nobody has read yet
     int cus = 0;
     unsigned epoch = 0;         // scale_kernel_patch: one per launch, the upper bits of its records' tags
     StateBufs state{};          // scale_kernel_mem only: allocated when the finest scale exceeds the register slots
@@ -1167,7 +1168,7 @@ static hipError_t tvl1_run_lanes(Tvl1Workspace* w, const float* I0, const float*
     } while (0)
     const int nx = w->nx, ny = w->ny, n0 = nx * ny;
     while ((int)w->lanes.size() < np) CK(tvl1_add_lane(w));
-    if (first) CK(hipMemsetAsync(w->abort_word, 0, sizeof(int), st));
+    if (first && !w->unchecked) CK(hipMemsetAsync(w->abort_word, 0, sizeof(int), st));      // (an unread abort stays set until somebody reads it)
     const double zsigma = (double)(float)(kZoomSigma0 * std::sqrt(1.0 / ((double)kZoom * (double)kZoom) - 1.0));
     // Pre-processing of all pairs together (blockIdx.z / .y = image / pair): normalisation to [0,255], pre-smoothing, pyramid.
     // The finest flow is the caller's buffer (fin): u(ny*nx) then v(ny*nx) per pair.
@@ -1375,6 +1376,7 @@ static hipError_t tvl1_run_lanes(Tvl1Workspace* w, const float* I0, const float*
         CK(hipMemcpyAsync(&ab, w->abort_word, sizeof ab, hipMemcpyDeviceToHost, st));
         for (int q = 0; q < np; ++q) CK(hipMemcpyAsync(c[q], w->lanes[q].ctl, 4 * sizeof(int), hipMemcpyDeviceToHost, st));
         CK(hipStreamSynchronize(st));
+        w->unchecked = false;
         if (ab) return hipErrorLaunchTimeOut;
 #ifdef RVDD_STAMPS
         if (std::getenv("RVDD_TVL1_STAMPS")) {
@@ -1399,14 +1401,33 @@ hipError_t tvl1_run(Tvl1Workspace* w, const float* I0, const float* I1, float* u
     return tvl1_run_lanes(w, I0, I1, u, 1, st, total_iters);
 }
 
-// n pairs of the same size, kMaxLanes at a time
-hipError_t tvl1_run_batch(Tvl1Workspace* w, const float* I0, const float* I1, float* u, int n, hipStream_t st, int* iters) {
+// n pairs of the same size, kMaxLanes at a time.  async (and no iteration counts wanted): nothing is read back and the stream
+// is not synchronised -- the flows are the stream's business, and a grid barrier that gave up (tvl1.hip grid_sync: never seen
+// outside fault injection) leaves the abort word set for tvl1_check, or for the next synchronous run, to report.
+hipError_t tvl1_run_batch(Tvl1Workspace* w, const float* I0, const float* I1, float* u, int n, hipStream_t st, int* iters, bool async) {
     const size_t n0 = (size_t)w->nx * w->ny;
+    async = async && !iters;
     for (int q = 0; q < n; q += kMaxLanes) {
         const int np = n - q < kMaxLanes ? n - q : kMaxLanes;
         hipError_t e = tvl1_run_lanes(w, I0 + q * n0, I1 + q * n0, u + q * 2 * n0, np, st, iters ? iters + q : nullptr, q == 0,
-                                      iters != nullptr || q + kMaxLanes >= n);
+                                      !async && (iters != nullptr || q + kMaxLanes >= n));
         if (e != hipSuccess) return e;
+        if (async) w->unchecked = true;
+    }
+    return hipSuccess;
+}
+
+// the deferred half of an asynchronous batch: synchronise the stream and read the abort word (a no-op when nothing is pending)
+hipError_t tvl1_check(Tvl1Workspace* w, hipStream_t st) {
+    if (!w || !w->unchecked) return hipSuccess;
+    int ab = 0;
+    hipError_t e = hipMemcpyAsync(&ab, w->abort_word, sizeof ab, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) return e;
+    w->unchecked = false;
+    if (ab) {
+        (void)hipMemsetAsync(w->abort_word, 0, sizeof(int), st);
+        return hipErrorLaunchTimeOut;
     }
     return hipSuccess;
 }
