@@ -975,6 +975,36 @@ const char* rvdd_version(void) { return "rvdd-hip 0.1 (gfx950)"; }
 
 const char* rvdd_last_error(const rvdd_t* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
 
+namespace {
+// stream2 and its fork / join events, on first use; false (and nothing half-made left behind) if the runtime refuses one
+bool second_stream(rvdd_t* h) {
+    if (h->stream2) return true;
+    if (hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_wfork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_wjoin, hipEventDisableTiming) != hipSuccess) {
+        (void)hipGetLastError();
+        if (h->stream2) (void)hipStreamDestroy(h->stream2);
+        h->stream2 = nullptr;
+        return false;
+    }
+    return true;
+}
+bool graph_stream(rvdd_t* h) {
+    if (h->gstream) return true;
+    if (hipStreamCreateWithFlags(&h->gstream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&h->g_in, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->g_out, hipEventDisableTiming) != hipSuccess) {
+        (void)hipGetLastError();
+        if (h->gstream) (void)hipStreamDestroy(h->gstream);
+        h->gstream = nullptr;
+        return false;
+    }
+    return true;
+}
+}  // namespace
+
 int rvdd_create(const rvdd_cfg* cfg, rvdd_t** out) {
     if (!cfg || !out) return fail(nullptr, RVDD_ERR_ARG, "rvdd_create: null argument");
     *out = nullptr;
@@ -1010,7 +1040,7 @@ int rvdd_create(const rvdd_cfg* cfg, rvdd_t** out) {
     if (const char* nsp = std::getenv("RVDD_NEXT_SPLIT")) h->next_split = std::atoi(nsp) != 0;
     if (const char* npp = std::getenv("RVDD_NEXT_PIPE")) h->next_pipe = std::atoi(npp) != 0;
     if (const char* npf = std::getenv("RVDD_NEXT_PROJFUSE")) h->next_projfuse = std::atoi(npf) != 0;
-    if (const char* ns = std::getenv("RVDD_NEXT_STREAMS")) h->next_streams = std::atoi(ns) != 0;
+    if (const char* ns = std::getenv("RVDD_NEXT_STREAMS")) h->next_streams = std::atoi(ns) != 0 && second_stream(h);
     if (const char* cv = std::getenv("RVDD_CONV")) {
         // f32 (the f32-MFMA kernels, direct or Winograd by launch size) | direct | winograd (that f32 kernel at every size) |
         // anything else = the default: split-f16 kernel for the 48-channel layers, f32 kernels by size for the rest
@@ -1053,23 +1083,12 @@ int rvdd_create(const rvdd_cfg* cfg, rvdd_t** out) {
     }
     (void)hipEventCreate(&h->t0);
     (void)hipEventCreate(&h->t1);
-    if (hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&h->ev_wfork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&h->ev_wjoin, hipEventDisableTiming) != hipSuccess) {
-        (void)hipGetLastError();
-        h->next_streams = false;
-    }
-    if (const char* wa = std::getenv("RVDD_WARP_ASYNC")) h->warp_async = std::atoi(wa) != 0;
-    if (!h->stream2 || !h->ev_wfork || !h->ev_wjoin) h->warp_async = false;
-    if (const char* gv = std::getenv("RVDD_GRAPH")) h->use_graphs = std::atoi(gv) != 0;
-    if (hipStreamCreateWithFlags(&h->gstream, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreateWithFlags(&h->g_in, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&h->g_out, hipEventDisableTiming) != hipSuccess) {
-        (void)hipGetLastError();
-        h->use_graphs = 0;
-    }
+    // The second stream (options next_streams, warp_async) and the capture stream (option graphs) are created when an option
+    // first asks for them, not here: every stream a process holds is a hardware queue the device's scheduler keeps mapped, and a
+    // handle that merely EXISTED beside another one made that one's cooperative TV-L1 launches and the kernels behind them
+    // 20 % slower (profiles/r05k_online_flow_two_handles.txt)
+    if (const char* wa = std::getenv("RVDD_WARP_ASYNC")) h->warp_async = std::atoi(wa) != 0 && second_stream(h);
+    if (const char* gv = std::getenv("RVDD_GRAPH")) h->use_graphs = std::atoi(gv) != 0 && graph_stream(h);
     *out = h;
     return RVDD_OK;
 }
@@ -1232,7 +1251,7 @@ int rvdd_set_option(rvdd_t* h, const char* name, int32_t value) {
         drop_graphs(h);            // a captured step has the options it was captured with
     }
     if (std::strcmp(name, "graphs") == 0) {
-        h->use_graphs = value != 0 && h->gstream != nullptr;
+        h->use_graphs = value != 0 && graph_stream(h);
         return RVDD_OK;
     }
     if (std::strcmp(name, "no_warp") == 0) {
@@ -1294,13 +1313,13 @@ int rvdd_set_option(rvdd_t* h, const char* name, int32_t value) {
     }
     if (std::strcmp(name, "next_streams") == 0) {
         // 0 = ConvNeXt's two-kernel blocks on the caller's stream only (A/B reference of the two half-batch chains)
-        h->next_streams = value != 0 && h->stream2 != nullptr;
+        h->next_streams = value != 0 && second_stream(h);
         return RVDD_OK;
     }
     if (std::strcmp(name, "warp_async") == 0) {
         // 1 = the feature warp on a second stream beside the network-input assembly and the net's first launch(es), instead of in
         // line on the caller's stream (measured: no gain; default 0; same bits)
-        h->warp_async = value != 0 && h->stream2 != nullptr && h->ev_wfork != nullptr && h->ev_wjoin != nullptr;
+        h->warp_async = value != 0 && second_stream(h);
         return RVDD_OK;
     }
     if (std::strcmp(name, "fuse_pre") == 0) {
