@@ -1249,8 +1249,8 @@ __global__ __launch_bounds__(512, 2) void convblock_pipe_kernel(const float* __r
             for (int j = 0; j < 3; ++j)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) acc[i][j] = *reinterpret_cast<const f32x4*>(Pl + 16 * j + 4 * g);
-#pragma unroll
             PSTAMP(0);
+#pragma unroll
             for (int j = 0; j < 3; ++j) {
                 // j = 0: chunks 0 and 1 have landed (requested together, a tile ago); j = 2: so has chunk 2, requested below
                 // when every front wave was done with chunk 0 (the wait inside fsync covers every request of this wave)
