@@ -223,9 +223,6 @@ int rvdd_srgb_metrics(rvdd_t* h, const uint8_t* a, const uint8_t* b, int32_t n, 
  *               kernel, instead of as two 48 -> 48 halves in the epilogues of the blocks that form the two concatenated maps
  *               (default 1 with the pipelined split-f16 block; the A/B reference: the same linear map, summed in another
  *               order).
- *   "warp_async": 1 = the bicubic warp of the recurrent features runs on a second stream beside the network-input assembly and
- *               the net's first launch(es) (it depends on the last step's features and the flow only) instead of in line on the
- *               caller's stream (default 0: measured, no gain on MI355X; same bits).
  *   "fuse_pre": 0 = preprocessing_layer (3x3, no activation, networks/unet.py:742) and the first source of EncoderConvs[0][0]
  *               (3x3, :743) run as the two convs they are, instead of as their composition -- ONE 5x5 conv of the network
  *               input plus a fix of the border ring, where the zero padding between the two layers matters (default 1, the
@@ -238,8 +235,6 @@ int rvdd_srgb_metrics(rvdd_t* h, const uint8_t* a, const uint8_t* b, int32_t n, 
  *               floating point; right only while every activation stays within 2^-14 .. 65504).  Default 1.
  *   "wino4":    1 / 2 = the plain and two-pass 48 -> 48 3x3 convs on the Winograd F(4x4,3x3) kernel where a launch has
  *               at least 400 units / at every size (measured slower than F(2x2,3x3) on MI355X; off; a few ulp apart).
- *   "next_streams": 1 = with next_fused = 0 and a batch of at least two sequences, the two halves of the batch run as
- *               two chains on two streams (measured: no gain; off).
  * Unknown names are an error. */
 int rvdd_set_option(rvdd_t* h, const char* name, int32_t value);
 

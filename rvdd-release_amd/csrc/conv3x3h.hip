@@ -708,6 +708,9 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3h_kernel(ConvArgs a) {
 #pragma unroll
     for (int j = 0; j < NOUT; ++j) store_prev(j);
     if (a.amax_out && amx_b >= 0) {
+        // (behind a barrier of its own: the group's first wave may still be reading Rl for the sequence that ended with the last
+        // tile -- amax_send(pend_b) above -- when the other waves arrive here)
+        gsync();
         const unsigned wm = wave_max_u32(__float_as_uint(amx));
         if (lane == 0) Rl[gw] = wm;
         gsync();

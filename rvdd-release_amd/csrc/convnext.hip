@@ -1655,7 +1655,7 @@ hipError_t launch_proj1x1(const float* in1, int c1, const float* in2, int c2, co
     return hipGetLastError();
 }
 
-hipError_t launch_next_dwln(const float* x, float* ln_out, const NextBlockW& w, int B, int H, int W, hipStream_t s, bool co) {
+hipError_t launch_next_dwln(const float* x, float* ln_out, const NextBlockW& w, int B, int H, int W, hipStream_t s) {
     if ((size_t)H * W * kF * 4 >= 0x80000000ull) return hipErrorInvalidValue;
     static std::atomic<uint64_t> attr{0};
     if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(dwln_kernel), E_LDS_BYTES, attr); e != hipSuccess)
@@ -1663,44 +1663,36 @@ hipError_t launch_next_dwln(const float* x, float* ln_out, const NextBlockW& w, 
     const int tx = (W + E_TW - 1) / E_TW, ty = (H + E_TH - 1) / E_TH;
     const int ntiles = B * tx * ty;
     // persistent: two workgroups per CU (LDS), never more blocks than tiles; the XCD band map needs a multiple of 8
-    // (co: one per CU, beside a workgroup of the other chain's MLP kernel)
-    const int grid = ((std::min(ntiles, (co ? 1 : 2) * num_cus()) + 7) / 8) * 8;
+    const int grid = ((std::min(ntiles, 2 * num_cus()) + 7) / 8) * 8;
     hipLaunchKernelGGL(dwln_kernel, dim3(grid), dim3(256), E_LDS_BYTES, s, x, w.dw_w, w.dw_b, w.ln_w, w.ln_b, ln_out, B, H, W,
                        tx, ty, ntiles);
     return hipGetLastError();
 }
 
-template <bool OUT3, int NW>
+template <bool OUT3>
 static hipError_t launch_mlp(const float* ln, const float* x, float* out, const NextBlockW& w, int64_t npix, Out3 o3, hipStream_t s) {
     // one 16-pixel group per wave iteration, eight waves per workgroup: measured against <2, 4> and <1, 4>
-    // (profiles/r02_k_mlp_variants.json); NW = 4 (one wave per SIMD) when the kernel shares its CUs with the
-    // depth-wise kernel of the other half-batch chain
-    constexpr int NPB = 1;
+    // (profiles/r02_k_mlp_variants.json)
+    constexpr int NPB = 1, NW = 8;
     static std::atomic<uint64_t> attr{0};
     if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(mlp_kernel<NPB, NW, OUT3>), M2_LDS_BYTES, attr); e != hipSuccess)
         return e;
     const long nblk = (npix + 16 * NPB - 1) / (16 * NPB);
     const long blocks = std::min<long>((nblk + NW - 1) / NW, num_cus());
-    // alone on its CUs the kernel asks for more than half the LDS (one workgroup per CU); beside the depth-wise kernel
-    // of the other chain (NW = 4) only for what it uses, so that the two fit together: 75.5 + 75.8 KiB of 160
-    const size_t lds = NW == 4 ? (size_t)(2 * M_W_FLOATS + M2_BV_FLOATS + 148) * 4 : M2_LDS_BYTES;
-    hipLaunchKernelGGL((mlp_kernel<NPB, NW, OUT3>), dim3((unsigned)blocks), dim3(64 * NW), lds, s, ln, x, w.fc1_w,
+    hipLaunchKernelGGL((mlp_kernel<NPB, NW, OUT3>), dim3((unsigned)blocks), dim3(64 * NW), M2_LDS_BYTES, s, ln, x, w.fc1_w,
                        w.fc1_b, w.fc2_w, w.fc2_b, w.ls, out, (long)npix, o3);
     return hipGetLastError();
 }
 
-hipError_t launch_next_mlp(const float* ln, const float* x, float* out, const NextBlockW& w, int64_t npix,
-                           hipStream_t s, bool co) {
+hipError_t launch_next_mlp(const float* ln, const float* x, float* out, const NextBlockW& w, int64_t npix, hipStream_t s) {
     if (npix <= 0) return hipSuccess;
-    return co ? launch_mlp<false, 4>(ln, x, out, w, npix, Out3{}, s) : launch_mlp<false, 8>(ln, x, out, w, npix, Out3{}, s);
+    return launch_mlp<false>(ln, x, out, w, npix, Out3{}, s);
 }
 
 hipError_t launch_next_mlp_out3(const float* ln, const float* x, float* out, const NextBlockW& w, int64_t npix,
-                                const float* w3x48, const float* b3, float* out_nchw, float* out_nhwc4, int hw,
-                                hipStream_t s, bool co) {
+                                const float* w3x48, const float* b3, float* out_nchw, float* out_nhwc4, int hw, hipStream_t s) {
     if (npix <= 0) return hipSuccess;
-    const Out3 o3{w3x48, b3, out_nchw, out_nhwc4, hw};
-    return co ? launch_mlp<true, 4>(ln, x, out, w, npix, o3, s) : launch_mlp<true, 8>(ln, x, out, w, npix, o3, s);
+    return launch_mlp<true>(ln, x, out, w, npix, Out3{w3x48, b3, out_nchw, out_nhwc4, hw}, s);
 }
 
 template <bool OUT3, bool POOL, bool SPLIT>

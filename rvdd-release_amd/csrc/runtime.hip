@@ -154,16 +154,6 @@ struct rvdd_handle {
     bool next_pool = true;        // ConvNeXt, fused blocks: MaxPool2d(2) from the epilogue of the block in front of a DownConv
     bool next_projfuse = true;    // ConvNeXt, pipelined split-f16 blocks: the 96 -> 48 projection behind a concat as two halves in the epilogues of
                                   // the blocks that form the concatenated maps (RVDD_NEXT_PROJFUSE=0 / option "next_projfuse" 0: proj1x1_kernel)
-    bool next_streams = false;    // ConvNeXt, two-kernel blocks, B >= 2: the two halves of the batch as two chains on two streams (measured: no gain)
-    hipStream_t stream2 = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    // The feature warp of a step depends on the last step's features and the flow only; the net reads its result in its second
-    // (convunet) / third (ConvNeXt) launch.  It runs on stream2 beside the network-input assembly and the first launch(es):
-    // a texture-path-bound gather beside kernels that leave that path alone.  Measured (profiles/r04_warp_async_ab.txt): C2 718.7
-    // against 716.5 frames/s, C4 351.8 against 352.7 -- nothing; off by default (RVDD_WARP_ASYNC=1 / option "warp_async" 1).
-    bool warp_async = false;
-    hipEvent_t ev_wfork = nullptr, ev_wjoin = nullptr;
-    bool warp_join_pending = false, warp_async_now = false;
     bool netin_proj = false;      // lv[0].t[0] of the running step already holds the first ConvBlock's projection of the network input (run_prologue)
     bool featw_proj = false;      // `featw` of the running step holds W_f warp(features) + bias (run_prologue, next_pf_pre), not the warped features
     bool serpentine = false;      // sequence order of the current frame-step (flips every step when seq_major is on)
@@ -623,13 +613,6 @@ const char* conv_name_h(int epi, bool acc) {
     return names[epi][acc];
 }
 
-// Before the first launch that reads the warped features: wait for the warp the prologue started on the second stream.
-int join_warp(rvdd_t* h, hipStream_t s) {
-    if (!h->warp_join_pending) return RVDD_OK;
-    h->warp_join_pending = false;
-    HIPCHK(h, hipStreamWaitEvent(s, h->ev_wjoin, 0));
-    return RVDD_OK;
-}
 
 // the amax words (rvdd_internal.h) of map `slot`, from sequence b0 on
 unsigned* amax_words(const rvdd_t* h, int slot, size_t b0 = 0) { return h->amax + ((size_t)slot * h->cfg.batch + b0) * kAmaxSeqWords; }
@@ -827,14 +810,12 @@ int run_convunet(rvdd_t* h, const float* netin, const float* featw, float* feat_
             // preprocessing_layer (:742, no activation) and the first source of EncoderConvs[0][0] (:743) as ONE 5x5 conv of the
             // network input (compose_pre_enc0), its border ring put right, then the second source (the old features) as before
             RC(run_pre5(h, netin, lv[0].part, s, sb));
-            RC(join_warp(h, s));
             ConvCall c;
             c.in = featw; c.src = 1; c.acc_in = lv[0].part; c.out = lv[0].t[1]; c.H = lv[0].H; c.W = lv[0].W; c.epi = EPI_RELU;
             c.amax_in = h->amax_feat_in; c.amax_out = L(CU_ENC0_0);
             RC(run_conv(h, cu[CU_ENC0_0], c, s, sb));
         } else if (feat) {
             RC(conv(CU_PRE, netin, AMAX_NETIN, lv[0].t[0], 0, EPI_NONE, sb));               // :742 (no activation)
-            RC(join_warp(h, s));
             RC(conv2(CU_ENC0_0, lv[0].t[0], L(CU_PRE), featw, h->amax_feat_in, lv[0].t[1], 0, sb)); // cat[y, old_features] :743
         } else {
             RC(conv(CU_ENC0_0, netin, AMAX_NETIN, lv[0].t[1], 0, EPI_RELU, sb));
@@ -943,28 +924,13 @@ namespace {
 int run_net(rvdd_t* h, const float* netin, const float* featw, float* feat_dst, float* out_nchw,
             float* out_nhwc4, hipStream_t s, const StepInputs* prologue) {
     if (!h->is_next()) {
-        const int rc = run_convunet(h, netin, featw, feat_dst, out_nchw, out_nhwc4, s, prologue);
-        const int rj = join_warp(h, s);          // (a no-op when the net has read the warped features, as it always has)
-        return rc ? rc : rj;
+        return run_convunet(h, netin, featw, feat_dst, out_nchw, out_nhwc4, s, prologue);
     }
     const int B = h->cfg.batch;
     h->featw_proj = false;          // a caller's own features (rvdd_unet_forward) come as they are
     h->netin_proj = false;          // and so does a caller's own network input
     if (prologue) RC(run_prologue(h, *prologue, Sub{0, B}, s));
-    if (h->next_streams && !h->next_fused && B >= 2 && h->stream2) {
-        // Two chains, one per half of the batch, on two streams.  The MLP kernel is bound by the matrix cores, the
-        // depth-wise kernel by latencies (its waves wait 58 % of their time): with one workgroup of each resident per
-        // CU the second fills the first's issue slots.  The MLP kernels of the two chains cannot share a CU (LDS), so
-        // the chains fall out of phase by themselves: A's depth-wise kernel beside B's MLP, then the reverse.
-        HIPCHK(h, hipEventRecord(h->ev_fork, s));
-        HIPCHK(h, hipStreamWaitEvent(h->stream2, h->ev_fork, 0));
-        RC(run_convnext(h, netin, featw, feat_dst, out_nchw, out_nhwc4, s, Sub{0, B / 2}, true));
-        RC(run_convnext(h, netin, featw, feat_dst, out_nchw, out_nhwc4, h->stream2, Sub{B / 2, B - B / 2}, true));
-        HIPCHK(h, hipEventRecord(h->ev_join, h->stream2));
-        HIPCHK(h, hipStreamWaitEvent(s, h->ev_join, 0));
-        return RVDD_OK;
-    }
-    return run_convnext(h, netin, featw, feat_dst, out_nchw, out_nhwc4, s, Sub{0, B}, false);
+    return run_convnext(h, netin, featw, feat_dst, out_nchw, out_nhwc4, s, Sub{0, B});
 }
 }  // namespace
 
@@ -976,21 +942,6 @@ const char* rvdd_version(void) { return "rvdd-hip 0.1 (gfx950)"; }
 const char* rvdd_last_error(const rvdd_t* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
 
 namespace {
-// stream2 and its fork / join events, on first use; false (and nothing half-made left behind) if the runtime refuses one
-bool second_stream(rvdd_t* h) {
-    if (h->stream2) return true;
-    if (hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&h->ev_wfork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&h->ev_wjoin, hipEventDisableTiming) != hipSuccess) {
-        (void)hipGetLastError();
-        if (h->stream2) (void)hipStreamDestroy(h->stream2);
-        h->stream2 = nullptr;
-        return false;
-    }
-    return true;
-}
 bool graph_stream(rvdd_t* h) {
     if (h->gstream) return true;
     if (hipStreamCreateWithFlags(&h->gstream, hipStreamNonBlocking) != hipSuccess ||
@@ -1040,7 +991,6 @@ int rvdd_create(const rvdd_cfg* cfg, rvdd_t** out) {
     if (const char* nsp = std::getenv("RVDD_NEXT_SPLIT")) h->next_split = std::atoi(nsp) != 0;
     if (const char* npp = std::getenv("RVDD_NEXT_PIPE")) h->next_pipe = std::atoi(npp) != 0;
     if (const char* npf = std::getenv("RVDD_NEXT_PROJFUSE")) h->next_projfuse = std::atoi(npf) != 0;
-    if (const char* ns = std::getenv("RVDD_NEXT_STREAMS")) h->next_streams = std::atoi(ns) != 0 && second_stream(h);
     if (const char* cv = std::getenv("RVDD_CONV")) {
         // f32 (the f32-MFMA kernels, direct or Winograd by launch size) | direct | winograd (that f32 kernel at every size) |
         // anything else = the default: split-f16 kernel for the 48-channel layers, f32 kernels by size for the rest
@@ -1083,11 +1033,10 @@ int rvdd_create(const rvdd_cfg* cfg, rvdd_t** out) {
     }
     (void)hipEventCreate(&h->t0);
     (void)hipEventCreate(&h->t1);
-    // The second stream (options next_streams, warp_async) and the capture stream (option graphs) are created when an option
-    // first asks for them, not here: every stream a process holds is a hardware queue the device's scheduler keeps mapped, and a
-    // handle that merely EXISTED beside another one made that one's cooperative TV-L1 launches and the kernels behind them
-    // 20 % slower (profiles/r05k_online_flow_two_handles.txt)
-    if (const char* wa = std::getenv("RVDD_WARP_ASYNC")) h->warp_async = std::atoi(wa) != 0 && second_stream(h);
+    // The capture stream (option graphs) is created when the option first asks for it, not here: every stream a process holds is a
+    // hardware queue the device's scheduler keeps mapped, and a handle that merely EXISTED beside another one -- with the two idle
+    // streams every handle used to create -- made that one's cooperative TV-L1 launches and the kernels behind them 20 % slower
+    // (profiles/r05k_online_flow_two_handles.txt)
     if (const char* gv = std::getenv("RVDD_GRAPH")) h->use_graphs = std::atoi(gv) != 0 && graph_stream(h);
     *out = h;
     return RVDD_OK;
@@ -1101,11 +1050,6 @@ void rvdd_destroy(rvdd_t* h) {
     if (h->g_in) (void)hipEventDestroy(h->g_in);
     if (h->g_out) (void)hipEventDestroy(h->g_out);
     if (h->gstream) (void)hipStreamDestroy(h->gstream);
-    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
-    if (h->ev_join) (void)hipEventDestroy(h->ev_join);
-    if (h->ev_wfork) (void)hipEventDestroy(h->ev_wfork);
-    if (h->ev_wjoin) (void)hipEventDestroy(h->ev_wjoin);
-    if (h->stream2) (void)hipStreamDestroy(h->stream2);
     for (void* p : h->allocs) (void)hipFree(p);
     if (h->scratch) (void)hipFree(h->scratch);
     tvl1_free(h->tvl1);
@@ -1311,17 +1255,6 @@ int rvdd_set_option(rvdd_t* h, const char* name, int32_t value) {
         h->tvl1_async = value != 0;
         return RVDD_OK;
     }
-    if (std::strcmp(name, "next_streams") == 0) {
-        // 0 = ConvNeXt's two-kernel blocks on the caller's stream only (A/B reference of the two half-batch chains)
-        h->next_streams = value != 0 && second_stream(h);
-        return RVDD_OK;
-    }
-    if (std::strcmp(name, "warp_async") == 0) {
-        // 1 = the feature warp on a second stream beside the network-input assembly and the net's first launch(es), instead of in
-        // line on the caller's stream (measured: no gain; default 0; same bits)
-        h->warp_async = value != 0 && second_stream(h);
-        return RVDD_OK;
-    }
     if (std::strcmp(name, "fuse_pre") == 0) {
         // 0 = preprocessing_layer and EncoderConvs[0][0] as the two convs they are, instead of their composition (the A/B
         // reference: same map up to fp32 rounding of a different summation order)
@@ -1367,7 +1300,7 @@ int rvdd_set_option(rvdd_t* h, const char* name, int32_t value) {
         h->split16 = value == 0;
         return RVDD_OK;
     }
-    return fail(h, RVDD_ERR_ARG, "rvdd_set_option: unknown option '%s' (known: no_warp, warp_raw, prev_noisy_frame, conv_kernel, seq_major, graphs, fuse_upsample, next_fused, next_split, next_pipe, next_pool, next_projfuse, next_streams, tvl1_async, wino4, block_fp, conv_groups, fuse_pre, warp_async)", name);
+    return fail(h, RVDD_ERR_ARG, "rvdd_set_option: unknown option '%s' (known: no_warp, warp_raw, prev_noisy_frame, conv_kernel, seq_major, graphs, fuse_upsample, next_fused, next_split, next_pipe, next_pool, next_projfuse, tvl1_async, wino4, block_fp, conv_groups, fuse_pre)", name);
 }
 
 int rvdd_reset(rvdd_t* h) {
@@ -1395,24 +1328,6 @@ int run_prologue(rvdd_t* h, const StepInputs& in, Sub sb, hipStream_t s) {
     float* green = h->green + o * img;
     float* netin = h->netin + o * img * kNetInC;
     // amax words of the maps the split-f16 convs read first (block floating point, rvdd_internal.h)
-    // the feature warp first, on the second stream (see rvdd_handle::warp_async): it waits for what the caller's stream has
-    // done so far (the last step, which wrote the features it gathers from), the net waits for it where it reads `featw`
-    h->warp_async_now = h->warp_async && h->has_feat() && !nw && !h->warp_raw && h->stream2 && sb.b0 == 0 && sb.nb == h->cfg.batch;
-    if (h->warp_async_now) {
-        HIPCHK(h, hipEventRecord(h->ev_wfork, s));
-        HIPCHK(h, hipStreamWaitEvent(h->stream2, h->ev_wfork, 0));
-        {
-            Scope sc(h, h->stream2, "warp48_kernel", 0.0, (double)n * img * (384.0 + 2.0));
-            h->featw_proj = next_pf_pre(h);
-            if (h->featw_proj)
-                HIPCHK(h, launch_warp48_proj(h->lastfeat, fp_, h->featw, n, H, W, h->nx[NX_ENC0_0].w.proj_w, h->nx[NX_ENC0_0].w.proj_b,
-                                             h->stream2, (int64_t)in.flowf));
-            else
-                HIPCHK(h, launch_warp48(h->lastfeat, fp_, h->featw, n, H, W, h->stream2, (int64_t)in.flowf));
-        }
-        HIPCHK(h, hipEventRecord(h->ev_wjoin, h->stream2));
-        h->warp_join_pending = true;
-    }
     const bool bfp = h->bfp && h->split16 && !h->is_next();
     unsigned* amax_netin = bfp ? amax_words(h, h->amax_base + AMAX_REL_NETIN, o) : nullptr;
     // the zeroing for the step after this one rides in the first netin_bound launch of the step; a step without one memsets
@@ -1476,7 +1391,7 @@ int run_prologue(rvdd_t* h, const StepInputs& in, Sub sb, hipStream_t s) {
                                (int64_t)in.flowf, first ? first->w.proj_w : nullptr, first ? first->w.proj_b : nullptr,
                                first ? h->lv[0].t[0] + o * img * kF : nullptr));
     }
-    if (h->has_feat() && !nw && !h->warp_async_now) {
+    if (h->has_feat() && !nw) {
         h->featw_proj = next_pf_pre(h);
         Scope sc(h, s, "warp48_kernel", h->featw_proj ? 2.0 * 48 * 48 * n * img : 0.0, (double)n * img * (384.0 + 2.0));
         if (h->featw_proj)
@@ -1640,18 +1555,19 @@ int rvdd_set_state(rvdd_t* h, const float* lastden, const float* lastfeat, void*
     ENTER(h);
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int B = h->cfg.batch, H = h->cfg.height, W = h->cfg.width;
+    if (lastfeat && !h->has_feat()) return fail(h, RVDD_ERR_ARG, "rvdd_set_state: this architecture has no recurrent features");
     if (lastden) {
         HIPCHK(h, launch_nchw_to_nhwc(lastden, h->lastden4, B, 3, H, W, 4, s));
         h->need_init = false;
     }
-    if (lastfeat) {
-        if (!h->has_feat()) return fail(h, RVDD_ERR_ARG, "rvdd_set_state: this architecture has no recurrent features");
-        HIPCHK(h, launch_nchw_to_nhwc(lastfeat, h->lastfeat, B, kF, H, W, kF, s));
-        if (h->bfp && h->split16 && !h->is_next()) {      // the words the next step reads for these features (block floating point)
-            unsigned* w = amax_words(h, AMAX_FEAT0 + (h->step_ctr + 2) % 3);
-            HIPCHK(h, hipMemsetAsync(w, 0, amax_bytes(B, 1), s));
-            HIPCHK(h, launch_amax_reduce(h->lastfeat, B, (int64_t)H * W * kF, w, s));
-        }
+    if (lastfeat) HIPCHK(h, launch_nchw_to_nhwc(lastfeat, h->lastfeat, B, kF, H, W, kF, s));
+    if ((lastden || lastfeat) && h->bfp && h->split16 && !h->is_next()) {
+        // The words the next step reads as the bound of "the previous output" (block floating point): features and output frame
+        // together, as PostConvs leaves them -- rebuilt from the state as it now stands, whichever half the caller replaced
+        unsigned* w = amax_words(h, AMAX_FEAT0 + (h->step_ctr + 2) % 3);
+        HIPCHK(h, hipMemsetAsync(w, 0, amax_bytes(B, 1), s));
+        if (h->has_feat()) HIPCHK(h, launch_amax_reduce(h->lastfeat, B, (int64_t)H * W * kF, w, s));
+        HIPCHK(h, launch_amax_reduce(h->lastden4, B, (int64_t)H * W * 4, w, s));
     }
     return RVDD_OK;
 }

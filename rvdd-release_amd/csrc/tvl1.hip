@@ -405,6 +405,7 @@ struct Lane {
 struct Lanes {
     Lane l[kMaxLanes];
     int gp;             // blocks per lane
+    int cus;            // compute units of the device: blocks numbered from here on are the second block of their CU (speed heuristic only)
     int* abort_word;    // shared: a barrier that gave up in any lane ends the launch
 };
 __device__ __forceinline__ float bld(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
@@ -701,7 +702,7 @@ __global__ __launch_bounds__(NT) void scale_kernel_patch(Lanes lanes, unsigned e
             // Two blocks on a CU: the older one wins the issue slots whenever both compute, and the lane that holds the younger
             // blocks sets the launch's pace.  Every other iteration the younger block is given the higher priority instead.
             // (launches of two lanes, i.e. 640x360: with more lanes the pace is set by the lane with the most iterations, wherever it sits)
-            if (blockIdx.x >= 256u && par && gridDim.x == 2u * gp) __builtin_amdgcn_s_setprio(1);
+            if (blockIdx.x >= (unsigned)lanes.cus && par && gridDim.x == 2u * gp) __builtin_amdgcn_s_setprio(1);
             else __builtin_amdgcn_s_setprio(0);
             unsigned long long esum = 0;
             float u1s[T], u2s[T];                // u of iteration n - 1: this update is undone if that one turns out to have converged
@@ -1256,6 +1257,7 @@ static hipError_t tvl1_run_lanes(Tvl1Workspace* w, const float* I0, const float*
     auto launch_scale = [&](int s, int q0, int cnt) -> hipError_t {
         Lanes lanes{};
         lanes.abort_word = w->abort_word;
+        lanes.cus = w->cus;
         for (int q = 0; q < cnt; ++q) {
             Tvl1LaneBufs& L = w->lanes[q0 + q];
             Scale sc = L.sc[s];

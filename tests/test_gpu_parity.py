@@ -880,6 +880,43 @@ def test_split_path_any_magnitude(arch, stem, fut, mag):
         assert err < 1e-4 * scale, (arch, mag, t, err, scale)
 
 
+@pytest.mark.parametrize("arch,stem", [("convunet", "recurrent-convunet-iso3200"), ("convunet+feat", "recurrent-convunet+feat-iso3200")])
+def test_set_state_previous_output_of_another_magnitude(arch, stem):
+    """rvdd_set_state(lastden) hands in a previous output the runtime did not produce: the bound of max |network input| that the
+    block floating point of the first convs rests on (netin_bound_kernel: raw frames + the words PostConvs left) must follow it.
+    A previous output 4096 times brighter than the raw frames, alone and with features of that magnitude: the next frame within
+    1e-4 of the oracle relative to its max-abs."""
+    from rvdd_release_amd import synth
+    from rvdd_release_amd.runtime import RvddRuntime
+    sd = load_weights(stem)
+    feat = arch.endswith("feat")
+    H, W = 64, 96
+    s = synth.make_sequence(3, H, W, iso=3200, seed=9, device="cuda")
+    rt = RvddRuntime(arch, 0, 1, H, W, 0)
+    rt.load_state_dict(sd)
+    orc = O.RecurrentOracle(sd, future=0)
+    rt.step(s.raw[0][None], s.raw[1][None], None, s.flow_prev[1][None], None)
+    orc.step(s.raw[0][None].cpu(), s.raw[1][None].cpu(), None, s.flow_prev[1][None].cpu(), None, first=True)
+    den, f = rt.get_state()
+    for with_feat in ((False, True) if feat else (False,)):
+        big_den = den * 4096.0
+        big_f = f * 4096.0 if with_feat else None
+        rt.set_state(big_den, big_f)
+        orc.lastden = big_den.cpu()
+        if feat:
+            orc.lastfeat = (big_f if with_feat else f).cpu()
+        got = rt.step(None, s.raw[2][None], None, s.flow_prev[2][None], None).clone().cpu()
+        ref = orc.step(s.raw[1][None].cpu(), s.raw[2][None].cpu(), None, s.flow_prev[2][None].cpu(), None, first=False)
+        assert torch.isfinite(got).all()
+        scale = float(ref.abs().max())
+        assert float((got - ref).abs().max()) < 1e-4 * scale, (arch, with_feat, float((got - ref).abs().max()), scale)
+        rt.set_state(den, f if feat else None)           # back to the state after step 1 for the next variant
+        orc.lastden = den.cpu()
+        if feat:
+            orc.lastfeat = f.cpu()
+    rt.close()
+
+
 def test_split_path_mixed_magnitudes_in_one_batch():
     """Block floating point is per map AND per sequence: three sequences of one batch a factor 1e5 and 2^-10 apart.  Each is
     within 1e-4 of its own oracle relative to its own max-abs, and bit for bit what it is when it runs alone (a workgroup whose
