@@ -30,9 +30,15 @@ rep('''                if (j >= SH && j - SH < G::NR) fetch_round(qn, j - SH);''
     '''#if !(RVDD_XP & 2)
                 if (j >= SH && j - SH < G::NR) fetch_round(qn, j - SH);
 #endif''')
+# 128 (round 5): the halo pieces arrive already split -- loads and staging stores stay, the split's instructions go (the two
+# halves of the loaded piece stand in for hi and lo)
 rep('''                        split4<SC>(pre[r0], sc_nxt, shi[r0], slo[r0]);
                         asm volatile("" : "+v"(shi[r0]), "+v"(slo[r0]));''',
-    '''#if !(RVDD_XP & 2)
+    '''#if RVDD_XP & 128
+                        shi[r0] = u32x2{__builtin_bit_cast(unsigned, pre[r0][0]), __builtin_bit_cast(unsigned, pre[r0][1])};
+                        slo[r0] = u32x2{__builtin_bit_cast(unsigned, pre[r0][2]), __builtin_bit_cast(unsigned, pre[r0][3])};
+                        asm volatile("" : "+v"(shi[r0]), "+v"(slo[r0]));
+#elif !(RVDD_XP & 2)
                         split4<SC>(pre[r0], sc_nxt, shi[r0], slo[r0]);
                         asm volatile("" : "+v"(shi[r0]), "+v"(slo[r0]));
 #endif''')
@@ -77,6 +83,20 @@ rep('''    auto gsync = [&]() {
         return;
 #endif
         if constexpr (NGRP == 1) {''')
+# 64 (round 5): the PRODUCER's share of a pre-split map -- every 16-B piece the epilogue hands to the stores is split into its f16
+# halves (split4) and the halves of two neighbouring channel groups change lanes (two v_permlane16_swap), so that a lane again
+# stores one 16-B piece ([hi of 8 channels] or [lo of 8 channels]); with bit 2 (no input side in the consumer) this is the UPPER
+# bound of "maps stored split, halo by LDS-DMA" (VERDICT r4 item 3): the DMA itself and its addresses are still missing
+rep('''                    outv[nt * 3 + mt] = x;''', '''#if RVDD_XP & 64
+                    {
+                        u32x2 hh_, ll_;
+                        split4<false>(x, 1.f, hh_, ll_);
+                        auto s0_ = __builtin_amdgcn_permlane16_swap(ll_[0], hh_[0], false, false);
+                        auto s1_ = __builtin_amdgcn_permlane16_swap(ll_[1], hh_[1], false, false);
+                        x = __builtin_bit_cast(f32x4, u32x4{s0_[0], s1_[0], s0_[1], s1_[1]});
+                    }
+#endif
+                    outv[nt * 3 + mt] = x;''')
 s = s.replace('#include "rvdd_internal.h"', '#ifndef RVDD_XP\n#define RVDD_XP 0\n#endif\n#include "rvdd_internal.h"', 1)
 out = sys.argv[1]
 os.makedirs(os.path.dirname(out) or ".", exist_ok=True)
