@@ -27,6 +27,33 @@ int main(int argc, char** argv) {
         _Float16 hv = (_Float16)((float)rand() / RAND_MAX - 0.5f);
         memcpy(&v, &hv, 2);
     }
+#if defined(RVDD_XP) && (RVDD_XP & 128)
+    {   // the input as a map stored split: per pixel six blocks of [hi of 8 channels | lo of 8 channels], f16, hi toward zero
+        auto rtz = [](float v) {
+            _Float16 h = (_Float16)v;
+            if (fabsf((float)h) > fabsf(v)) {
+                uint16_t b;
+                memcpy(&b, &h, 2);
+                b -= 1;                       // one step toward zero (same sign, magnitude bits down)
+                memcpy(&h, &b, 2);
+            }
+            return h;
+        };
+        std::vector<float> y(x.size());
+        for (size_t p = 0; p < px; ++p)
+            for (int c8 = 0; c8 < 6; ++c8) {
+                _Float16 hi[8], lo[8];
+                for (int i = 0; i < 8; ++i) {
+                    const float v = x[p * 48 + 8 * c8 + i];
+                    hi[i] = rtz(v);
+                    lo[i] = (_Float16)(v - (float)hi[i]);
+                }
+                memcpy(&y[p * 48 + 8 * c8], hi, 16);
+                memcpy(&y[p * 48 + 8 * c8 + 4], lo, 16);
+            }
+        x.swap(y);
+    }
+#endif
     float *din, *dout, *dbias;
     void* dw;
     hipMalloc(&din, px * 192);

@@ -30,18 +30,31 @@ rep('''                if (j >= SH && j - SH < G::NR) fetch_round(qn, j - SH);''
     '''#if !(RVDD_XP & 2)
                 if (j >= SH && j - SH < G::NR) fetch_round(qn, j - SH);
 #endif''')
-# 128 (round 5): the halo pieces arrive already split -- loads and staging stores stay, the split's instructions go (the two
-# halves of the loaded piece stand in for hi and lo)
+# 128 (round 5): the input map is stored SPLIT (per pixel six blocks of [hi of 8 channels, 16 B | lo of 8 channels, 16 B]; the harness
+# converts its input): a loaded 16-B piece goes to its plane as it is, one ds_write_b128 -- the real consumer side of such a map
 rep('''                        split4<SC>(pre[r0], sc_nxt, shi[r0], slo[r0]);
                         asm volatile("" : "+v"(shi[r0]), "+v"(slo[r0]));''',
     '''#if RVDD_XP & 128
-                        shi[r0] = u32x2{__builtin_bit_cast(unsigned, pre[r0][0]), __builtin_bit_cast(unsigned, pre[r0][1])};
-                        slo[r0] = u32x2{__builtin_bit_cast(unsigned, pre[r0][2]), __builtin_bit_cast(unsigned, pre[r0][3])};
-                        asm volatile("" : "+v"(shi[r0]), "+v"(slo[r0]));
+                        asm volatile("" : "+v"(pre[r0]));
 #elif !(RVDD_XP & 2)
                         split4<SC>(pre[r0], sc_nxt, shi[r0], slo[r0]);
                         asm volatile("" : "+v"(shi[r0]), "+v"(slo[r0]));
 #endif''')
+rep('''#pragma unroll
+        for (int r0 = 0; r0 < G::NR; ++r0)
+            if (ld_thread && G::RPR * r0 + rp < IH) {
+                *(lds_u2*)(L + l_lane + r0 * G::RPR * IW * G::S) = shi[r0];
+                *(lds_u2*)(L + l_lane + r0 * G::RPR * IW * G::S + G::PLANE) = slo[r0];
+            }''', '''#pragma unroll
+        for (int r0 = 0; r0 < G::NR; ++r0)
+            if (ld_thread && G::RPR * r0 + rp < IH) {
+#if RVDD_XP & 128
+                *(lds_f4*)(L + plane0 + (unsigned)((rp * IW + hx) * G::S + (part >> 1) * 16 + ((part & 1) ? G::PLANE : 0)) + r0 * G::RPR * IW * G::S) = pre[r0];
+#else
+                *(lds_u2*)(L + l_lane + r0 * G::RPR * IW * G::S) = shi[r0];
+                *(lds_u2*)(L + l_lane + r0 * G::RPR * IW * G::S + G::PLANE) = slo[r0];
+#endif
+            }''')
 i = s.rindex('        write_tile();')
 s = s[:i] + '''#if !(RVDD_XP & 2)
         write_tile();
