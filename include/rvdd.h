@@ -228,13 +228,8 @@ int rvdd_srgb_metrics(rvdd_t* h, const uint8_t* a, const uint8_t* b, int32_t n, 
  *               input plus a fix of the border ring, where the zero padding between the two layers matters (default 1, the
  *               feature-recurrent convunet on the split-f16 path; the A/B reference: the same linear map, summed in another
  *               order, a few 1e-7 apart).
- *   "conv_groups": 2 = the split-f16 conv kernel's eight waves work as two groups of four, each on an 8x16-pixel tile with a
- *               barrier of its own, instead of all eight on one 16x16-pixel tile (default 1; process-wide; same sums in the same
- *               order, same bits; measured: no gain in the net).
  *   "block_fp": 0 = the split-f16 convs split their operands without the per-map power of two (the A/B reference of the block
  *               floating point; right only while every activation stays within 2^-14 .. 65504).  Default 1.
- *   "wino4":    1 / 2 = the plain and two-pass 48 -> 48 3x3 convs on the Winograd F(4x4,3x3) kernel where a launch has
- *               at least 400 units / at every size (measured slower than F(2x2,3x3) on MI355X; off; a few ulp apart).
  * Unknown names are an error. */
 int rvdd_set_option(rvdd_t* h, const char* name, int32_t value);
 

@@ -51,7 +51,7 @@ typedef __attribute__((address_space(3))) void lds_void;
 constexpr int TW = 16;
 constexpr int NTHREADS = 512;
 
-// NGRP = 1 (the default): the eight waves of a workgroup share one 16x16-pixel tile.  NGRP = 2 (round 4, option "conv_groups"):
+// NGRP = 1 (the library): the eight waves of a workgroup share one 16x16-pixel tile.  NGRP = 2 (round 4, the harness only):
 // two GROUPS of four waves, one wave of each per SIMD, each group with its own 8x16-pixel tile, halo planes and barrier (an
 // LDS counter), walking the tile list independently -- while one group is between its barriers (epilogue, staging stores) the
 // other group's wave keeps the SIMD's matrix pipe busy.  Same sums in the same order, same bits; 2.6 % faster on its own
@@ -740,10 +740,15 @@ hipError_t launch_g(const ConvArgs& a0, hipStream_t s) {
     return hipGetLastError();
 }
 
-int g_conv3x3h_groups = 1;      // conv3x3h_set_groups: 2 = two groups of four waves with an 8x16-pixel tile each (measured: no gain in the net)
+// The two-group form (NGRP = 2: measured in round 4, +2.6 % stand-alone, nothing in the net) is instantiated for the stand-alone
+// harness only (tools/conv3x3h_bench.hip, -DRVDD_CONV_GROUPS2): the library runs one 16x16 tile per workgroup.
+int g_conv3x3h_groups = 1;
 template <int CIN, int EPI, bool ACC_IN, bool UPS = false>
 hipError_t launch_h(const ConvArgs& a, hipStream_t s) {
-    return g_conv3x3h_groups == 1 ? launch_g<CIN, EPI, ACC_IN, UPS, 1>(a, s) : launch_g<CIN, EPI, ACC_IN, UPS, 2>(a, s);
+#ifdef RVDD_CONV_GROUPS2
+    if (g_conv3x3h_groups == 2) return launch_g<CIN, EPI, ACC_IN, UPS, 2>(a, s);
+#endif
+    return launch_g<CIN, EPI, ACC_IN, UPS, 1>(a, s);
 }
 
 }  // namespace

@@ -458,25 +458,44 @@ __global__ __launch_bounds__(192) void warp48_kernel(const float* __restrict__ s
 
 // warp48_kernel with a 48 -> 48 projection of the warped pixel on its way out: dst = W warp(src) + bias.  ConvNeXtUnet's first
 // encoder block projects cat[y, warped features] 96 -> 48 (networks/new_unet.py:381-382, 85-88); the projection is linear
-// in the two maps and the warped features have no other reader, so their half of it rides here (f32 MFMA 16x16x4, exact
-// f32 products: the gather leaves the matrix pipe idle) and the other half in the epilogue of the block that forms y
-// (convnext.hip PROJ) -- the projection kernel and its 4 S of traffic are gone.  The 32 warped pixels of the workgroup
-// change lanes through LDS (pixel pitch 52 floats: the 16 lanes of a ds_read_b128 group on 16 distinct bank quads):
-// wave m forms output channels 16 m .. 16 m + 15 of both 16-pixel groups.
-// pw: the projection arranged as proj1x1_kernel's, [j 6][m 3][lr 16][g 4][i 4] = W[16m+lr][16j+4g+i]; the features are
-// input channels 48..95 (j = 3..5).
+// in the two maps and the warped features have no other reader, so their half of it rides here and the other half in the
+// epilogue of the block that forms y (convnext.hip PROJ) -- the projection kernel and its 4 S of traffic are gone.
+// The 32 warped pixels of the workgroup change lanes through LDS (pixel pitch 52 floats: the 16 lanes of a ds_read_b128 group
+// on 16 distinct bank quads); waves 0 and 1 then project one 16-pixel group each on the F16 matrix pipe exactly as convnext.hip's
+// PROJ epilogue does: per-pixel power of two (the features have no a-priori bound), split into f16 halves, fc1's five-MFMA
+// pattern on the three 16-row blocks of 2^s W (frag: runtime_next.inc's half[1] fragments, 9 KiB, copied to LDS once per
+// workgroup), one fma back.  (The first form multiplied f32 on v_mfma_f32_16x16x4_f32: 72 per workgroup at 32 cycles each ON the
+// vector lanes the gather's FMAs need -- 1 247 us against warp48_kernel's 899.)
+typedef _Float16 wp_h8 __attribute__((ext_vector_type(8)));
+typedef __fp16 wp_fp16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 wp_h2 __attribute__((ext_vector_type(2)));
+typedef unsigned int wp_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void wp_split4(f32x4 x, unsigned (&hi)[2], unsigned (&lo)[2]) {      // convnext.hip split4h
+    const wp_fp16x2 h01 = __builtin_amdgcn_cvt_pkrtz(x[0], x[1]);
+    const wp_fp16x2 h23 = __builtin_amdgcn_cvt_pkrtz(x[2], x[3]);
+    const unsigned u01 = __builtin_bit_cast(unsigned, h01), u23 = __builtin_bit_cast(unsigned, h23);
+    float r0, r1, r2, r3;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(u01), "v"(x[0]));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(u01), "v"(x[1]));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r2) : "v"(u23), "v"(x[2]));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r3) : "v"(u23), "v"(x[3]));
+    const wp_h2 l01 = {(_Float16)r0, (_Float16)r1};
+    const wp_h2 l23 = {(_Float16)r2, (_Float16)r3};
+    hi[0] = u01; hi[1] = u23;
+    lo[0] = __builtin_bit_cast(unsigned, l01); lo[1] = __builtin_bit_cast(unsigned, l23);
+}
 __global__ __launch_bounds__(192) void warp48_proj_kernel(const float* __restrict__ src, const float* __restrict__ flow_raw,
                                                           float* __restrict__ dst, int B, int H, int W, int64_t fbs,
-                                                          const float* __restrict__ pw, const float* __restrict__ bias) {
+                                                          const float* __restrict__ frag, int inv_e, const float* __restrict__ bias) {
     __shared__ int s_i[32][8];      // xi[4], yi[4] * W
     __shared__ float s_w[32][8];    // wx[4], wy[4]
     __shared__ __attribute__((aligned(16))) float s_t[32][52];
+    __shared__ __attribute__((aligned(16))) float s_f[2304];       // the projection's fragments: [m 3][Fa Fb Fc][64 lanes][16 B]
     const int y = blockIdx.y, b = blockIdx.z, x0 = blockIdx.x * 32;
-    const int lane = threadIdx.x & 63, m = threadIdx.x >> 6, lr = lane & 15, g = lane >> 4;
-    f32x4 wa[3];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, lr = lane & 15, g = lane >> 4;
 #pragma unroll
-    for (int j = 0; j < 3; ++j) wa[j] = *reinterpret_cast<const f32x4*>(pw + ((((size_t)(3 + j) * 3 + m) * 16 + lr) * 4 + g) * 4);
-    const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + 16 * m + 4 * g);
+    for (int k = 0; k < 3; ++k)
+        reinterpret_cast<f32x4*>(s_f)[threadIdx.x + 192 * k] = reinterpret_cast<const f32x4*>(frag)[threadIdx.x + 192 * k];
     if (threadIdx.x < 32) {
         const int x = x0 + threadIdx.x;
         if (x < W) {
@@ -544,18 +563,43 @@ __global__ __launch_bounds__(192) void warp48_proj_kernel(const float* __restric
     *reinterpret_cast<f32x4*>(&s_t[pa][4 * c4]) = acca;
     *reinterpret_cast<f32x4*>(&s_t[pb][4 * c4]) = accb;
     __syncthreads();
+    if (wv >= 2) return;
+    // ---- waves 0, 1: the 16 pixels of group wv, all 48 output channels
+    f32x4 v[3];
 #pragma unroll
-    for (int gq = 0; gq < 2; ++gq) {
-        f32x4 xb[3];
+    for (int j = 0; j < 3; ++j) v[j] = *reinterpret_cast<const f32x4*>(&s_t[16 * wv + lr][16 * j + 4 * g]);
+    float mx = 0.f;
 #pragma unroll
-        for (int j = 0; j < 3; ++j) xb[j] = *reinterpret_cast<const f32x4*>(&s_t[16 * gq + lr][16 * j + 4 * g]);
-        f32x4 acc = bv;
+    for (int j = 0; j < 3; ++j) mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v[j][0]), fabsf(v[j][1]))), fmaxf(fabsf(v[j][2]), fabsf(v[j][3])));
+    unsigned mb = __float_as_uint(mx);
+    auto s32 = __builtin_amdgcn_permlane32_swap(mb, mb, false, false);
+    mb = max(s32[0], s32[1]);
+    auto s16 = __builtin_amdgcn_permlane16_swap(mb, mb, false, false);
+    mb = max(s16[0], s16[1]);
+    const int e = min((int)(mb >> 23) & 0xff, 252);
+    const float fwd = __uint_as_float((unsigned)(253 - e) << 23);
+    const float back = __uint_as_float((unsigned)min(max(e + 1 + inv_e, 1), 254) << 23);
+    unsigned xh[3][2], xl[3][2];
 #pragma unroll
-        for (int j = 0; j < 3; ++j)
+    for (int j = 0; j < 3; ++j) wp_split4(v[j] * fwd, xh[j], xl[j]);
+    const wp_h8 P1 = __builtin_bit_cast(wp_h8, wp_u32x4{xh[0][0], xh[0][1], xh[1][0], xh[1][1]});
+    const wp_h8 P2 = __builtin_bit_cast(wp_h8, wp_u32x4{xl[0][0], xl[0][1], xl[1][0], xl[1][1]});
+    const wp_h8 P3 = __builtin_bit_cast(wp_h8, wp_u32x4{xh[2][0], xh[2][1], xh[2][0], xh[2][1]});
+    const wp_h8 P4 = __builtin_bit_cast(wp_h8, wp_u32x4{xl[2][0], xl[2][1], xl[2][0], xl[2][1]});
+    const int x = x0 + 16 * wv + lr;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[j][i], xb[j][i], acc, 0, 0, 0);
-        const int x = x0 + 16 * gq + lr;
-        if (x < W) *reinterpret_cast<f32x4*>(dst + (((size_t)b * H + y) * W + x) * kF + 16 * m + 4 * g) = acc;
+    for (int m = 0; m < 3; ++m) {
+        const wp_h8 fa = __builtin_bit_cast(wp_h8, *reinterpret_cast<const f32x4*>(s_f + (m * 3 + 0) * 256 + lane * 4));
+        const wp_h8 fb = __builtin_bit_cast(wp_h8, *reinterpret_cast<const f32x4*>(s_f + (m * 3 + 1) * 256 + lane * 4));
+        const wp_h8 fc = __builtin_bit_cast(wp_h8, *reinterpret_cast<const f32x4*>(s_f + (m * 3 + 2) * 256 + lane * 4));
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa, P2, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb, P1, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(fc, P4, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(fc, P3, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa, P1, acc, 0, 0, 0);
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + 16 * m + 4 * g);
+        if (x < W) *reinterpret_cast<f32x4*>(dst + (((size_t)b * H + y) * W + x) * kF + 16 * m + 4 * g) = acc * back + bv;
     }
 }
 
@@ -846,11 +890,11 @@ hipError_t launch_warp48(const float* src, const float* flow_raw, float* dst, in
     return hipGetLastError();
 }
 
-hipError_t launch_warp48_proj(const float* src, const float* flow_raw, float* dst, int B, int H, int W, const float* proj_w96,
-                              const float* bias, hipStream_t s, int64_t flow_bstride) {
+hipError_t launch_warp48_proj(const float* src, const float* flow_raw, float* dst, int B, int H, int W, const float* frag,
+                              int inv_e, const float* bias, hipStream_t s, int64_t flow_bstride) {
     if (!B || !H || !W) return hipSuccess;
     const int64_t fbs = flow_bstride ? flow_bstride : (int64_t)2 * (H / 2) * (W / 2);
-    hipLaunchKernelGGL(warp48_proj_kernel, dim3((W + 31) / 32, H, B), dim3(192), 0, s, src, flow_raw, dst, B, H, W, fbs, proj_w96, bias);
+    hipLaunchKernelGGL(warp48_proj_kernel, dim3((W + 31) / 32, H, B), dim3(192), 0, s, src, flow_raw, dst, B, H, W, fbs, frag, inv_e, bias);
     return hipGetLastError();
 }
 

@@ -28,7 +28,6 @@ struct Conv3 {            // one 3x3 conv layer, split per 48-channel source
     int cin_pad[2] = {0, 0};
     float* w[2] = {nullptr, nullptr};
     float* wu[2] = {nullptr, nullptr};   // Winograd F(2x2,3x3) transformed bank (48-channel sources only)
-    float* w4[2] = {nullptr, nullptr};   // Winograd F(4x4,3x3) transformed banks, three cout thirds (48-channel sources only)
     float* wh[2] = {nullptr, nullptr};   // split-f16 banks of conv3x3h.hip (hi / lo halves of 2^s w; 48-channel sources only)
     float wh_inv[2] = {1.f, 1.f};        // 2^-s of each
     float* bias = nullptr;
@@ -145,7 +144,6 @@ struct rvdd_handle {
                                   // winograd / "conv_kernel" 1, 2, 4 select the f32-MFMA kernels (the A/B reference)
     bool bfp = true;              // block floating point of the split-f16 convs (amax words per map and sequence; RVDD_BFP=0 / option "block_fp" 0:
                                   // operands split as they are, the round-3 behaviour with its 2^-14 .. 65504 domain -- A/B reference only)
-    int wino4 = 0;                // 1 = F(4x4,3x3) (wino4x4.hip) for the plain / two-pass 48->48 layers of the large levels (RVDD_WINO4)
     int seq_major = 0;            // 1 = full-resolution stages one sequence at a time (see seq_major_on)
     bool fuse_upsample = true;    // UpConv's bilinear x2 inside the Winograd patch load (RVDD_FUSE_UPSAMPLE=0: separate kernel)
     bool next_fused = true;       // ConvNeXt ConvBlock as ONE kernel (RVDD_NEXT_FUSED=0 / option "next_fused" 0: dwln + mlp kernels, the A/B reference)
@@ -385,28 +383,6 @@ std::vector<float> arrange_conv3x3h(const HostTensor& t, int c0, float* inv_scal
     return out;
 }
 
-// OIHW [48][cin_total][3][3], channels [c0, c0+48) -> U = G g G^T of F(4x4,3x3) per (cout, cin) (G 6x3, computed in double),
-// stored [third 3][pos 36][j 3][lane = 16g + (cout & 15)][i 4] with cout = 16 third + (cout & 15), channel = c0 + 16j+4g+i:
-// the A-fragment order of wino4x4.hip, one 108-KiB bank per cout third.
-std::vector<float> arrange_wino4x4(const HostTensor& t, int c0) {
-    const int cin_total = (int)t.shape[1];
-    static const double G[6][3] = {{1.0 / 4, 0, 0},        {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
-                                   {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6},  {0, 0, 1}};
-    std::vector<float> out((size_t)3 * 36 * 3 * 256, 0.f);
-    for (int co = 0; co < 48; ++co)
-        for (int c = 0; c < 48; ++c) {
-            const float* gk = &t.data[((size_t)co * cin_total + c0 + c) * 9];
-            double tmp[6][3], u[6][6];
-            for (int i = 0; i < 6; ++i)
-                for (int k = 0; k < 3; ++k) tmp[i][k] = G[i][0] * gk[k] + G[i][1] * gk[3 + k] + G[i][2] * gk[6 + k];
-            for (int i = 0; i < 6; ++i)
-                for (int k = 0; k < 6; ++k) u[i][k] = tmp[i][0] * G[k][0] + tmp[i][1] * G[k][1] + tmp[i][2] * G[k][2];
-            const int j = c / 16, g = (c % 16) / 4, ii = c % 4, third = co / 16, lr = co % 16;
-            for (int pos = 0; pos < 36; ++pos)
-                out[((((size_t)third * 36 + pos) * 3 + j) * 64 + g * 16 + lr) * 4 + ii] = (float)u[pos / 6][pos % 6];
-        }
-    return out;
-}
 
 // preprocessing_layer (3x3, cin -> 48, NO activation: networks/unet.py:742) followed by the first 48 input channels of
 // EncoderConvs[0][0] (3x3, :743) is one linear map of the network input: out(p) = sum_d W2[d] y(p + d - 1), y(q) = b1 +
@@ -711,15 +687,6 @@ int run_conv(rvdd_t* h, const Conv3& L, const ConvCall& c, hipStream_t s, Sub su
         HIPCHK(h, launch_conv3x3h(a, cin == 48 ? 48 : 16, c.epi, s));
         return RVDD_OK;
     }
-    // F(4x4,3x3): plain and two-pass 48 -> 48 layers with enough 64x16-pixel units for every one of the 80 unit sequences
-    if (h->wino4 && h->use_wino && cin == 48 && !c.ups && L.w4[c.src] && (c.epi == EPI_NONE || c.epi == EPI_RELU) &&
-        (h->wino4 == 2 || (long)a.B * ((c.W + 63) / 64) * ((c.H + 15) / 16) >= 400)) {
-        a.w = L.w4[c.src];
-        Scope sc(h, s, c.acc_in ? (c.epi == EPI_RELU ? "wino4_kernel<1, true>" : "wino4_kernel<0, true>")
-                                : (c.epi == EPI_RELU ? "wino4_kernel<1, false>" : "wino4_kernel<0, false>"), flops, bytes);
-        HIPCHK(h, launch_wino4x4(a, c.epi, s));
-        return RVDD_OK;
-    }
     if ((cin == 48 || c16_ok) && L.wu[c.src] && wino_applies(h, c.H, c.W)) {
         a.w = L.wu[c.src];
         Scope sc(h, s, c.ups ? "wino3x3_ups_kernel<1>" : cin == 48 ? wino_name(c.epi, c.acc_in != nullptr)
@@ -983,10 +950,8 @@ int rvdd_create(const rvdd_cfg* cfg, rvdd_t** out) {
     if (const char* sm = std::getenv("RVDD_SEQ_MAJOR")) h->seq_major = std::atoi(sm) != 0;     // measurement switches
     if (const char* fu = std::getenv("RVDD_FUSE_UPSAMPLE")) h->fuse_upsample = std::atoi(fu) != 0;
     if (const char* nf = std::getenv("RVDD_NEXT_FUSED")) h->next_fused = std::atoi(nf) != 0;
-    if (const char* w4 = std::getenv("RVDD_WINO4")) h->wino4 = std::atoi(w4);
     if (const char* bf = std::getenv("RVDD_BFP")) h->bfp = std::atoi(bf) != 0;
     if (const char* fp = std::getenv("RVDD_FUSE_PRE")) h->fuse_pre = std::atoi(fp) != 0;
-    if (const char* cg = std::getenv("RVDD_CONV_GROUPS")) conv3x3h_set_groups(std::atoi(cg));      // process-wide A/B switch
     if (const char* np = std::getenv("RVDD_NEXT_POOL")) h->next_pool = std::atoi(np) != 0;
     if (const char* nsp = std::getenv("RVDD_NEXT_SPLIT")) h->next_split = std::atoi(nsp) != 0;
     if (const char* npp = std::getenv("RVDD_NEXT_PIPE")) h->next_pipe = std::atoi(npp) != 0;
@@ -1105,7 +1070,6 @@ int rvdd_finalize_weights(rvdd_t* h) {
                     L.cin_pad[sidx] = 48;
                     RC(upload(h, &L.w[sidx], arrange_conv3x3(wt, 48 * sidx, 48, 48)));
                     RC(upload(h, &L.wu[sidx], arrange_wino3x3(wt, 48 * sidx)));
-                    RC(upload(h, &L.w4[sidx], arrange_wino4x4(wt, 48 * sidx)));
                     RC(upload(h, &L.wh[sidx], arrange_conv3x3h(wt, 48 * sidx, &L.wh_inv[sidx])));
                 }
             } else {
@@ -1114,7 +1078,6 @@ int rvdd_finalize_weights(rvdd_t* h) {
                 L.cin_pad[0] = cin == 48 ? 48 : kNetInC;
                 RC(upload(h, &L.w[0], arrange_conv3x3(wt, 0, cin, L.cin_pad[0])));
                 RC(upload(h, &L.wu[0], cin == 48 ? arrange_wino3x3(wt, 0) : arrange_wino3x3(wt, 0, 1)));
-                if (cin == 48) RC(upload(h, &L.w4[0], arrange_wino4x4(wt, 0)));
                 RC(upload(h, &L.wh[0], arrange_conv3x3h(wt, 0, &L.wh_inv[0], cin == 48 ? 48 : 16)));
             }
             RC(upload(h, &L.bias, h->staged.at(n + ".bias").data));
@@ -1261,13 +1224,6 @@ int rvdd_set_option(rvdd_t* h, const char* name, int32_t value) {
         h->fuse_pre = value != 0;
         return RVDD_OK;
     }
-    if (std::strcmp(name, "conv_groups") == 0) {
-        // 2 = the split-f16 conv kernel's eight waves as two groups of four, each with an 8x16-pixel tile and a barrier of its own;
-        // 1 (default) = one 16x16-pixel tile per workgroup.  Process-wide; same bits either way.
-        if (value != 1 && value != 2) return fail(h, RVDD_ERR_ARG, "rvdd_set_option: conv_groups must be 1 or 2");
-        conv3x3h_set_groups(value);
-        return RVDD_OK;
-    }
     if (std::strcmp(name, "block_fp") == 0) {
         // 0 = the split-f16 convs split their operands as they are (no per-map power of two): the round-3 behaviour, right only
         // while every activation stays inside 2^-14 .. 65504 -- kept as the A/B reference of the block floating point
@@ -1276,12 +1232,6 @@ int rvdd_set_option(rvdd_t* h, const char* name, int32_t value) {
             ENTER(h);
             HIPCHK(h, hipMemset(h->amax, 0, amax_bytes(h->cfg.batch, AMAX_SLOTS)));      // no stale words across the switch
         }
-        return RVDD_OK;
-    }
-    if (std::strcmp(name, "wino4") == 0) {
-        // 0 = off, 1 = F(4x4,3x3) for the plain / two-pass 48 -> 48 layers where a launch has >= 400 units, 2 = at every size
-        if (value < 0 || value > 2) return fail(h, RVDD_ERR_ARG, "rvdd_set_option: wino4 must be 0, 1 or 2");
-        h->wino4 = value;
         return RVDD_OK;
     }
     if (std::strcmp(name, "seq_major") == 0) {
@@ -1300,7 +1250,7 @@ int rvdd_set_option(rvdd_t* h, const char* name, int32_t value) {
         h->split16 = value == 0;
         return RVDD_OK;
     }
-    return fail(h, RVDD_ERR_ARG, "rvdd_set_option: unknown option '%s' (known: no_warp, warp_raw, prev_noisy_frame, conv_kernel, seq_major, graphs, fuse_upsample, next_fused, next_split, next_pipe, next_pool, next_projfuse, tvl1_async, wino4, block_fp, conv_groups, fuse_pre)", name);
+    return fail(h, RVDD_ERR_ARG, "rvdd_set_option: unknown option '%s' (known: no_warp, warp_raw, prev_noisy_frame, conv_kernel, seq_major, graphs, fuse_upsample, next_fused, next_split, next_pipe, next_pool, next_projfuse, tvl1_async, block_fp, fuse_pre)", name);
 }
 
 int rvdd_reset(rvdd_t* h) {
@@ -1395,8 +1345,8 @@ int run_prologue(rvdd_t* h, const StepInputs& in, Sub sb, hipStream_t s) {
         h->featw_proj = next_pf_pre(h);
         Scope sc(h, s, "warp48_kernel", h->featw_proj ? 2.0 * 48 * 48 * n * img : 0.0, (double)n * img * (384.0 + 2.0));
         if (h->featw_proj)
-            HIPCHK(h, launch_warp48_proj(h->lastfeat + o * img * kF, fp_, h->featw + o * img * kF, n, H, W, h->nx[NX_ENC0_0].w.proj_w,
-                                         h->nx[NX_ENC0_0].w.proj_b, s, (int64_t)in.flowf));
+            HIPCHK(h, launch_warp48_proj(h->lastfeat + o * img * kF, fp_, h->featw + o * img * kF, n, H, W, h->nx[NX_ENC0_0].half[1].frag,
+                                         h->nx[NX_ENC0_0].half[1].inv_e, h->nx[NX_ENC0_0].w.proj_b, s, (int64_t)in.flowf));
         else
             HIPCHK(h, launch_warp48(h->lastfeat + o * img * kF, fp_, h->featw + o * img * kF, n, H, W, s, (int64_t)in.flowf));
     }

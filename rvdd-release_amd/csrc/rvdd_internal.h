@@ -146,10 +146,6 @@ size_t conv3x3_weight_floats(int cin);
 // Winograd F(2x2,3x3) variant for 48 -> 48 layers; a.w = bank arranged by arrange_wino3x3 (runtime.hip)
 hipError_t launch_wino3x3(const ConvArgs& a, int cin, int epi, hipStream_t s);   // cin: 48, or 16 = the zero-padded network input
 size_t wino3x3_weight_floats();
-// Winograd F(4x4,3x3) for plain 48 -> 48 layers (EPI_NONE / EPI_RELU, with or without a.acc_in); a.w = the three cout-third
-// banks arranged by arrange_wino4x4 (runtime.hip)
-hipError_t launch_wino4x4(const ConvArgs& a, int epi, hipStream_t s);
-size_t wino4x4_weight_floats();
 // the same layers on the F16 matrix pipe with split f32 operands (conv3x3h.hip); a.w = the split bank arranged by
 // arrange_conv3x3h (runtime.hip), a.wscale its scale; cin 48 (every epilogue, with or without a.acc_in, with a.ups for
 // UpConv's fused upsample) or 16 (the zero-padded network input): every 3x3 conv of the convunet by default
@@ -162,7 +158,7 @@ hipError_t launch_conv5x5h_c16(const ConvArgs& a, hipStream_t s);
 size_t conv5x5h_weight_bytes();
 hipError_t launch_pre_border_fix(const float* netin, const float* w1, const float* b1, const float* w2, float* part, int B, int H, int W,
                                  hipStream_t s);
-void conv3x3h_set_groups(int g);   // 1 (default) = one 16x16 tile per workgroup; 2 = two groups of four waves with an 8x16 tile each (A/B)
+void conv3x3h_set_groups(int g);   // stand-alone harness (-DRVDD_CONV_GROUPS2): 2 = two groups of four waves with an 8x16 tile each
 void conv3x3_set_variant(int v);   // A/B switch used by rvdd_debug_conv_bench only
 
 // -------------------------------------------------------------- pre-stages --
@@ -194,10 +190,10 @@ hipError_t launch_netin_bound(const float* raw_a, const float* raw_b, const floa
 // src NHWC48 -> dst NHWC48.
 hipError_t launch_warp48(const float* src, const float* flow_raw, float* dst, int B, int H, int W,
                          hipStream_t s, int64_t flow_bstride = 0);
-// the same, and a 48 -> 48 projection of every warped pixel: dst = W warp(src) + bias; proj_w96 = a 96 -> 48 projection arranged
-// as launch_proj1x1's (runtime_next.inc), of which input channels 48..95 are applied (prestage.hip warp48_proj_kernel)
-hipError_t launch_warp48_proj(const float* src, const float* flow_raw, float* dst, int B, int H, int W, const float* proj_w96,
-                              const float* bias, hipStream_t s, int64_t flow_bstride = 0);
+// the same, and a 48 -> 48 projection of every warped pixel: dst = W warp(src) + bias; frag / inv_e = the projection as a
+// NextProj's split-f16 fragments and scale (runtime_next.inc), applied per pixel in block floating point (prestage.hip)
+hipError_t launch_warp48_proj(const float* src, const float* flow_raw, float* dst, int B, int H, int W, const float* frag,
+                              int inv_e, const float* bias, hipStream_t s, int64_t flow_bstride = 0);
 // generic NCHW warp with a full-resolution flow (util.flow_utils.warp).
 hipError_t launch_remosaick4(const float* rgb4, float* raw, int B, int H, int W, hipStream_t s);
 hipError_t launch_warp_nchw(const float* x, const float* flow, float* y, int n, int c, int H, int W,

@@ -1018,41 +1018,6 @@ def test_composed_first_layer_matches_two_convs():
                     assert float(d[ring].max()) <= max(4 * float(d[~ring].max()), 1e-6), (stem, B, H, W, k, float(d[ring].max()), float(d[~ring].max()))
 
 
-def test_conv_two_wave_groups_same_bits():
-    """Option "conv_groups" 2: the split-f16 conv kernel's eight waves as two groups of four, each on an 8x16-pixel tile with halo
-    planes and an LDS-counter barrier of its own, instead of all eight on one 16x16-pixel tile.  The same sums in the same order:
-    the same bits -- every epilogue (two-pass layers, pooling, bottleneck sum, fused upsample and 1x1 output, zero-padded
-    placement), ragged tiles, fewer tiles than groups, batches, both convunet families, three recurrent steps."""
-    from rvdd_release_amd import synth
-    from rvdd_release_amd.runtime import RvddRuntime
-    for arch, stem, fut in (("convunet+feat", "recurrent-convunet+feat-iso3200", 0), ("convunet", "recurrent-convunet-future-iso3200", 1)):
-        sd = load_weights(stem)
-        for B, H, W in ((1, 16, 16), (2, 72, 104), (1, 180, 320), (3, 50, 66), (2, 256, 256)):
-            T = 4 + fut
-            seqs = [synth.make_sequence(T, H, W, iso=3200, seed=900 + b, device="cuda") for b in range(B)]
-            st = lambda f: torch.stack([f(s) for s in seqs], 0)
-            outs = []
-            try:
-                for groups in (1, 2):
-                    rt = RvddRuntime(arch, fut, B, H, W, 0)
-                    rt.set_option("conv_groups", groups)
-                    rt.load_state_dict(sd)
-                    o = []
-                    for t in range(1, T - fut):
-                        o.append(rt.step(st(lambda s: s.raw[t - 1]) if t == 1 else None, st(lambda s: s.raw[t]),
-                                         st(lambda s: s.raw[t + 1]) if fut else None, st(lambda s: s.flow_prev[t]),
-                                         st(lambda s: s.flow_next[t]) if fut else None).clone())
-                    if arch.endswith("feat"):
-                        o.append(rt.get_state()[1])
-                    outs.append(o)
-                    rt.close()
-            finally:
-                rt = RvddRuntime(arch, fut, 1, 16, 16, 0)
-                rt.set_option("conv_groups", 1)          # process-wide switch: back to the default
-                rt.close()
-            for a, b in zip(*outs):
-                assert torch.equal(a, b), (arch, B, H, W, float((a - b).abs().max()))
-
 
 def test_pipelined_convblock_equals_phased():
     """convblock_pipe_kernel (the default: waves 0-3 run the depth-wise conv and the LayerNorm of tile t + 1 while waves
@@ -1168,25 +1133,3 @@ def test_two_kernel_convblock_golden(name, monkeypatch):
         out = net(g[f"x_{tag}"].cuda()).cpu()
         assert (out - g[f"out_{tag}"]).abs().max() < 1e-4, tag
 
-
-def test_wino4_f4x4_kernel_matches_default():
-    """The Winograd F(4x4,3x3) kernel (wino4x4.hip, option "wino4"; measured slower than F(2x2,3x3) on MI355X and
-    therefore off) forced at every size: two recurrent steps against the default path -- ragged tiles in x and y,
-    the two-pass 96 -> 48 layers, zero-padded decoder levels, batches.  F(4x4)'s transforms cost a few ulp more."""
-    from rvdd_release_amd import synth
-    from rvdd_release_amd.runtime import RvddRuntime
-    sd = load_weights("recurrent-convunet+feat-iso3200")
-    for B, H, W in ((1, 64, 96), (2, 72, 104), (1, 36, 52), (3, 22, 130), (2, 180, 320)):
-        seqs = [synth.make_sequence(3, H, W, iso=3200, seed=60 + b, device="cuda") for b in range(B)]
-        st = lambda f: torch.stack([f(s) for s in seqs], 0)
-        outs = []
-        for w4 in (0, 2):
-            rt = RvddRuntime("convunet+feat", 0, B, H, W, 0)
-            rt.set_option("conv_kernel", 2)
-            rt.set_option("wino4", w4)
-            rt.load_state_dict(sd)
-            outs.append([rt.step(st(lambda s: s.raw[0]), st(lambda s: s.raw[1]), None, st(lambda s: s.flow_prev[1]), None).clone(),
-                         rt.step(None, st(lambda s: s.raw[2]), None, st(lambda s: s.flow_prev[2]), None).clone()])
-            rt.close()
-        for a, b in zip(*outs):
-            assert (a - b).abs().max() < 2e-5 and parity_psnr(a.cpu(), b.cpu()) > 120.0, (B, H, W, float((a - b).abs().max()))

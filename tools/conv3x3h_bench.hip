@@ -1,5 +1,5 @@
 // Stand-alone timing of conv3x3h_kernel (the split-f16 3x3 conv) on random maps, with the kernel's phase stamps:
-//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -DRVDD_STAMPS -Irvdd-release_amd/csrc tools/conv3x3h_bench.hip -o /tmp/c3hb && /tmp/c3hb [B H W]
+//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -DRVDD_STAMPS -DRVDD_CONV_GROUPS2 -Irvdd-release_amd/csrc tools/conv3x3h_bench.hip -o /tmp/c3hb && /tmp/c3hb [B H W]
 // Prints microseconds per launch (HIP events), shader cycles per tile and phase of wave 0 (s_memtime), and the clock
 // the two imply.
 #ifdef CONV_SRC          // an instrumented copy of the kernel (tools/conv3x3h_xp_patch.py)

@@ -2,7 +2,7 @@
 """Registers, spills, scratch and LDS of every kernel in the BUILT library, read from the code objects inside
 rvdd-release_amd/librvdd_hip.so (no recompilation: the numbers are those of the binary that runs).
 
-    python tools/kernel_resources.py                 # table
+    python tools/kernel_resources.py [library.so]    # table (default: the in-tree library)
     python tools/kernel_resources.py --spills        # only the kernels that spill or use scratch; exit 1 if any
 
 The .hip_fatbin section holds one clang offload bundle per translation unit; each bundle's gfx950 entry is an ELF code
@@ -69,7 +69,8 @@ def kernel_table(lib=LIB):
 
 def main():
     only = "--spills" in sys.argv
-    rows = kernel_table()
+    libs = [a for a in sys.argv[1:] if not a.startswith("--")]
+    rows = kernel_table(libs[0]) if libs else kernel_table()
     bad = [r for r in rows if r.get("vgpr_spill_count", 0) or r.get("sgpr_spill_count", 0) or r.get("private_segment_fixed_size", 0)]
     print(f"{'kernel':58s} {'vgpr':>5s} {'agpr':>5s} {'sgpr':>5s} {'vspill':>6s} {'sspill':>6s} {'scratch':>7s} {'lds':>7s}")
     for r in (bad if only else rows):
