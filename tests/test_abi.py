@@ -35,6 +35,20 @@ def test_library_exports_every_declared_symbol():
     assert b"gfx950" in lib.rvdd_version()
 
 
+def test_documented_options_are_the_options_the_library_knows():
+    """include/rvdd.h documents rvdd_set_option's names one by one; the library lists the names it accepts in the message it
+    raises for an unknown one.  The two lists are the same set (an option removed from one and not the other is a stale ABI)."""
+    from rvdd_release_amd import _lib
+    txt = open(HEADER).read()
+    doc = txt[txt.index("Known names:"):txt.index("int rvdd_set_option(")]
+    documented = set(re.findall(r'^ \*   "([a-z0-9_]+)"', doc, flags=re.M))
+    blob = open(_lib.LIB_PATH, "rb").read()
+    m = re.search(rb"unknown option '%s' \(known: ([a-z0-9_, ]+)\)", blob)
+    assert m, "the library's unknown-option message was not found"
+    known = set(m.group(1).decode().split(", "))
+    assert documented == known, (sorted(documented - known), sorted(known - documented))
+
+
 def test_library_carries_gfx950_code_object():
     from rvdd_release_amd import _lib
     blob = open(_lib.LIB_PATH, "rb").read()
