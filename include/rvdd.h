@@ -212,6 +212,10 @@ int rvdd_srgb_metrics(rvdd_t* h, const uint8_t* a, const uint8_t* b, int32_t n, 
  *               next_split; same bits either way).
  *   "next_pool": 0 = with next_fused, MaxPool2d(2) in front of a DownConv (new_unet.py:200-204) as its own kernel instead
  *               of the fused block's epilogue (default 1; same bits either way).
+ *   "cout_split": 0 = every launch of the split-f16 conv kernel forms all 48 output channels of a tile in one workgroup.
+ *               Default 1: a launch with at most a third of a 16x16 tile per compute unit (the coarse levels of one small
+ *               sequence) gives a tile to three workgroups of 16 output channels each -- a third of the filter bank's copy and
+ *               of the matrix work per workgroup; same sums in the same order, same bits.  Process-wide.
  *   "tvl1_async": 1 = rvdd_tvl1flow_batch called without iteration counts enqueues its launches on the stream and returns
  *               (the flows are ready in stream order; nothing is read back, the stream is not synchronised): the form for a
  *               caller that feeds the flows straight into rvdd_step on the same stream (validate.py's --val_flow_from_denoised loop

@@ -61,7 +61,12 @@ constexpr int NTHREADS = 512;
 // first source of EncoderConvs[0][0] (3x3) into ONE 5x5 conv of the network input -- two linear maps in a row are one linear
 // map (runtime.hip: compose_pre_enc0); what the zero padding BETWEEN the two does at the image border is put right by
 // pre_border_fix_kernel below.
-template <int CIN, int NGRP, int KS = 3>
+// MT = 3 (every launch with enough tiles): a workgroup forms all 48 output channels of its tiles.  MT = 1 (launches with at most a
+// third of a tile per CU -- the coarse levels of one small sequence): a workgroup forms ONE block of 16 output channels
+// (blockIdx.y), three workgroups share a tile: a launch of one tile per workgroup is the copy of its filter bank (84 KiB at the
+// 11-16 GB/s an LDS-DMA stream delivers: 6 us) plus the tile (3 us) plus the ramp, and a third of the bank and of the MFMAs per
+// workgroup is most of it gone.  Same sums per output channel in the same order: the same bits.
+template <int CIN, int NGRP, int KS = 3, int MT = 3>
 struct HGeo {
     static constexpr int PAD = KS / 2;
     static constexpr int TH = 16 / NGRP, IH = TH + KS - 1;   // tile rows of a group (two per wave), with halo
@@ -77,7 +82,7 @@ struct HGeo {
                                                              // (tools/lds_b128_bench.hip; 192 or 208 are 2-way), and 10 KiB less than one
                                                              // interleaved [hi | lo | pad] image of 224 B per pixel
     static constexpr int PLANE = IH * IW * HI;
-    static constexpr int W_BYTES = NCH * 3 * 2 * 1024;
+    static constexpr int W_BYTES = NCH * MT * 2 * 1024;
     static constexpr int I_BYTES = 2 * PLANE;                // one group's two planes
     static constexpr int P_FLOATS = 48 + 3 * 48 + 4 + 8 + 4; // bias, PostConvs[1] weights and bias, one word per wave (amax reduction), the groups' barrier counters
     static constexpr int LDS_BYTES = W_BYTES + NGRP * I_BYTES + P_FLOATS * 4;
@@ -151,9 +156,11 @@ __device__ unsigned long long g_stamps[8 * 8];      // [wave][phase 0..6, tiles]
 // bilinear x2 upsample (align_corners=False), interpolated in the halo fetch (2x2 blocks of halo pixels from four source
 // pixels each) with the expressions of upsample2x_kernel (prestage.hip) in the same order: the same bits as "upsample,
 // then conv", the upsampled map is never written.
-template <int CIN, int EPI, bool ACC_IN, bool UPS = false, int NGRP = 2, int KS = 3>
+template <int CIN, int EPI, bool ACC_IN, bool UPS = false, int NGRP = 2, int KS = 3, int MT = 3>
 __global__ __launch_bounds__(NTHREADS) void conv3x3h_kernel(ConvArgs a) {
-    using G = HGeo<CIN, NGRP, KS>;
+    using G = HGeo<CIN, NGRP, KS, MT>;
+    static_assert(MT == 3 || (MT == 1 && EPI != EPI_RELU_OUT3 && NGRP == 1), "the 1x1 output needs all 48 channels of a pixel");
+    const int mt0 = MT == 3 ? 0 : (int)blockIdx.y;      // first 16-channel output block of this workgroup
     constexpr int TH = G::TH, IH = G::IH, IW = G::IW, PAD = G::PAD;
     static_assert(KS == 3 || (!UPS && !ACC_IN), "the 5x5 form exists for the composed first layer only");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -231,13 +238,15 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3h_kernel(ConvArgs a) {
     }
 
     {   // split filter bank -> LDS (linear copy of the host arrangement), every workgroup starting at another piece
-        __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, G::W_BYTES, 0x00020000);
+        __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, G::NCH * 3 * 2 * 1024, 0x00020000);
         constexpr int NP = G::W_BYTES / 1024;
         const int rot = (int)((blockIdx.x * 37u) % (unsigned)NP);
         for (int i = wave; i < NP; i += NTHREADS / 64) {
             int k = i + rot;
             if (k >= NP) k -= NP;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lds_void*)(smem + k * 1024), 16, (unsigned)(k * 1024 + lane * 16), 0, 0, 0);
+            // (MT = 1: piece k = (chunk, hi | lo) of this workgroup's output block, out of the host's [chunk][block 3][hi lo] order)
+            const unsigned src = MT == 3 ? (unsigned)k : (unsigned)(((k >> 1) * 3 + mt0) * 2 + (k & 1));
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lds_void*)(smem + k * 1024), 16, src * 1024u + (unsigned)(lane * 16), 0, 0, 0);
         }
     }
     if (tid < kF) Pl[tid] = a.bias[tid];
@@ -382,9 +391,9 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3h_kernel(ConvArgs a) {
         const int ky = tap / KS, kx = tap - KS * ky;
         boff[j] = L + (plane0 + (unsigned)(((2 * gw + ky) * IW + n + kx) * G::S + c0 * 2));
     }
-    lds_u8* abase[2] = {L + (unsigned)(lane * 16), L + (unsigned)(lane * 16 + G::A_SPLIT * 6 * 1024)};
+    lds_u8* abase[2] = {L + (unsigned)(lane * 16), L + (unsigned)(lane * 16 + G::A_SPLIT * MT * 2 * 1024)};
     asm volatile("" : "+v"(abase[0]), "+v"(abase[1]));
-    h8 Af[2][3][2], Bf[2][2][2];
+    h8 Af[2][MT][2], Bf[2][2][2];
     auto read_frags = [&](int buf, int j) {
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
@@ -392,11 +401,11 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3h_kernel(ConvArgs a) {
             for (int hl = 0; hl < 2; ++hl)
                 Bf[buf][nt][hl] = __builtin_bit_cast(h8, *(lds_f4*)(boff[j] + nt * IW * G::S + hl * G::PLANE));
 #pragma unroll
-        for (int mt = 0; mt < 3; ++mt)
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int hl = 0; hl < 2; ++hl) {
                 const int jj = j < G::A_SPLIT ? j : j - G::A_SPLIT;
-                Af[buf][mt][hl] = __builtin_bit_cast(h8, *(lds_f4*)(abase[j < G::A_SPLIT ? 0 : 1] + ((jj * 3 + mt) * 2 + hl) * 1024));
+                Af[buf][mt][hl] = __builtin_bit_cast(h8, *(lds_f4*)(abase[j < G::A_SPLIT ? 0 : 1] + ((jj * MT + mt) * 2 + hl) * 1024));
             }
     };
 
@@ -411,7 +420,7 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3h_kernel(ConvArgs a) {
         unsigned t = lane < G::WPG ? Rl[lane] : 0u;
         t = amax_lines_max(t);
         if (lane == 0 && t)
-            atomicMax(a.amax_out + (size_t)b * kAmaxSeqWords + ((blockIdx.x * NGRP + grp) % kAmaxLines) * kAmaxLineWords, t);
+            atomicMax(a.amax_out + (size_t)b * kAmaxSeqWords + (((MT == 3 ? blockIdx.x : blockIdx.x + blockIdx.y * 5u) * NGRP + grp) % kAmaxLines) * kAmaxLineWords, t);
     };
     // The group's barrier.  One group = the whole workgroup: s_barrier.  Two groups: a counter in LDS every wave of the group
     // adds one to and polls (s_barrier counts all eight waves, and the point of the groups is that they do NOT wait for each
@@ -471,7 +480,7 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3h_kernel(ConvArgs a) {
     }
     // results of the tile before, stored one 16-B piece per chunk inside the current tile's MFMA loop (before the first
     // tile: out-of-range offsets, the stores are dropped)
-    constexpr int NOUT = EPI == EPI_POOL ? 3 : 6;
+    constexpr int NOUT = (EPI == EPI_POOL ? 1 : 2) * MT;
     f32x4 outv[NOUT];
     unsigned so_prev[2] = {0x80000000u, 0x80000000u};
     __amdgpu_buffer_rsrc_t orr_prev = __builtin_amdgcn_make_buffer_rsrc((void*)a.out, 0, 0, 0x00020000);
@@ -479,7 +488,7 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3h_kernel(ConvArgs a) {
     for (int i = 0; i < NOUT; ++i) outv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     // one 16-B piece of the previous tile's results: they ride between the chunks of the current tile's MFMA loop
     auto store_prev = [&](int i) {
-        bstore(orr_prev, so_prev[EPI == EPI_POOL ? 0 : i / 3] + 64 * (i % 3), outv[i]);
+        bstore(orr_prev, so_prev[EPI == EPI_POOL ? 0 : i / MT] + 64 * (mt0 + i % MT), outv[i]);
     };
     STAMP_DECL;
 #pragma unroll 1
@@ -500,7 +509,7 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3h_kernel(ConvArgs a) {
         Src qn;
         const int yy0 = cur.y0 + 2 * gw, xx = cur.x0 + n;
         unsigned po[2], so[2];
-        f32x4 side[2][3];
+        f32x4 side[2][MT];
         __amdgpu_buffer_rsrc_t pr;
         auto addresses = [&]() {
             locate(t + t_step, nxt);
@@ -526,7 +535,7 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3h_kernel(ConvArgs a) {
 
         // ---- 14 chunks x 18 MFMAs, and between the chunks: a store of the last tile, a side load of this one, a halo
         // load of the next one (nine chunks from SH on), the split of what those loads brought (the last three chunks)
-        f32x4 acc[2][3];
+        f32x4 acc[2][MT];
         read_frags(0, 0);
 #pragma unroll
         for (int j = 0; j < G::NCH; ++j) {
@@ -538,7 +547,7 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3h_kernel(ConvArgs a) {
             if constexpr (ACC_IN) {
                 // (behind the previous tile's stores, which take the first six chunks: one memory instruction of each kind per chunk)
                 constexpr int SL = G::NCH >= 14 ? 7 : SH;
-                if (j >= SL && j - SL < 6) side[(j - SL) / 3][(j - SL) % 3] = bload(pr, po[(j - SL) / 3], 64 * ((j - SL) % 3));
+                if (j >= SL && j - SL < 2 * MT) side[(j - SL) / MT][(j - SL) % MT] = bload(pr, po[(j - SL) / MT], 64 * (mt0 + (j - SL) % MT));
             }
             if constexpr (SC) {
                 if (j == (UPS ? SH + UL : G::NCH - 1 - (G::NR - 1) / 3)) scale_from(ab_nxt, sc_nxt, inv_nxt);      // the chunk of the first split
@@ -571,7 +580,7 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3h_kernel(ConvArgs a) {
             for (int p = 0; p < 3; ++p) {
                 const int ha = p == 1 ? 1 : 0, hb = p == 0 ? 1 : 0;      // hi.lo, lo.hi, then hi.hi
 #pragma unroll
-                for (int mt = 0; mt < 3; ++mt)      // (filter fragment constant over two MFMAs in a row: 0.3 % over the other nest)
+                for (int mt = 0; mt < MT; ++mt)      // (filter fragment constant over two MFMAs in a row: 0.3 % over the other nest)
 #pragma unroll
                     for (int nt = 0; nt < 2; ++nt) {
                         const f32x4 c = (j == 0 && p == 0) ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[nt][mt];
@@ -586,12 +595,12 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3h_kernel(ConvArgs a) {
 
         // ---- epilogue: scale back, bias / partial sums, activation; the 48-channel results wait in registers for the
         // next tile's chunks
-        f32x4 v[2][3];
+        f32x4 v[2][MT];
         float m3 = 0.f;        // EPI_RELU_OUT3: max |output frame| over this lane's two pixels
         const float ws = SC ? a.wscale * inv_cur : a.wscale;      // the filters' and the map's powers of two, undone together
 #pragma unroll
-        for (int mt = 0; mt < 3; ++mt) {
-            const f32x4 bias = *reinterpret_cast<const f32x4*>(Pl + 16 * mt + 4 * g);
+        for (int mt = 0; mt < MT; ++mt) {
+            const f32x4 bias = *reinterpret_cast<const f32x4*>(Pl + 16 * (mt0 + mt) + 4 * g);
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
                 const f32x4 base = ACC_IN ? side[nt][mt] : bias;
@@ -601,7 +610,7 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3h_kernel(ConvArgs a) {
         if constexpr (EPI == EPI_POOL) {
             // MaxPool2d(2) of the un-activated conv output: the wave's two rows are one pooling row pair, columns n, n ^ 1
 #pragma unroll
-            for (int mt = 0; mt < 3; ++mt)
+            for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float q = fmaxf(v[0][mt][e], v[1][mt][e]);
@@ -621,14 +630,14 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3h_kernel(ConvArgs a) {
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-                for (int mt = 0; mt < 3; ++mt) {
+                for (int mt = 0; mt < MT; ++mt) {
                     f32x4 x = v[nt][mt];
                     if constexpr (EPI == EPI_RELU || EPI == EPI_RELU_ADD2 || EPI == EPI_RELU_OUT3) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) x[e] = __builtin_amdgcn_fmed3f(x[e], 0.f, __builtin_inff());      // ONE instruction (fmaxf: a canonicalising v_max in front)
                     }
-                    if constexpr (EPI == EPI_RELU_ADD2) x = (bload(r1, po[nt], 64 * mt) + bload(r2, po[nt], 64 * mt)) + x;   // e3 + d1 + d2 (unet.py:563-566)
-                    outv[nt * 3 + mt] = x;
+                    if constexpr (EPI == EPI_RELU_ADD2) x = (bload(r1, po[nt], 64 * (mt0 + mt)) + bload(r2, po[nt], 64 * (mt0 + mt))) + x;   // e3 + d1 + d2 (unet.py:563-566)
+                    outv[nt * MT + mt] = x;
                     if constexpr (EPI == EPI_RELU_OUT3) {
 #pragma unroll
                         for (int c = 0; c < 3; ++c) {
@@ -676,7 +685,7 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3h_kernel(ConvArgs a) {
             float m0 = 0.f, m1 = 0.f;
 #pragma unroll
             for (int i = 0; i < NOUT; ++i) {
-                float& m = (EPI == EPI_POOL || i < 3) ? m0 : m1;
+                float& m = (EPI == EPI_POOL || i < MT) ? m0 : m1;
                 asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(m) : "v"(outv[i][0]), "v"(outv[i][1]));
                 asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(m) : "v"(outv[i][2]), "v"(outv[i][3]));
             }
@@ -722,12 +731,13 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3h_kernel(ConvArgs a) {
     else tile_loop(std::false_type{});
 }
 
-template <int CIN, int EPI, bool ACC_IN, bool UPS, int NGRP, int KS = 3>
+bool g_conv3x3h_cout_split = true;      // conv3x3h_set_cout_split: false = every launch forms all 48 output channels per workgroup (A/B, tests)
+template <int CIN, int EPI, bool ACC_IN, bool UPS, int NGRP, int KS = 3, int MT = 3>
 hipError_t launch_g(const ConvArgs& a0, hipStream_t s) {
     static std::atomic<uint64_t> attr_done{0};
-    using G = HGeo<CIN, NGRP, KS>;
+    using G = HGeo<CIN, NGRP, KS, MT>;
     constexpr int TH = G::TH;
-    void (*kern)(ConvArgs) = conv3x3h_kernel<CIN, EPI, ACC_IN, UPS, NGRP, KS>;
+    void (*kern)(ConvArgs) = conv3x3h_kernel<CIN, EPI, ACC_IN, UPS, NGRP, KS, MT>;
     if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(kern), G::LDS_BYTES, attr_done); e != hipSuccess) return e;
     ConvArgs a = a0;
     a.tiles_x = (a.W + TW - 1) / TW;
@@ -736,18 +746,26 @@ hipError_t launch_g(const ConvArgs& a0, hipStream_t s) {
     const int cus = current_device_cus();
     const int want = (a.ntiles + NGRP - 1) / NGRP;         // one tile per group at least
     const int grid = want < cus ? want : cus;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHREADS), G::LDS_BYTES, s, a);
+    hipLaunchKernelGGL(kern, dim3(grid, MT == 3 ? 1 : 3), dim3(NTHREADS), G::LDS_BYTES, s, a);
     return hipGetLastError();
 }
-
-// The two-group form (NGRP = 2: measured in round 4, +2.6 % stand-alone, nothing in the net) is instantiated for the stand-alone
-// harness only (tools/conv3x3h_bench.hip, -DRVDD_CONV_GROUPS2): the library runs one 16x16 tile per workgroup.
+// Does a launch of this many 16x16 tiles take the output-channel split (MT = 1)?  At most a third of a tile per CU, i.e. every
+// workgroup of the split launch has ONE tile and a CU of its own.  (Measured, profiles/r05y_c1_cout_split.txt: up to one tile per
+// CU -- 85 walkers of three tiles each at 256 tiles -- loses what the coarse levels gain: the halo fetch of a tile does not shrink
+// with the output channels.)
+bool cout_split_applies(const ConvArgs& a) {
+    const int ntiles = a.B * ((a.W + TW - 1) / TW) * ((a.H + 15) / 16);
+    return g_conv3x3h_cout_split && 3 * ntiles <= current_device_cus();
+}
 int g_conv3x3h_groups = 1;
 template <int CIN, int EPI, bool ACC_IN, bool UPS = false>
 hipError_t launch_h(const ConvArgs& a, hipStream_t s) {
 #ifdef RVDD_CONV_GROUPS2
     if (g_conv3x3h_groups == 2) return launch_g<CIN, EPI, ACC_IN, UPS, 2>(a, s);
 #endif
+    if constexpr (CIN == 48 && EPI != EPI_RELU_OUT3) {
+        if (cout_split_applies(a)) return launch_g<CIN, EPI, ACC_IN, UPS, 1, 3, 1>(a, s);
+    }
     return launch_g<CIN, EPI, ACC_IN, UPS, 1>(a, s);
 }
 
@@ -764,6 +782,7 @@ hipError_t launch_conv5x5h_c16(const ConvArgs& a, hipStream_t s) {
     return launch_g<16, EPI_NONE, false, false, 1, 5>(a, s);
 }
 void conv3x3h_set_groups(int g) { g_conv3x3h_groups = g == 1 ? 1 : 2; }
+void conv3x3h_set_cout_split(bool on) { g_conv3x3h_cout_split = on; }
 
 hipError_t launch_conv3x3h(const ConvArgs& a, int cin, int epi, hipStream_t s) {
     if (a.B <= 0 || a.H <= 0 || a.W <= 0) return hipSuccess;

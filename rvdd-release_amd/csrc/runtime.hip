@@ -1002,6 +1002,7 @@ int rvdd_create(const rvdd_cfg* cfg, rvdd_t** out) {
     // hardware queue the device's scheduler keeps mapped, and a handle that merely EXISTED beside another one -- with the two idle
     // streams every handle used to create -- made that one's cooperative TV-L1 launches and the kernels behind them 20 % slower
     // (profiles/r05k_online_flow_two_handles.txt)
+    if (const char* cs = std::getenv("RVDD_COUT_SPLIT")) conv3x3h_set_cout_split(std::atoi(cs) != 0);      // process-wide A/B switch
     if (const char* gv = std::getenv("RVDD_GRAPH")) h->use_graphs = std::atoi(gv) != 0 && graph_stream(h);
     *out = h;
     return RVDD_OK;
@@ -1207,6 +1208,12 @@ int rvdd_set_option(rvdd_t* h, const char* name, int32_t value) {
         h->next_projfuse = value != 0;
         return RVDD_OK;
     }
+    if (std::strcmp(name, "cout_split") == 0) {
+        // 0 = every launch of the split-f16 conv kernel forms all 48 output channels per workgroup (A/B reference of the
+        // output-channel split that launches of at most a third of a tile per CU take; same bits).  Process-wide.
+        conv3x3h_set_cout_split(value != 0);
+        return RVDD_OK;
+    }
     if (std::strcmp(name, "tvl1_async") == 0) {
         // 1 = rvdd_tvl1flow_batch without iteration counts enqueues its launches and returns; its control word is read by the next
         // synchronising call.  0 switches back and reports what is pending now.
@@ -1250,7 +1257,7 @@ int rvdd_set_option(rvdd_t* h, const char* name, int32_t value) {
         h->split16 = value == 0;
         return RVDD_OK;
     }
-    return fail(h, RVDD_ERR_ARG, "rvdd_set_option: unknown option '%s' (known: no_warp, warp_raw, prev_noisy_frame, conv_kernel, seq_major, graphs, fuse_upsample, next_fused, next_split, next_pipe, next_pool, next_projfuse, tvl1_async, block_fp, fuse_pre)", name);
+    return fail(h, RVDD_ERR_ARG, "rvdd_set_option: unknown option '%s' (known: no_warp, warp_raw, prev_noisy_frame, conv_kernel, seq_major, graphs, fuse_upsample, next_fused, next_split, next_pipe, next_pool, next_projfuse, tvl1_async, block_fp, fuse_pre, cout_split)", name);
 }
 
 int rvdd_reset(rvdd_t* h) {

@@ -158,6 +158,7 @@ hipError_t launch_conv5x5h_c16(const ConvArgs& a, hipStream_t s);
 size_t conv5x5h_weight_bytes();
 hipError_t launch_pre_border_fix(const float* netin, const float* w1, const float* b1, const float* w2, float* part, int B, int H, int W,
                                  hipStream_t s);
+void conv3x3h_set_cout_split(bool on);   // false: no launch takes the output-channel split of small launches (conv3x3h.hip MT = 1); process-wide
 void conv3x3h_set_groups(int g);   // stand-alone harness (-DRVDD_CONV_GROUPS2): 2 = two groups of four waves with an 8x16 tile each
 void conv3x3_set_variant(int v);   // A/B switch used by rvdd_debug_conv_bench only
 

@@ -1052,6 +1052,42 @@ def test_pipelined_convblock_equals_phased():
         assert torch.equal(outs[0][1], outs[1][1]), (B, H, W)
 
 
+@pytest.mark.parametrize("arch,stem,fut", [("convunet", "recurrent-convunet-iso3200", 0), ("convunet+feat", "recurrent-convunet+feat-future-iso12800", 1)])
+def test_conv_output_channel_split_same_bits(arch, stem, fut):
+    """Launches of the split-f16 conv kernel with at most a third of a 16x16 tile per compute unit (the coarse levels of a small
+    sequence) give each tile to THREE workgroups of 16 output channels (conv3x3h.hip MT = 1; option cout_split 0: one workgroup,
+    48 channels): the same sums per output channel in the same order -- frames and features bit for bit.  Sizes whose levels
+    fall on both sides of the threshold, ragged tiles, zero-padded decoder levels (odd level sizes), batches; every epilogue
+    (plain, pooling, two-pass, fused upsample, bottleneck sum) takes the split at some level."""
+    from rvdd_release_amd import synth
+    from rvdd_release_amd.runtime import RvddRuntime
+    sd = load_weights(stem)
+    for B, H, W in ((1, 256, 256), (1, 64, 96), (2, 72, 104), (1, 36, 52), (3, 22, 130), (1, 360, 640)):
+        T = 3 + fut
+        seqs = [synth.make_sequence(T, H, W, iso=3200, seed=690 + b, device="cuda") for b in range(B)]
+        st = lambda f: torch.stack([f(s) for s in seqs], 0)
+        outs = []
+        try:
+            for split in (1, 0):
+                rt = RvddRuntime(arch, fut, B, H, W, 0)
+                rt.set_option("cout_split", split)
+                rt.load_state_dict(sd)
+                o = []
+                for t in range(1, T - fut):
+                    o.append(rt.step(st(lambda s: s.raw[t - 1]) if t == 1 else None, st(lambda s: s.raw[t]),
+                                     st(lambda s: s.raw[t + 1]) if fut else None, st(lambda s: s.flow_prev[t]),
+                                     st(lambda s: s.flow_next[t]) if fut else None).clone())
+                outs.append((o, rt.get_state()[1]))
+                rt.close()
+        finally:
+            from rvdd_release_amd.util._ops import ops_runtime
+            ops_runtime(0).set_option("cout_split", 1)          # process-wide switch: back to the default
+        for a, b in zip(outs[0][0], outs[1][0]):
+            assert torch.equal(a, b), (arch, B, H, W, float((a - b).abs().max()))
+        if outs[0][1] is not None:
+            assert torch.equal(outs[0][1], outs[1][1]), (arch, B, H, W)
+
+
 def test_projection_halves_equal_projection_kernel():
     """The 96 -> 48 projection behind cat((x_dec, x_enc)) (networks/new_unet.py:321-329, 85-88) as two 48 -> 48 halves in the
     epilogues of the blocks that form x_enc and x_dec (the default) against proj1x1_kernel on the concatenated maps (option
