@@ -71,18 +71,18 @@ rep('''    auto read_frags = [&](int buf, int j) {''', '''    auto read_frags = 
         if (j >= 2) return;
 #endif''')
 # 16: the epilogue's arithmetic (scale / bias / activation / maxima) replaced by a copy of the accumulators
-rep('''        f32x4 v[2][3];
+rep('''        f32x4 v[2][MT];
         float m3 = 0.f;''', '''#if RVDD_XP & 16
         {
-            constexpr int NO = EPI == EPI_POOL ? 3 : 6;
-            for (int i = 0; i < NO; ++i) outv[i] = acc[i / 3][i % 3];
+            constexpr int NO = (EPI == EPI_POOL ? 1 : 2) * MT;
+            for (int i = 0; i < NO; ++i) outv[i] = acc[i / MT][i % MT];
             so_prev[0] = so[0];
             so_prev[1] = so[1];
             orr_prev = __builtin_amdgcn_make_buffer_rsrc((void*)(a.out + (size_t)cur.b * a.Hout * a.Wout * kF), 0, out_bytes, 0x00020000);
             goto after_epilogue;
         }
 #endif
-        f32x4 v[2][3];
+        f32x4 v[2][MT];
         float m3 = 0.f;''')
 rep('''        STAMP(4);
         gsync();               // every wave of the group has read its last fragment''', '''#if RVDD_XP & 16
@@ -100,7 +100,7 @@ rep('''    auto gsync = [&]() {
 # halves (split4) and the halves of two neighbouring channel groups change lanes (two v_permlane16_swap), so that a lane again
 # stores one 16-B piece ([hi of 8 channels] or [lo of 8 channels]); with bit 2 (no input side in the consumer) this is the UPPER
 # bound of "maps stored split, halo by LDS-DMA" (VERDICT r4 item 3): the DMA itself and its addresses are still missing
-rep('''                    outv[nt * 3 + mt] = x;''', '''#if RVDD_XP & 64
+rep('''                    outv[nt * MT + mt] = x;''', '''#if RVDD_XP & 64
                     {
                         u32x2 hh_, ll_;
                         split4<false>(x, 1.f, hh_, ll_);
@@ -109,7 +109,11 @@ rep('''                    outv[nt * 3 + mt] = x;''', '''#if RVDD_XP & 64
                         x = __builtin_bit_cast(f32x4, u32x4{s0_[0], s1_[0], s0_[1], s1_[1]});
                     }
 #endif
-                    outv[nt * 3 + mt] = x;''')
+                    outv[nt * MT + mt] = x;''')
+# 256 (round 5): no filter-bank copy at the top of the kernel (what a launch of one tile per workgroup pays for it)
+rep('''        for (int i = wave; i < NP; i += NTHREADS / 64) {
+            int k = i + rot;''', '''        for (int i = wave; i < NP && !(RVDD_XP & 256); i += NTHREADS / 64) {
+            int k = i + rot;''')
 s = s.replace('#include "rvdd_internal.h"', '#ifndef RVDD_XP\n#define RVDD_XP 0\n#endif\n#include "rvdd_internal.h"', 1)
 out = sys.argv[1]
 os.makedirs(os.path.dirname(out) or ".", exist_ok=True)
