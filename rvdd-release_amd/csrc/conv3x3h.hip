@@ -63,9 +63,9 @@ constexpr int NTHREADS = 512;
 // pre_border_fix_kernel below.
 // MT = 3 (every launch with enough tiles): a workgroup forms all 48 output channels of its tiles.  MT = 1 (launches with at most a
 // third of a tile per CU -- the coarse levels of one small sequence): a workgroup forms ONE block of 16 output channels
-// (blockIdx.y), three workgroups share a tile: a launch of one tile per workgroup is the copy of its filter bank (84 KiB at the
-// 11-16 GB/s an LDS-DMA stream delivers: 6 us) plus the tile (3 us) plus the ramp, and a third of the bank and of the MFMAs per
-// workgroup is most of it gone.  Same sums per output channel in the same order: the same bits.
+// (blockIdx.y), three workgroups share a tile: a launch of one tile per workgroup is one workgroup's serial path (fetch, staging,
+// 252 MFMAs per wave = 4 us, epilogue, tail: 10 us whatever the level) on as many CUs as it has tiles, and a third of the MFMAs per
+// workgroup on three times the CUs takes 3 us off it.  Same sums per output channel in the same order: the same bits.
 template <int CIN, int NGRP, int KS = 3, int MT = 3>
 struct HGeo {
     static constexpr int PAD = KS / 2;
