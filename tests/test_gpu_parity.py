@@ -1118,6 +1118,25 @@ def test_projection_halves_equal_projection_kernel():
             rt.close()
         for a, b in zip(outs[0][0] + [outs[0][1]], outs[1][0] + [outs[1][1]]):
             assert float((a - b).abs().max()) <= 5e-6 * max(1.0, float(b.abs().max())), (B, H, W, float((a - b).abs().max()))
+    # the feature warp's half (warp48_proj_kernel) on flows that leave the frame and differ from pixel to pixel: clamped taps, pixel
+    # pairs whose footprints do not line up -- against warp48_kernel + the projection kernel
+    B, H, W, T = 2, 72, 104, 4
+    gen = torch.Generator(device="cpu").manual_seed(5)
+    seqs = [synth.make_sequence(T, H, W, iso=3200, seed=680 + b, device="cuda") for b in range(B)]
+    st = lambda f: torch.stack([f(s) for s in seqs], 0)
+    wild = lambda fl: fl * 6.0 + (torch.randn(fl.shape, generator=gen) * 9.0).cuda()
+    fp = {t: wild(st(lambda s: s.flow_prev[t])) for t in range(1, T - fut)}
+    outs = []
+    for fuse in (1, 0):
+        rt = RvddRuntime(arch, fut, B, H, W, 0)
+        rt.set_option("next_projfuse", fuse)
+        rt.load_state_dict(sd)
+        o = [rt.step(st(lambda s: s.raw[t - 1]) if t == 1 else None, st(lambda s: s.raw[t]), st(lambda s: s.raw[t + 1]), fp[t],
+                     st(lambda s: s.flow_next[t])).clone() for t in range(1, T - fut)]
+        outs.append(o + [rt.get_state()[1].clone()])
+        rt.close()
+    for a, b in zip(*outs):      # (frames of this chaos are rougher and the rounding of the two summation orders shows more: observed 9e-6)
+        assert torch.isfinite(a).all() and float((a - b).abs().max()) <= 2e-5 * max(1.0, float(b.abs().max())), float((a - b).abs().max())
 
 
 def test_pooling_epilogue_equals_maxpool_kernel():
