@@ -296,7 +296,7 @@ __global__ __launch_bounds__(256) void netin_kernel(NetinArgs a, float* __restri
 // through LDS (pixel pitch 24 floats: the 16 lanes of a ds_read_b128 group on 16 distinct bank quads) and each wave projects
 // four 16-pixel groups on the f32 matrix pipe (16x16x4, exact f32 products).  pw as proj1x1_kernel<16, 0>'s:
 // [m 3][lr 16][g 4][i 4] = W[16m+lr][4g+i] (zero for channels the input does not have).
-__global__ __launch_bounds__(256) void netin_proj_kernel(NetinArgs a, const float* __restrict__ pw, const float* __restrict__ bias,
+__global__ __launch_bounds__(256, 5) void netin_proj_kernel(NetinArgs a, const float* __restrict__ pw, const float* __restrict__ bias,
                                                          float* __restrict__ out) {
     __shared__ __attribute__((aligned(16))) float s_t[256][24];
     const size_t total = (size_t)a.B * 4 * a.h * a.w;
