@@ -614,7 +614,7 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3h_kernel(ConvArgs a) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float q = fmaxf(v[0][mt][e], v[1][mt][e]);
-                    outv[mt][e] = fmaxf(q, __shfl_xor(q, 1));
+                    outv[mt][e] = lane_xor_max<1>(q);
                 }
         } else {
             float o3[2][3];
@@ -654,8 +654,8 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3h_kernel(ConvArgs a) {
 #pragma unroll
                     for (int c = 0; c < 3; ++c) {
                         float q = o3[nt][c];
-                        q += __shfl_xor(q, 16);
-                        q += __shfl_xor(q, 32);
+                        q = lane_xor_add<16>(q);
+                        q = lane_xor_add<32>(q);
                         tq[c] = q + Pl[4 * kF + c];
                     }
                     // (the output frame's maximum joins the features' in this launch's words: the next step's input bound reads them)

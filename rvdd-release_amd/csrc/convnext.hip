@@ -242,8 +242,8 @@ __global__ __launch_bounds__(256, 2) void dwln_kernel(const float* __restrict__ 
             float sm = 0.f;
 #pragma unroll
             for (int j = 0; j < 3; ++j) sm += (acc[i][j][0] + acc[i][j][1]) + (acc[i][j][2] + acc[i][j][3]);
-            sm += __shfl_xor(sm, 1);
-            sm += __shfl_xor(sm, 2);
+            sm = lane_xor_add<1>(sm);
+            sm = lane_xor_add<2>(sm);
             const float u = sm / 48.f;
             float v2 = 0.f;
 #pragma unroll
@@ -253,8 +253,8 @@ __global__ __launch_bounds__(256, 2) void dwln_kernel(const float* __restrict__ 
                     const float d = acc[i][j][r] - u;
                     v2 += d * d;
                 }
-            v2 += __shfl_xor(v2, 1);
-            v2 += __shfl_xor(v2, 2);
+            v2 = lane_xor_add<1>(v2);
+            v2 = lane_xor_add<2>(v2);
             // (x - u) / sqrt(var + eps) as (x - u) * (1 / sqrt(...)): one correctly rounded division per pixel instead
             // of twelve per lane (each ~10 instructions); the quotient moves by at most one ulp
             const float rden = 1.0f / sqrtf(v2 / 48.f + 1e-6f);
@@ -567,8 +567,8 @@ __global__ __launch_bounds__(64 * NW, NPB == 2 ? 1 : 8 / NW) void mlp_kernel(con
 #pragma unroll
                     for (int c = 0; c < 3; ++c) {
                         float v = part[n][c];
-                        v += __shfl_xor(v, 16);
-                        v += __shfl_xor(v, 32);
+                        v = lane_xor_add<16>(v);
+                        v = lane_xor_add<32>(v);
                         t[c] = v + BV[M2_BV_FLOATS + 144 + c];
                     }
                     const long pix = (blk * NPB + n) * 16 + lr;
@@ -840,8 +840,8 @@ __global__ __launch_bounds__(512, 2) void convblock_kernel(const float* __restri
             float sm = 0.f;
 #pragma unroll
             for (int j = 0; j < 3; ++j) sm += (acc[i][j][0] + acc[i][j][1]) + (acc[i][j][2] + acc[i][j][3]);
-            sm += __shfl_xor(sm, 1);
-            sm += __shfl_xor(sm, 2);
+            sm = lane_xor_add<1>(sm);
+            sm = lane_xor_add<2>(sm);
             const float u = sm / 48.f;
             float v2 = 0.f;
 #pragma unroll
@@ -851,8 +851,8 @@ __global__ __launch_bounds__(512, 2) void convblock_kernel(const float* __restri
                     const float d = acc[i][j][r] - u;
                     v2 += d * d;
                 }
-            v2 += __shfl_xor(v2, 1);
-            v2 += __shfl_xor(v2, 2);
+            v2 = lane_xor_add<1>(v2);
+            v2 = lane_xor_add<2>(v2);
             const float rden = 1.0f / sqrtf(v2 / 48.f + 1e-6f);
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
@@ -1051,7 +1051,7 @@ __global__ __launch_bounds__(512, 2) void convblock_kernel(const float* __restri
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             const float a = fmaxf(vkeep[mo][e], v[e]);
-                            m[e] = fmaxf(a, __shfl_xor(a, 1));
+                            m[e] = lane_xor_max<1>(a);
                         }
                         bstore(rp, (lr & 1) ? 0x80000000u : (unsigned)((lr >> 1) * (kF * 4) + kk * 16 + 64 * mo), m);
                     }
@@ -1069,8 +1069,8 @@ __global__ __launch_bounds__(512, 2) void convblock_kernel(const float* __restri
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
                     float v = part[c];
-                    v += __shfl_xor(v, 16);
-                    v += __shfl_xor(v, 32);
+                    v = lane_xor_add<16>(v);
+                    v = lane_xor_add<32>(v);
                     t[c] = v + BV[M2_BV_FLOATS + 144 + c];
                 }
                 if (kk == 0 && lr < valid) {
@@ -1299,8 +1299,8 @@ __global__ __launch_bounds__(512, 2) void convblock_pipe_kernel(const float* __r
                 float sm = 0.f;
 #pragma unroll
                 for (int j = 0; j < 3; ++j) sm += (acc[i][j][0] + acc[i][j][1]) + (acc[i][j][2] + acc[i][j][3]);
-                sm += __shfl_xor(sm, 1);
-                sm += __shfl_xor(sm, 2);
+                sm = lane_xor_add<1>(sm);
+                sm = lane_xor_add<2>(sm);
                 const float u = sm / 48.f;
                 float v2 = 0.f;
 #pragma unroll
@@ -1310,8 +1310,8 @@ __global__ __launch_bounds__(512, 2) void convblock_pipe_kernel(const float* __r
                         const float d = acc[i][j][r] - u;
                         v2 += d * d;
                     }
-                v2 += __shfl_xor(v2, 1);
-                v2 += __shfl_xor(v2, 2);
+                v2 = lane_xor_add<1>(v2);
+                v2 = lane_xor_add<2>(v2);
                 const float rden = 1.0f / sqrtf(v2 / 48.f + 1e-6f);
 #pragma unroll
                 for (int j = 0; j < 3; ++j) {
@@ -1568,7 +1568,7 @@ __global__ __launch_bounds__(512, 2) void convblock_pipe_kernel(const float* __r
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             const float a = fmaxf(v[0][mo][e], v[1][mo][e]);
-                            m[e] = fmaxf(a, __shfl_xor(a, 1));
+                            m[e] = lane_xor_max<1>(a);
                         }
                         bstore(rp, (lr & 1) ? 0x80000000u : (unsigned)((lr >> 1) * (kF * 4) + kk * 16 + 64 * mo), m);
                     }
@@ -1585,8 +1585,8 @@ __global__ __launch_bounds__(512, 2) void convblock_pipe_kernel(const float* __r
                                 const f32x4 w3 = bvp[M2_BV_FLOATS / 4 + c * 12 + 4 * mo];
                                 pc += (v[q][mo][0] * w3[0] + v[q][mo][1] * w3[1]) + (v[q][mo][2] * w3[2] + v[q][mo][3] * w3[3]);
                             }
-                            pc += __shfl_xor(pc, 16);
-                            pc += __shfl_xor(pc, 32);
+                            pc = lane_xor_add<16>(pc);
+                            pc = lane_xor_add<32>(pc);
                             t[c] = pc + BV[M2_BV_FLOATS + 144 + c];
                         }
                         if (kk == 0 && lr < valid[q]) {

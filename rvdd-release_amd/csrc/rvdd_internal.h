@@ -103,6 +103,44 @@ __host__ __device__ inline float pow2f(int k) {          // 2^k, |k| <= 126
     return f;
 }
 #ifdef __HIPCC__
+// v (+ | max) the same variable of the lane whose index differs in bit 0 / 1 (a quad neighbour: DPP quad_perm) or in bit 4 / 5
+// (v_permlane16_swap / v_permlane32_swap): what `v + __shfl_xor(v, MASK)` / `fmaxf(v, __shfl_xor(v, MASK))` give, bit for bit
+// (addition and maximum commute) -- without the LDS round trip of the ds_bpermute_b32 hipcc lowers __shfl_xor to.  Every lane active.
+template <int MASK>
+__device__ __forceinline__ void lane_xor_pair(float v, float& a, float& b) {
+    static_assert(MASK == 1 || MASK == 2 || MASK == 16 || MASK == 32, "quad neighbours and row pairs only");
+    const int u = __builtin_bit_cast(int, v);
+    if constexpr (MASK == 1) {
+        a = v;
+        b = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, u, 0xB1, 0xf, 0xf, true));      // quad_perm:[1,0,3,2]
+    } else if constexpr (MASK == 2) {
+        a = v;
+        b = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, u, 0x4E, 0xf, 0xf, true));      // quad_perm:[2,3,0,1]
+    } else if constexpr (MASK == 16) {
+        // {own, partner} or {partner, own}.  (Elements into scalars first: __builtin_bit_cast of r[1] itself reads r[0].)
+        const auto r = __builtin_amdgcn_permlane16_swap((unsigned)u, (unsigned)u, false, false);
+        const unsigned r0 = r[0], r1 = r[1];
+        a = __builtin_bit_cast(float, r0);
+        b = __builtin_bit_cast(float, r1);
+    } else {
+        const auto r = __builtin_amdgcn_permlane32_swap((unsigned)u, (unsigned)u, false, false);
+        const unsigned r0 = r[0], r1 = r[1];
+        a = __builtin_bit_cast(float, r0);
+        b = __builtin_bit_cast(float, r1);
+    }
+}
+template <int MASK>
+__device__ __forceinline__ float lane_xor_add(float v) {
+    float a, b;
+    lane_xor_pair<MASK>(v, a, b);
+    return a + b;
+}
+template <int MASK>
+__device__ __forceinline__ float lane_xor_max(float v) {
+    float a, b;
+    lane_xor_pair<MASK>(v, a, b);
+    return fmaxf(a, b);
+}
 // max over the 64 lanes of a wave of an unsigned value (DPP; every lane must be active): the result, wave-uniform
 __device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
     v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true));      // row_shr:1
