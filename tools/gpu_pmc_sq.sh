@@ -12,8 +12,9 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 BENCH="python3 $ROOT/bench.py --steps 1 --warmup 1 --cpu-frames 0 --no-exact-ab --no-other-configs --frames 4 --no-kernel-events $*"
 rc=0
-for C in MfmaUtil SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU; do
-  timeout -k 10 400 rocprofv3 --pmc $C --output-format csv -d $OUT/$C -- $BENCH > $OUT/$C.log 2>&1 || { rc=$?; break; }
+# SQ_COUNTERS="A B ..." picks other counters (one the hardware does not know fails its own pass only)
+for C in ${SQ_COUNTERS:-MfmaUtil SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU}; do
+  timeout -k 10 400 rocprofv3 --pmc $C --output-format csv -d $OUT/$C -- $BENCH > $OUT/$C.log 2>&1 || { rc=$?; echo "$C: pass failed ($rc)"; [ -n "$SQ_COUNTERS" ] || break; }
 done
 ls $OUT | head -20
 exit $rc
