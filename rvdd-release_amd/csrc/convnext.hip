@@ -919,7 +919,7 @@ __global__ __launch_bounds__(512, 2) void convblock_kernel(const float* __restri
 #pragma unroll
                 for (int j = 0; j < 3; ++j) split4h(xc[n][j], xh[j], xl[j]);
                 const h8v B1 = cat8(xh[0], xh[1]), B2 = cat8(xl[0], xl[1]), B3 = cat8(xh[2], xh[2]);
-                const h8v B4 = cat8(xl[2], xl[2]);
+                const h8v B4 = cat8(xl[2], u32x2v{0u, 0u});       // (its other half would meet the filters' lo halves: lo x lo, below the split's own error)
 #pragma unroll
                 for (int mo = 0; mo < 3; ++mo) a2[mo] = bvp[48 + 4 * mo];
 #pragma unroll
@@ -1391,7 +1391,7 @@ __global__ __launch_bounds__(512, 2) void convblock_pipe_kernel(const float* __r
                     B1[q] = cat8(xh[0], xh[1]);
                     B2[q] = cat8(xl[0], xl[1]);
                     B3[q] = cat8(xh[2], xh[2]);
-                    B4[q] = cat8(xl[2], xl[2]);
+                    B4[q] = cat8(xl[2], u32x2v{0u, 0u});       // (the other half would meet the filters' lo halves: lo x lo; zeros also cost the matrix pipe less)
 #pragma unroll
                     for (int mo = 0; mo < 3; ++mo) a2[q][mo] = bvp[48 + 4 * mo];
 #pragma unroll
@@ -1525,7 +1525,7 @@ __global__ __launch_bounds__(512, 2) void convblock_pipe_kernel(const float* __r
                         P1[q] = cat8(xh[0], xh[1]);
                         P2[q] = cat8(xl[0], xl[1]);
                         P3[q] = cat8(xh[2], xh[2]);
-                        P4[q] = cat8(xl[2], xl[2]);
+                        P4[q] = cat8(xl[2], u32x2v{0u, 0u});
                     }
                     f32x4 pr[2][3];
                     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};

@@ -585,7 +585,7 @@ __global__ __launch_bounds__(192) void warp48_proj_kernel(const float* __restric
     const wp_h8 P1 = __builtin_bit_cast(wp_h8, wp_u32x4{xh[0][0], xh[0][1], xh[1][0], xh[1][1]});
     const wp_h8 P2 = __builtin_bit_cast(wp_h8, wp_u32x4{xl[0][0], xl[0][1], xl[1][0], xl[1][1]});
     const wp_h8 P3 = __builtin_bit_cast(wp_h8, wp_u32x4{xh[2][0], xh[2][1], xh[2][0], xh[2][1]});
-    const wp_h8 P4 = __builtin_bit_cast(wp_h8, wp_u32x4{xl[2][0], xl[2][1], xl[2][0], xl[2][1]});
+    const wp_h8 P4 = __builtin_bit_cast(wp_h8, wp_u32x4{xl[2][0], xl[2][1], 0u, 0u});
     const int x = x0 + 16 * wv + lr;
 #pragma unroll
     for (int m = 0; m < 3; ++m) {
