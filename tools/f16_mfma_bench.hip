@@ -3,7 +3,8 @@
 // v_mfma_f32_16x16x32_f16 with f32 accumulation.  Questions answered here, each needed by the conv / MLP kernels:
 //   1. cycles per MFMA of the f16 forms next to v_mfma_f32_16x16x4_f32 (one wave per SIMD, back to back);
 //   2. how many plain vector instructions of the SAME wave fit between two f16 MFMAs without stretching them, and what a
-//      second wave per SIMD issuing only vector instructions costs (the f32 MFMA runs on the SIMD's f32 lanes, so there
+//      second wave per SIMD issuing only vector instructions costs (round 5: nothing -- the 52-55 cycles per MFMA the first version
+//      reported for split roles were its own two branches per MFMA slot; the role is now decided outside the loop) (the f32 MFMA runs on the SIMD's f32 lanes, so there
 //      the two add; the f16 MFMA should not);
 //   3. does the f16 MFMA keep subnormal operands (lo of a small x is subnormal), and how close is the 3-product sum to
 //      the exact product of the f32 values.
@@ -27,7 +28,8 @@ typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 constexpr int ITER = 2000;
 
 // KIND 0: f32 16x16x4, 1: f16 16x16x32, 2: f16 16x16x16, 3: f16 32x32x16
-// MODE 0: every wave issues NM MFMAs with NV vector instructions spread between them; 1: waves 0-3 MFMAs, waves 4-7 vector only
+// MODE 0: every wave issues NM MFMAs with NV vector instructions spread between them; 1: waves 0-3 MFMAs, waves 4-7 vector only;
+// 2: as 1 with s_setprio 3 on the MFMA waves; 3: as 1 with s_setprio 3 on the vector waves (round 5: which way does the arbiter lean?)
 template <int KIND, int NM, int NV, int MODE>
 __global__ __launch_bounds__(512) void bench(float* sink, long long* cycles) {
     extern __shared__ float lds[];
@@ -59,25 +61,43 @@ __global__ __launch_bounds__(512) void bench(float* sink, long long* cycles) {
     const float inc = 1e-3f;
     const bool do_m = MODE == 0 || wave < 4;
     const bool do_v = MODE == 0 || wave >= 4;
+    if (MODE == 2 && wave < 4) __builtin_amdgcn_s_setprio(3);
+    if (MODE == 3 && wave >= 4) __builtin_amdgcn_s_setprio(3);
     __syncthreads();
     const long long t0 = __builtin_amdgcn_s_memtime();
+    auto mfma_slot = [&](int i) {
+        if (KIND == 0) acc[i % 8] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[i % 8], 0, 0, 0);
+        if (KIND == 1) acc[i % 8] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a8, b8, acc[i % 8], 0, 0, 0);
+        if (KIND == 2) acc[i % 8] = __builtin_amdgcn_mfma_f32_16x16x16f16(a4, b4, acc[i % 8], 0, 0, 0);
+        if (KIND == 3) acc32[i % 2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a8, b8, acc32[i % 2], 0, 0, 0);
+    };
+    if (MODE == 0) {
 #pragma unroll 1
-    for (int it = 0; it < ITER; ++it) {
+        for (int it = 0; it < ITER; ++it) {
 #pragma unroll
-        for (int i = 0; i < (NM > 0 ? NM : 1); ++i) {
-            if (do_m && NM > 0) {
-                if (KIND == 0) acc[i % 8] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[i % 8], 0, 0, 0);
-                if (KIND == 1) acc[i % 8] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a8, b8, acc[i % 8], 0, 0, 0);
-                if (KIND == 2) acc[i % 8] = __builtin_amdgcn_mfma_f32_16x16x16f16(a4, b4, acc[i % 8], 0, 0, 0);
-                if (KIND == 3) acc32[i % 2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a8, b8, acc32[i % 2], 0, 0, 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            if (do_v) {
+            for (int i = 0; i < (NM > 0 ? NM : 1); ++i) {
+                if (NM > 0) mfma_slot(i);
+                __builtin_amdgcn_sched_barrier(0);
                 constexpr int PER = NM > 0 ? NV / NM : NV;
 #pragma unroll
                 for (int j = 0; j < PER; ++j) asm volatile("v_add_f32 %0, %0, %1" : "+v"(v[(i * PER + j) % 16]) : "v"(inc));
+                __builtin_amdgcn_sched_barrier(0);
             }
-            __builtin_amdgcn_sched_barrier(0);
+        }
+    } else if (do_m) {      // the role is decided OUTSIDE the loop (round 3's version branched twice per MFMA slot: 52 cycles per slot were the branches)
+#pragma unroll 1
+        for (int it = 0; it < ITER; ++it) {
+#pragma unroll
+            for (int i = 0; i < NM; ++i) {
+                mfma_slot(i);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    } else {
+#pragma unroll 1
+        for (int it = 0; it < ITER; ++it) {
+#pragma unroll
+            for (int j = 0; j < NV; ++j) asm volatile("v_add_f32 %0, %0, %1" : "+v"(v[j % 16]) : "v"(inc));
         }
     }
     const long long t1 = __builtin_amdgcn_s_memtime();
@@ -106,7 +126,7 @@ void run(int threads, const char* label, float* sink, long long* dcyc) {
     std::vector<double> mw, vw;
     const int waves = threads / 64;
     for (int b = 0; b < blocks; ++b)
-        for (int w = 0; w < waves; ++w) ((MODE == 1 && w >= 4) ? vw : mw).push_back((double)h[b * 8 + w] / ITER);
+        for (int w = 0; w < waves; ++w) ((MODE >= 1 && w >= 4) ? vw : mw).push_back((double)h[b * 8 + w] / ITER);
     std::sort(mw.begin(), mw.end());
     std::sort(vw.begin(), vw.end());
     static const char* kn[] = {"f32 16x16x4", "f16 16x16x32", "f16 16x16x16", "f16 32x32x16"};
@@ -231,6 +251,10 @@ int main() {
     run<1, 8, 16, 1>(512, "split roles", sink, dcyc);
     run<1, 8, 32, 1>(512, "split roles", sink, dcyc);
     run<1, 8, 64, 1>(512, "split roles", sink, dcyc);
+    run<1, 8, 16, 2>(512, "split roles, prio on MFMA waves", sink, dcyc);
+    run<1, 8, 32, 2>(512, "split roles, prio on MFMA waves", sink, dcyc);
+    run<1, 8, 64, 2>(512, "split roles, prio on MFMA waves", sink, dcyc);
+    run<1, 8, 32, 3>(512, "split roles, prio on vector waves", sink, dcyc);
     run<0, 8, 32, 1>(512, "split roles", sink, dcyc);
     run<0, 8, 64, 1>(512, "split roles", sink, dcyc);
     run<1, 0, 64, 0>(256, "valu only, 1 wave/SIMD", sink, dcyc);
