@@ -659,6 +659,46 @@ __device__ __forceinline__ void split4h(f32x4 x, u32x2v& hi, u32x2v& lo) {
 }
 __device__ __forceinline__ h8v cat8(u32x2v a, u32x2v b) { return __builtin_bit_cast(h8v, u32x4{a[0], a[1], b[0], b[1]}); }
 
+// gelu_phi4_scaled + split4h in six stages (the same instructions on the same values, hence the same bits), so that a wave can deal
+// them out between the MFMAs of ANOTHER pixel group (convblock_pipe_kernel's back waves): 8 | 4 | 4 | 4 | 4 | 10 instructions.
+struct GeluStages {
+    f32x2 t[2], r[2], p[2];
+};
+template <int S>
+__device__ __forceinline__ void gelu_stage(GeluStages& g, const f32x4& h, const float (&gc)[7][2], u32x2v& hi, u32x2v& lo) {
+    auto K = [&](int i) { return f32x2{gc[i][0], gc[i][1]}; };
+    if constexpr (S == 0) {
+        const float zero = 0.0f, cap = gc[6][0];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) g.t[k >> 1][k & 1] = __builtin_amdgcn_fmed3f(__builtin_fabsf(h[k]), zero, cap);
+        typedef int i32x4 __attribute__((ext_vector_type(4)));
+        const f32x4 r4 = __builtin_bit_cast(f32x4, __builtin_elementwise_max(__builtin_bit_cast(i32x4, h), i32x4{0, 0, 0, 0}));
+        g.r[0] = f32x2{r4[0], r4[1]};
+        g.r[1] = f32x2{r4[2], r4[3]};
+    } else if constexpr (S == 1) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c) g.p[c] = __builtin_elementwise_fma(K(0), g.t[c], K(1));
+#pragma unroll
+        for (int c = 0; c < 2; ++c) g.p[c] = __builtin_elementwise_fma(g.p[c], g.t[c], K(2));
+    } else if constexpr (S == 2) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c) g.p[c] = __builtin_elementwise_fma(g.p[c], g.t[c], K(3));
+#pragma unroll
+        for (int c = 0; c < 2; ++c) g.p[c] = __builtin_elementwise_fma(g.p[c], g.t[c], K(4));
+    } else if constexpr (S == 3) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c) g.p[c] = __builtin_elementwise_fma(g.p[c], g.t[c], K(5));
+#pragma unroll
+        for (int c = 0; c < 2; ++c) g.p[c] = __builtin_elementwise_fma(g.t[c], g.p[c], f32x2{-1.0f, -1.0f});
+    } else if constexpr (S == 4) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) g.p[k >> 1][k & 1] = __builtin_amdgcn_exp2f(g.p[k >> 1][k & 1]);
+    } else {
+        const f32x2 o0 = __builtin_elementwise_fma(-g.t[0], g.p[0], g.r[0]), o1 = __builtin_elementwise_fma(-g.t[1], g.p[1], g.r[1]);
+        split4h(f32x4{o0[0], o0[1], o1[0], o1[1]}, hi, lo);
+    }
+}
+
 // Vector-memory instructions EVERY wave issues in the MLP phase of a tile, i.e. after the LDS-DMA of the next tile's
 // first two chunks: per 16-pixel group 3 residual loads + 3 stores through buffer descriptors (issued whether the row
 // exists or not: a missing row has zero records).  vmcnt retires in issue order, so "all but the newest 24" covers the
@@ -1435,47 +1475,59 @@ __global__ __launch_bounds__(512, 2) void convblock_pipe_kernel(const float* __r
                         gl[mo] = FG(p, mo, 1);
                     }
                     __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int q = 0; q < 2; ++q)
-#pragma unroll
-                        for (int k = 0; k < 2; ++k) hq[q][k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[cb][k], B2[q], hq[q][k], 0, 0, 0);
-#pragma unroll
-                    for (int q = 0; q < 2; ++q)
-#pragma unroll
-                        for (int k = 0; k < 2; ++k) hq[q][k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[cb][k], B1[q], hq[q][k], 0, 0, 0);
-#pragma unroll
-                    for (int q = 0; q < 2; ++q)
-#pragma unroll
-                        for (int k = 0; k < 2; ++k) hq[q][k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fc[cb][k], B4[q], hq[q][k], 0, 0, 0);
-#pragma unroll
-                    for (int q = 0; q < 2; ++q)
-#pragma unroll
-                        for (int k = 0; k < 2; ++k) hq[q][k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fc[cb][k], B3[q], hq[q][k], 0, 0, 0);
-#pragma unroll
-                    for (int q = 0; q < 2; ++q)
-#pragma unroll
-                        for (int k = 0; k < 2; ++k) hq[q][k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[cb][k], B1[q], hq[q][k], 0, 0, 0);
+                    // The wave issues in order, and only the first two vector instructions behind an MFMA run under it.  Order of a pair
+                    // of hidden blocks: fc1 of group 0 | fc1 of group 1, two instructions of GELU 0 behind each MFMA, then the rest of
+                    // GELU 0 | fc2 of group 0 with GELU 1 likewise | fc2 of group 1.  Every accumulator takes its MFMAs in the order it
+                    // did, every value the same instructions: same bits as the phased kernel.
+                    auto fc1_mfma = [&](int q, int i) {        // i-th of ten: term i >> 1 into hidden block i & 1
+                        const int k = i & 1, t = i >> 1;
+                        const h8v A = (t == 0 || t == 4) ? fa[cb][k] : t == 1 ? fb[cb][k] : fc[cb][k];
+                        const h8v Bv = t == 0 ? B2[q] : (t == 1 || t == 4) ? B1[q] : t == 2 ? B4[q] : B3[q];
+                        hq[q][k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A, Bv, hq[q][k], 0, 0, 0);
+                    };
                     h8v Bhh[2], Bhl[2];
+                    auto fc2_mfma = [&](int q, int i) {        // i-th of nine: term i / 3 into output block i % 3
+                        const int mo = i % 3, t = i / 3;
+                        a2[q][mo] = __builtin_amdgcn_mfma_f32_16x16x32_f16(t == 1 ? gl[mo] : gh[mo], t == 0 ? Bhl[q] : Bhh[q], a2[q][mo], 0, 0, 0);
+                    };
 #pragma unroll
-                    for (int q = 0; q < 2; ++q) {
-                        u32x2v hh[2], hl[2];
+                    for (int i = 0; i < 10; ++i) fc1_mfma(0, i);
+                    __builtin_amdgcn_sched_barrier(0);
+                    GeluStages gs[2];
+                    u32x2v hh[2], hl[2];
+#define GS_(q, k, S) gelu_stage<S>(gs[k], hq[q][k], wt.gelu_c, hh[k], hl[k])
+#define GELU_ALL_(q) GS_(q, 0, 0); GS_(q, 1, 0); GS_(q, 0, 1); GS_(q, 1, 1); GS_(q, 0, 2); GS_(q, 1, 2); GS_(q, 0, 3); GS_(q, 1, 3); \
+                     GS_(q, 0, 4); GS_(q, 1, 4); GS_(q, 0, 5); GS_(q, 1, 5)
+                    // two vector instructions behind an MFMA run under it (tools/f16_mfma_bench.hip: 20.0 cycles per slot against 19.5;
+                    // four cost 38.8): the first 2 N of a GELU go behind the N MFMAs of the other group, the rest follows in a run
 #pragma unroll
-                        for (int k = 0; k < 2; ++k) split4h(gelu_phi4_scaled(hq[q][k], wt.gelu_c), hh[k], hl[k]);
-                        Bhh[q] = cat8(hh[0], hh[1]);
-                        Bhl[q] = cat8(hl[0], hl[1]);
+                    for (int i = 0; i < 10; ++i) fc1_mfma(1, i);
+                    GELU_ALL_(0);
+#pragma unroll
+                    for (int i = 0; i < 10; ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
                     }
+                    __builtin_amdgcn_sched_group_barrier(0x402, 64, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    Bhh[0] = cat8(hh[0], hh[1]);
+                    Bhl[0] = cat8(hl[0], hl[1]);
 #pragma unroll
-                    for (int q = 0; q < 2; ++q)
+                    for (int i = 0; i < 9; ++i) fc2_mfma(0, i);
+                    GELU_ALL_(1);
 #pragma unroll
-                        for (int mo = 0; mo < 3; ++mo) a2[q][mo] = __builtin_amdgcn_mfma_f32_16x16x32_f16(gh[mo], Bhl[q], a2[q][mo], 0, 0, 0);
+                    for (int i = 0; i < 9; ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
+                        __builtin_amdgcn_sched_group_barrier(0x002, 2, 1);
+                    }
+                    __builtin_amdgcn_sched_group_barrier(0x402, 64, 1);
+                    __builtin_amdgcn_sched_barrier(0);
+#undef GELU_ALL_
+#undef GS_
+                    Bhh[1] = cat8(hh[0], hh[1]);
+                    Bhl[1] = cat8(hl[0], hl[1]);
 #pragma unroll
-                    for (int q = 0; q < 2; ++q)
-#pragma unroll
-                        for (int mo = 0; mo < 3; ++mo) a2[q][mo] = __builtin_amdgcn_mfma_f32_16x16x32_f16(gl[mo], Bhh[q], a2[q][mo], 0, 0, 0);
-#pragma unroll
-                    for (int q = 0; q < 2; ++q)
-#pragma unroll
-                        for (int mo = 0; mo < 3; ++mo) a2[q][mo] = __builtin_amdgcn_mfma_f32_16x16x32_f16(gh[mo], Bhh[q], a2[q][mo], 0, 0, 0);
+                    for (int i = 0; i < 9; ++i) fc2_mfma(1, i);
                 }
 #pragma unroll
                 for (int mo = 0; mo < 3; ++mo) lv[mo] = bvp[60 + 4 * mo];
