@@ -1448,6 +1448,7 @@ __global__ __launch_bounds__(512, 2) void convblock_pipe_kernel(const float* __r
                         fc[buf][k] = FA(2 * p + k, 2);
                     }
                 };
+                PSTAMP(3);      // (diagnostic: 3 = set-up of a row pair, 4 = its six pairs of hidden blocks, 5 = its epilogue)
                 load_fc1(0, 0);
 #pragma unroll
                 for (int p = 0; p < 6; ++p) {
@@ -1529,6 +1530,7 @@ __global__ __launch_bounds__(512, 2) void convblock_pipe_kernel(const float* __r
 #pragma unroll
                     for (int i = 0; i < 9; ++i) fc2_mfma(1, i);
                 }
+                PSTAMP(4);
 #pragma unroll
                 for (int mo = 0; mo < 3; ++mo) lv[mo] = bvp[60 + 4 * mo];
                 // ---- out = x + layerscale * r
@@ -1651,6 +1653,7 @@ __global__ __launch_bounds__(512, 2) void convblock_pipe_kernel(const float* __r
                         }
                     }
                 }
+                PSTAMP(5);
             }
             PSTAMP(3);
 #ifdef RVDD_STAMPS

@@ -22,7 +22,8 @@ if os.environ.get("RVDD_NEXT_PIPE") == "1":
     a = feat[0, :16, 0, 0].cpu().tolist()
     f, b = a[:8], a[8:]
     print("front (wave 0), cycles per tile: loop top %.0f, waiting for halo chunks %.0f, taps %.0f, LayerNorm + exchange %.0f, barriers A + B %.0f" % tuple(x / f[0] for x in f[1:6]))
-    print("back  (wave 4), cycles per tile: loop top %.0f, barrier A %.0f, exchange read + barrier B %.0f, MLP of four rows %.0f" % tuple(x / b[0] for x in b[1:5]))
+    print("back  (wave 4), cycles per tile: loop top %.0f, barrier A %.0f, exchange read + barrier B %.0f, MLP of four rows %.0f" % tuple(x / b[0] for x in b[1:4] + [b[4] + b[5] + b[6]]))
+    print("      of which: set-up of the two row pairs %.0f, their 12 pairs of hidden blocks %.0f, epilogues %.0f" % tuple(x / b[0] for x in b[4:7]))
     sys.exit(0)
 v = feat[0, :5, 0, 0].cpu().tolist()
 n = v[0]
