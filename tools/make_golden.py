@@ -101,12 +101,44 @@ def build_reference_model(name, tmp):
     return model, opt
 
 
-def main():
+def load_synth():
+    """The input generator of this repo, loaded BY FILE: its package mirrors the reference's module names
+    (util/, models/, networks/, options/, data/), so the package directory must never be on sys.path here."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("rvdd_synth", os.path.join(REPO, "rvdd-release_amd", "synth.py"))
+    synth = importlib.util.module_from_spec(spec)
+    sys.modules["rvdd_synth"] = synth
+    spec.loader.exec_module(synth)
+    return synth
+
+
+def assert_reference_modules(*mods):
+    """Every module the fixtures are computed with must come from the reference tree, not from this repo's
+    name-for-name plugin surface (a shadowed import would write 'golden' vectors from the build's own kernels)."""
+    for m in mods:
+        f = os.path.realpath(getattr(m, "__file__", "") or "")
+        if not f.startswith(os.path.realpath(REF) + os.sep):
+            raise RuntimeError(f"{m.__name__} was imported from {f!r}, not from {REF}: refusing to write fixtures")
+
+
+def parse_args(argv=None):
+    import argparse
+    ap = argparse.ArgumentParser(description=__doc__.split("\n\n")[0])
+    ap.add_argument("--out", default=None, help="write fixtures here instead of tests/golden (weights go to <out>/weights)")
+    ap.add_argument("--only", default=None, help="comma-separated subset of fixture names (ops, or variant / long names)")
+    return ap.parse_args(argv)
+
+
+def main(argv=None):
+    global GOLD, WDIR
+    args = parse_args(argv)
+    if args.out:
+        GOLD, WDIR = os.path.abspath(args.out), os.path.join(os.path.abspath(args.out), "weights")
+    only = set(args.only.split(",")) if args.only else None
     os.environ["PYTHONDONTWRITEBYTECODE"] = "1"
     sys.dont_write_bytecode = True
     _install_standins()
     sys.path.insert(0, REF)
-    sys.path.insert(0, os.path.join(REPO, "rvdd-release_amd"))
     os.makedirs(GOLD, exist_ok=True)
     os.makedirs(WDIR, exist_ok=True)
     tmp = tempfile.mkdtemp(prefix="rvdd_golden_")
@@ -115,9 +147,11 @@ def main():
     torch.set_num_threads(8)
 
     from safetensors.torch import save_file
+    import util.Hamilton_Adam_demo, util.flow_utils, models, networks, options.train_options
+    assert_reference_modules(util.Hamilton_Adam_demo, util.flow_utils, models, networks, options.train_options)
     from util.Hamilton_Adam_demo import HamiltonAdam
     from util.flow_utils import warp, upsample_factor_2
-    import synth
+    synth = load_synth()
 
     # ---- per-op fixtures ------------------------------------------------
     ha = HamiltonAdam("gbrg")

@@ -42,22 +42,25 @@ def keep_frames(n_out):
     return sorted(set([0, 1, n_out - 2, n_out - 1] + list(range(9, n_out, 10))))
 
 
-def main():
+def main(argv=None):
+    args = MG.parse_args(argv)
+    gold = os.path.abspath(args.out) if args.out else MG.GOLD
+    only = set(args.only.split(",")) if args.only else None
     os.environ["PYTHONDONTWRITEBYTECODE"] = "1"
     sys.dont_write_bytecode = True
     MG._install_standins()
     sys.path.insert(0, MG.REF)
+    os.makedirs(gold, exist_ok=True)
     tmp = tempfile.mkdtemp(prefix="rvdd_golden_long_")
     os.chdir(tmp)
     torch.set_num_threads(8)
-    # the input generator of this repo, loaded by file (its package mirrors the reference's module names)
-    import importlib.util
-    spec = importlib.util.spec_from_file_location("rvdd_synth", os.path.join(MG.REPO, "rvdd-release_amd", "synth.py"))
-    synth = importlib.util.module_from_spec(spec)
-    sys.modules["rvdd_synth"] = synth
-    spec.loader.exec_module(synth)
+    import models, networks, options.train_options, util.flow_utils
+    MG.assert_reference_modules(models, networks, options.train_options, util.flow_utils)
+    synth = MG.load_synth()
 
     for name, (variant, cfg, T, H, W, seed) in LONG.items():
+        if only and name not in only:
+            continue
         _, feat, fut, _ = MG.VARIANTS[variant]
         iso = 12800 if "12800" in variant else 3200
         model, _ = MG.build_reference_model(variant, tmp)
@@ -86,7 +89,7 @@ def main():
                  flow_next_check=seq.flow_next[::CHECK_EVERY].numpy(), gt_check=seq.gt[::CHECK_EVERY].numpy())
         if feat:
             d["feat_last"] = model._netDenoise.get_current_features()[0][0].numpy()
-        np.savez_compressed(os.path.join(MG.GOLD, f"seq_{name}.npz"), **d)
+        np.savez_compressed(os.path.join(gold, f"seq_{name}.npz"), **d)
         print(f"[golden-long] {name} ({cfg}): {n_out} frames, kept {keep}, PSNR first/last {psnrs[0]:.3f}/{psnrs[-1]:.3f}")
 
 

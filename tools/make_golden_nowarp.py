@@ -26,21 +26,24 @@ CASES = {"nowarp-iso3200": ("convunet-mode=fixedfeatures", 0, "non_recurrent-con
          "prevnoisy-feat-iso3200": ("convunet-mode=fixedfeatures+feat", 0, "recurrent-convunet+feat-iso3200", ["--prev_noisy_frame", "--feature_rec"], True)}
 
 
-def main():
+def main(argv=None):
+    args = MG.parse_args(argv)
+    gold = os.path.abspath(args.out) if args.out else MG.GOLD
+    wdir = os.path.join(gold, "weights") if args.out else MG.WDIR
     os.environ["PYTHONDONTWRITEBYTECODE"] = "1"
     sys.dont_write_bytecode = True
     MG._install_standins()
     sys.path.insert(0, MG.REF)
+    os.makedirs(gold, exist_ok=True)
+    os.makedirs(wdir, exist_ok=True)
     tmp = tempfile.mkdtemp(prefix="rvdd_golden_")
     os.chdir(tmp)
     torch.manual_seed(4321)
     torch.set_num_threads(8)
     from safetensors.torch import save_file
-    import importlib.util
-    spec = importlib.util.spec_from_file_location("rvdd_synth", os.path.join(REPO, "rvdd-release_amd", "synth.py"))
-    synth = importlib.util.module_from_spec(spec)
-    sys.modules["rvdd_synth"] = synth        # dataclasses look the module up by name
-    spec.loader.exec_module(synth)
+    synth = MG.load_synth()
+    import models, networks, options.train_options, util.flow_utils
+    MG.assert_reference_modules(models, networks, options.train_options, util.flow_utils)
     from options.train_options import TrainOptions
     from models import create_model
     for name, (netstr, fut, stem, extra, feat) in CASES.items():
@@ -53,7 +56,7 @@ def main():
         model.eval()
         sd = {k: v.detach().clone().contiguous() for k, v in model._netDenoise.state_dict().items()}
         if "--no_warp" in extra:
-            save_file(sd, os.path.join(MG.WDIR, stem + ".safetensors"),
+            save_file(sd, os.path.join(wdir, stem + ".safetensors"),
                       metadata={"netDenoiser": netstr, "feature_rec": "0", "future_patch_depth": str(fut), "no_warp": "1",
                                 "source": stem + "_net_Denoise.pth"})
         no_warp = "--no_warp" in extra
@@ -73,7 +76,7 @@ def main():
             outs.append(model.denoised[0].numpy().copy())
             l1s.append(losses["L1"])
             psnrs.append(losses["PSNR"])
-        np.savez(os.path.join(MG.GOLD, f"seq_{name}.npz"), raw=seq.raw.numpy(), gt=seq.gt.numpy(), denoised=np.stack(outs, 0),
+        np.savez(os.path.join(gold, f"seq_{name}.npz"), raw=seq.raw.numpy(), gt=seq.gt.numpy(), denoised=np.stack(outs, 0),
                  flow_prev=seq.flow_prev.numpy(), flow_next=seq.flow_next.numpy(),
                  L1=np.array(l1s, np.float64), PSNR=np.array(psnrs, np.float64))
         print(f"[golden] {name}: {len(outs)} frames, PSNR {psnrs}")

@@ -37,6 +37,8 @@ import fwd_ppipe as R  # noqa: E402
 from util.util import tensor2im  # noqa: E402
 
 GOLD = os.path.join(REPO, "tests", "golden")
+OUT = os.environ.get("RVDD_GOLDEN_OUT", GOLD)      # where the vectors are written (a test regenerates into a temp dir)
+os.makedirs(OUT, exist_ok=True)
 
 
 def run(x, seq, iso, bit_depth=8):
@@ -73,7 +75,7 @@ for name, (x, gt, seq, iso) in cases.items():
     img, srgb, u8 = run(x.astype(np.float32), seq, iso)
     _, _, gt_u8 = run(gt.astype(np.float32), seq, iso)
     p = float(R.psnr(u8, gt_u8))
-    np.savez_compressed(os.path.join(GOLD, f"ppipe_{name}.npz"), x=x.astype(np.float32), gt=gt.astype(np.float32),
+    np.savez_compressed(os.path.join(OUT, f"ppipe_{name}.npz"), x=x.astype(np.float32), gt=gt.astype(np.float32),
                         seq=seq, iso=iso, tif=img, srgb=srgb.astype(np.float32), u8=u8, gt_u8=gt_u8, psnr=p)
     print(name, "srgb range", float(srgb.min()), float(srgb.max()), "psnr", p)
 
@@ -84,7 +86,7 @@ for bd, scale in ((0, 1.0 / 255.0), (10, 1024.0 / 255.0), (12, 4095.0 / 255.0)):
     n, red_gain, blue_gain = R.find_gains(3, 3200)
     im = img * 4095 if bd == 0 else (img / 1024 * 4095 if bd == 10 else img)
     srgb = R.ppipe(im, 1 / n, red_gain, blue_gain, 3200)
-    np.savez_compressed(os.path.join(GOLD, f"ppipe_bitdepth{bd}.npz"), img=img.astype(np.float32), seq=3, iso=3200,
+    np.savez_compressed(os.path.join(OUT, f"ppipe_bitdepth{bd}.npz"), img=img.astype(np.float32), seq=3, iso=3200,
                         bit_depth=bd, srgb=srgb.astype(np.float32), u8=srgb.round().clip(0, 255).astype(np.uint8))
 
 with open(os.path.join(REPO, "rvdd-release_amd", "white_balance.json"), "w") as f:
