@@ -58,6 +58,11 @@ DESCR = {
 }
 FP32_PEAK_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md, chip table (vector = matrix f32)
 F16_PEAK_TFLOPS = 2500.0          # same table: dense F16 / BF16 MFMA (~2.5 PF; the 5 PF figure is 2:1 sparsity)
+# what the F16 matrix pipe SUSTAINS on this part under its package power limit: nothing but independent dense
+# v_mfma_f32_16x16x32_f16 on every SIMD for 3 s (tools/mfma_f16_shapes_power.hip, profiles/r04_mfma_f16_shapes_power.txt:
+# 1 926 TFLOP/s at ~1.85 GHz; the nominal 2.5 PFLOP/s needs 2.4 GHz, which the package does not hold with the pipe full)
+F16_SUSTAINED_TFLOPS = 1926.0
+F16_SUSTAINED_SOURCE = "profiles/r04_mfma_f16_shapes_power.txt (tools/mfma_f16_shapes_power.hip: dense 16x16x32 f16 MFMAs only, 3 s, package power limit)"
 # the convunet's plain 48 -> 48 3x3 conv: the split-f16 kernel (default), or the f32-MFMA kernels (RVDD_CONV=f32 | winograd | direct)
 _CONV = {"direct": "conv3x3_kernel<48, 1, false>", "winograd": "wino3x3_kernel<1, false>",
          "f32": "wino3x3_kernel<1, false>"}.get(os.environ.get("RVDD_CONV", ""), "conv3x3h_kernel<48, 1, false, false>")
@@ -109,7 +114,9 @@ def parse_args(argv=None):
                     help="skip the second, untimed-region-external run on the exact-f32-product kernels (one GPU only)")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the short runs of the other configurations after the timed region (one GPU, default config only)")
-    ap.add_argument("--other-steps", type=int, default=2, help="timed steps of each of those short runs")
+    ap.add_argument("--other-steps", type=int, default=6,
+                    help="timed steps of each of those short runs (six: 2-6 s each, enough to resolve 1 %%; round 5 ran two)")
+    ap.add_argument("--no-gpu-sampler", action="store_true", help="do not sample shader clock / package power (rocm-smi) during the timed regions")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--all-kernel-events", action="store_true",
                     help="diagnostic: bracket EVERY launch of every kernel (costs ~6 %% of the frame rate); "
@@ -206,6 +213,55 @@ def host_cpu_share():
     return info
 
 
+class GpuSampler:
+    """Shader clock and package power of one GPU, sampled by a thread of this process while a timed region runs, so that the
+    driver's record can tell a slow box from a regression (the boxes of this pool hold 1.86-1.98 GHz under the same load).
+    Source: `rocm-smi -d <dev> --showpower --showclocks` every `period` s (the tool tools/power_probe.sh has used since round 2;
+    a child process that reads sysfs -- it launches nothing on the GPU).  Never raises: no tool, no numbers."""
+
+    def __init__(self, dev_index=0, period=0.4):
+        import threading
+        self.dev, self.period = dev_index, period
+        self.samples = []                       # (perf_counter, sclk MHz or None, W or None)
+        self._stop = threading.Event()
+        self._thread = threading.Thread(target=self._run, daemon=True)
+        self.error = None
+        self._thread.start()
+
+    def _run(self):
+        import re
+        while not self._stop.is_set():
+            t = time.perf_counter()
+            try:
+                txt = subprocess.run(["rocm-smi", "-d", str(self.dev), "--showpower", "--showclocks"], capture_output=True,
+                                     text=True, timeout=10).stdout
+                mc = re.search(r"sclk[^\n]*?\((\d+)Mhz\)", txt)
+                mp = re.search(r"Power \(W\):\s*([\d.]+)", txt)
+                self.samples.append((0.5 * (t + time.perf_counter()), int(mc.group(1)) if mc else None, float(mp.group(1)) if mp else None))
+            except Exception as e:             # rocm-smi absent or hung: record why, stop sampling
+                self.error = f"{type(e).__name__}: {e}"
+                return
+            self._stop.wait(max(0.0, self.period - (time.perf_counter() - t)))
+
+    def window(self, t0, t1):
+        """Summary of the samples taken inside [t0, t1] (perf_counter times)."""
+        rows = [r for r in self.samples if t0 <= r[0] <= t1]
+        clk = [r[1] for r in rows if r[1] is not None]
+        pw = [r[2] for r in rows if r[2] is not None]
+        out = {"samples": len(rows), "source": "rocm-smi --showpower --showclocks, a thread of this process, inside the timed region only"}
+        if clk:
+            out.update(sclk_mhz_mean=round(sum(clk) / len(clk), 1), sclk_mhz_min=min(clk), sclk_mhz_max=max(clk))
+        if pw:
+            out.update(package_w_mean=round(sum(pw) / len(pw), 1), package_w_max=max(pw))
+        if self.error:
+            out["error"] = self.error
+        return out
+
+    def close(self):
+        self._stop.set()
+        self._thread.join(timeout=15)
+
+
 def flow_from_denoised(rt, den, raw_cur):
     """validate.py:16-38 for B sequences: moving = channel mean of remosaick(previous output), target = channel mean of
     the current packed raw frame, both mapped to [0,1] (library.py:67-68, :165-167) -> TV-L1 on the device."""
@@ -251,6 +307,10 @@ def roofline_of(dom, k, config, arch, events_note):
             "unit": "TFLOP/s", "frac": round(k["tflops"] / peak, 4),
             "frac_algorithmic": round(k["tflops"] / peak, 4),
             "executed_mfma_tflops": round(executed, 2), "frac_executed_mfma": round(executed / peak, 4),
+            # the same against what the matrix pipe sustains under the package power limit (F16 forms only)
+            "peak_sustained": F16_SUSTAINED_TFLOPS if split else None,
+            "peak_sustained_source": F16_SUSTAINED_SOURCE if split else None,
+            "frac_executed_sustained": round(executed / F16_SUSTAINED_TFLOPS, 4) if split else None,
             "frac_hbm": round(k["gbps"] / 8000.0, 4), "hbm_peak_gbps": 8000.0,
             "traffic": traffic, "traffic_source": traffic_src,
             "algorithmic_bytes_per_launch": round(k["bytes_per_launch"]),
@@ -279,7 +339,7 @@ def kernel_table(prof):
     return kernels
 
 
-def quick_config(name, steps, dev_index, online_flow=False, batch=None):
+def quick_config(name, steps, dev_index, online_flow=False, batch=None, sampler=None):
     """A short run of another configuration (default: at its default batch): 1 warm-up step, `steps` timed steps (wall clock
     between device synchronisations) of the SAME loop the headline run times (advance), HIP events around every 3rd launch of
     its dominant kernel and that kernel's `roofline`.  Inputs synthetic, resident in HBM."""
@@ -311,7 +371,8 @@ def quick_config(name, steps, dev_index, online_flow=False, batch=None):
     for _ in range(steps):
         advance(rt, raw, fprev, fnext, outs, T, fut, online_flow)
     torch.cuda.synchronize()
-    el = time.perf_counter() - t0
+    t1 = time.perf_counter()
+    el = t1 - t0
     kernels = kernel_table(rt.profile_read())
     rt.profile_enable(False)
     psnr_last = rt.psnr_l1(outs[n_out - 1], gt_last)[1]      # (also the call that reads an asynchronous flow batch's control word)
@@ -322,6 +383,8 @@ def quick_config(name, steps, dev_index, online_flow=False, batch=None):
            "value": round(steps * n_out * B / el, 2), "unit": "frames/s",
            "ms_per_step": round(1e3 * el / steps, 3), "steps": steps, "warmup": 1, "sequences_in_lockstep": B,
            "output_frames_per_step": n_out * B, "finite": finite, "task_psnr_db_last_frame": round(psnr_last, 3)}
+    if sampler is not None:
+        res["gpu_clock_power"] = sampler.window(t0, t1)
     dom = DOMINANT[arch]
     if dom in kernels:
         res["dominant_kernel"] = dom
@@ -415,6 +478,8 @@ def main():
 
     for _ in range(args.warmup):
         one_step()
+    # shader clock and package power through every timed region of this process (rank 0 of a single-node run samples its own GPU)
+    sampler = GpuSampler(dev_index) if (rank == 0 and not stub and not args.no_gpu_sampler) else None
     barrier()
     if not args.no_kernel_events:
         if args.all_kernel_events:
@@ -428,7 +493,9 @@ def main():
         one_step()
     ev_ms = rt.timer_stop_ms()
     barrier()
-    wall = time.perf_counter() - t0
+    t1 = time.perf_counter()
+    wall = t1 - t0
+    clock_power = sampler.window(t0, t1) if sampler is not None else None
     prof = rt.profile_read() if not args.no_kernel_events else []
     rt.profile_enable(False)
 
@@ -466,6 +533,9 @@ def main():
         if dist is not None:
             dist.destroy_process_group()
         return
+    if sampler is not None and (world > 1 or args.no_other_configs or args.online_flow or config != "C2" or args.batch or args.frames):
+        sampler.close()          # nothing else is timed in this process
+        sampler = None
 
     # ---- roofline of the dominant kernel (HIP events around a uniform sample of its launches, this rank)
     roofline = None
@@ -505,15 +575,17 @@ def main():
         other = {}
         for name in ("C3", "C4", "C5", "C1"):
             try:
-                other[name] = quick_config(name, args.other_steps, dev_index)
+                other[name] = quick_config(name, args.other_steps, dev_index, sampler=sampler)
             except Exception as e:          # a failure here must not take the headline line with it
                 other[name] = {"error": f"{type(e).__name__}: {e}"}
         # C1 as BASELINE.json states it: ONE sequence of 8 frames (the default batch above runs eight in lockstep)
         for key, kw in (("C1_one_sequence", dict(name="C1", batch=1)), ("C2_online_flow", dict(name="C2", online_flow=True))):
             try:
-                other[key] = quick_config(steps=args.other_steps * (8 if key.startswith("C1") else 1), dev_index=dev_index, **kw)
+                other[key] = quick_config(steps=args.other_steps * (8 if key.startswith("C1") else 1), dev_index=dev_index, sampler=sampler, **kw)
             except Exception as e:
                 other[key] = {"error": f"{type(e).__name__}: {e}"}
+    if sampler is not None:
+        sampler.close()
 
     # ---- CPU baseline: the oracle on this host's cores, bounded sample, sequence 0
     cpu = None
@@ -611,6 +683,7 @@ def main():
         "algorithmic_gflop_per_frame": gflop_frame,
         "whole_path_algorithmic_tflops": round(fps / world * gflop_frame / 1e3, 2),
         "task_psnr_db": round(psnr_mean, 3),
+        "gpu_clock_power": clock_power,
         "roofline": roofline, "cpu_baseline": cpu, "exact_f32_kernels": exact, "other_configs": other, "collate": collate,
         "kernels": kernels,
     }

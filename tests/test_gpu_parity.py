@@ -176,6 +176,10 @@ def test_sequence_golden_model_surface(name, conv_kernel):
     ("convunet+feat", "recurrent-convunet+feat-iso3200", 0, 2, 136, 248),     # shaped like the 1/8 level of 1080p: Winograd
                                                                               # by size, ragged in x at every level
     ("convunet", "recurrent-convunet-future-iso3200", 1, 3, 20, 28),          # smallest golden size, batch 3
+    # one sequence of 80 / 48 tiles at level 0: 3 x tiles <= 256 CUs, so EVERY conv launch of the step takes the output-channel
+    # split (conv3x3h MT = 1, cout_split_applies) and meets the oracle itself, not only its MT = 3 sibling
+    ("convunet+feat", "recurrent-convunet+feat-iso3200", 0, 1, 128, 160),
+    ("convunet", "recurrent-convunet-iso3200", 0, 1, 96, 128),
 ])
 def test_sequence_vs_oracle(arch, stem, fut, B, H, W, conv_kernel):
     from rvdd_release_amd import synth
