@@ -316,8 +316,29 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3h_kernel(ConvArgs a) {
     f32x4 ulo[UNR][4];                 // source pixels (row 0 col 0, row 0 col 1, row 1 col 0, row 1 col 1)
     float u_ly[UNR][2], u_lx[UNR][2];  // weight of the second source row / column per block row / column; < 0: outside the map
     u32x2 ushi[UNR][4], uslo[UNR][4];
+    // INTERIOR tiles (the halo and the source rows / columns it interpolates between all inside the map: 93 % of a 720p level's tiles):
+    // no clamp acts and no weight depends on the tile -- an item's four source pieces sit at a thread constant plus a wave-uniform
+    // offset (scalar operand of the load, the column step in the instruction's immediate), the weights are 1/4 and 3/4.  No address
+    // or weight arithmetic at all on the vector ALU, and no zero select (the general form below spends ~85 vector instructions per
+    // item on them, beside the 64 of interpolation and split; this kernel's vector instructions add to its tile time one for one).
+    // The same expressions on the same values as the general form: the same bits.
+    int u_off00[UNR];
+#pragma unroll
+    for (int r0 = 0; r0 < UNR; ++r0)
+        u_off00[r0] = u_ok[r0] ? ((u_by[r0] * (a.W >> 1) + u_bx[r0]) * (CIN * 4) + u_part[r0] * 16) : (int)0x80000000;
+    auto interior = [&](const Src& q) {
+        return UPS && q.y0 >= 16 && q.y0 + IH <= a.H && q.x0 >= 16 && q.x0 + IW <= a.W;
+    };
     auto fetch_ups = [&](const Src& q, int r0) {
         const int ih = a.H >> 1, iw = a.W >> 1;
+        if (interior(q)) {
+            const int soff0 = (((q.y0 >> 1) - 1) * iw + (q.x0 >> 1) - 1) * (CIN * 4), soff1 = soff0 + iw * (CIN * 4);
+            ulo[r0][0] = bload(q.r, (unsigned)u_off00[r0], soff0);
+            ulo[r0][1] = bload(q.r, (unsigned)u_off00[r0] + (unsigned)(CIN * 4), soff0);
+            ulo[r0][2] = bload(q.r, (unsigned)u_off00[r0], soff1);
+            ulo[r0][3] = bload(q.r, (unsigned)u_off00[r0] + (unsigned)(CIN * 4), soff1);
+            return;
+        }
         const int i = (q.y0 >> 1) - 1 + u_by[r0], jx = (q.x0 >> 1) - 1 + u_bx[r0];
         const int rr0 = min(max(i, 0), ih - 1), cc0 = min(max(jx, 0), iw - 1);
         const int rr1 = rr0 + (rr0 < ih - 1 ? 1 : 0), cc1 = cc0 + (cc0 < iw - 1 ? 1 : 0);
@@ -336,9 +357,22 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3h_kernel(ConvArgs a) {
         ulo[r0][3] = bload(q.r, any ? (unsigned)((rr1 * iw + cc1) * (CIN * 4)) + p16 : 0x80000000u);
     };
     // vertical pass, then horizontal, each "a * wa, then one fused multiply-add": upsample2x_kernel's expressions in its order
-    auto interp_ups = [&](int r0, float sc_st, auto scaled_tag) {
+    auto interp_ups = [&](const Src& q, int r0, float sc_st, auto scaled_tag) {
         constexpr bool SC_ = decltype(scaled_tag)::value;
         auto fma4 = [](f32x4 x, float sc, f32x4 c) { return __builtin_elementwise_fma(x, f32x4{sc, sc, sc, sc}, c); };
+        if (interior(q)) {      // halo rows / columns of an interior tile: odd first (weight 1/4 on the second source), then even (3/4)
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const float ly1 = e ? 0.75f : 0.25f, ly0 = 1.f - ly1;
+                const f32x4 c0 = fma4(ulo[r0][2], ly1, ulo[r0][0] * ly0), c1 = fma4(ulo[r0][3], ly1, ulo[r0][1] * ly0);
+#pragma unroll
+                for (int f = 0; f < 2; ++f) {
+                    const float lx1 = f ? 0.75f : 0.25f, lx0 = 1.f - lx1;
+                    split4<SC_>(fma4(c1, lx1, c0 * lx0), sc_st, ushi[r0][2 * e + f], uslo[r0][2 * e + f]);
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
             const float ly1 = u_ly[r0][e], ly0 = 1.f - ly1;
@@ -467,7 +501,7 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3h_kernel(ConvArgs a) {
 #pragma unroll
             for (int r0 = 0; r0 < UNR; ++r0) fetch_ups(q, r0);
 #pragma unroll
-            for (int r0 = 0; r0 < UNR; ++r0) interp_ups(r0, sc_nxt, scaled_tag);
+            for (int r0 = 0; r0 < UNR; ++r0) interp_ups(q, r0, sc_nxt, scaled_tag);
         } else {
 #pragma unroll
             for (int r0 = 0; r0 < G::NR; ++r0) fetch_round(q, r0);
@@ -561,7 +595,7 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3h_kernel(ConvArgs a) {
                 for (int r0 = 0; r0 < UNR; ++r0) {
                     if (j == SH + US * r0) fetch_ups(qn, r0);
                     if (j == SH + UL + UI * r0) {
-                        interp_ups(r0, sc_nxt, scaled_tag);
+                        interp_ups(qn, r0, sc_nxt, scaled_tag);
 #pragma unroll
                         for (int e = 0; e < 4; ++e) asm volatile("" : "+v"(ushi[r0][e]), "+v"(uslo[r0][e]));      // here, not behind the barrier
                     }

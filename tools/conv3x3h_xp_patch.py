@@ -114,6 +114,47 @@ rep('''                    outv[nt * MT + mt] = x;''', '''#if RVDD_XP & 64
 rep('''        for (int i = wave; i < NP; i += NTHREADS / 64) {
             int k = i + rot;''', '''        for (int i = wave; i < NP && !(RVDD_XP & 256); i += NTHREADS / 64) {
             int k = i + rot;''')
+# 512 / 1024 (round 6, VERDICT r05 item 3b): a PART of the fused feature warp in the halo fetch -- every halo piece gathered from 4 (512) or 8
+# (1024) sixteen-byte loads of a 4-wide footprint (rows y, y + 1) and combined with 4 / 8 packed-f32 FMAs one chunk later (the loads of one
+# round in flight at a time: 16 / 32 registers, what the kernel has free).  The bicubic warp needs 16 loads and 16 FMAs per piece plus its
+# taps' table; timing only (wrong results), no table: what a quarter / a half of the gather costs the L0 second pass.
+rep('''    auto fetch_round = [&](const Src& q, int r0) { pre[r0] = bload(q.r, q.base + (unsigned)(r0 * G::RPR * a.W * (CIN * 4))); };''',
+    '''#if RVDD_XP & (512 | 1024)
+    constexpr int NGTH = (RVDD_XP & 1024) ? 8 : 4;
+    f32x4 gth[NGTH];
+    auto fetch_round = [&](const Src& q, int r0) {
+#pragma unroll
+        for (int k = 0; k < NGTH; ++k) gth[k] = bload(q.r, q.base + (unsigned)((r0 * G::RPR + (k >> 2)) * a.W * (CIN * 4) + (k & 3) * (CIN * 4)));
+    };
+    auto combine_round = [&](int r0) {
+        f32x4 s_ = gth[0] * 0.53125f;
+#pragma unroll
+        for (int k = 1; k < NGTH; ++k) s_ = __builtin_elementwise_fma(gth[k], f32x4{0.0625f * k, 0.0625f * k, 0.0625f * k, 0.0625f * k}, s_);
+        pre[r0] = s_;
+    };
+#else
+    auto fetch_round = [&](const Src& q, int r0) { pre[r0] = bload(q.r, q.base + (unsigned)(r0 * G::RPR * a.W * (CIN * 4))); };
+#endif''')
+rep('''#if !(RVDD_XP & 2)
+                if (j >= SH && j - SH < G::NR) fetch_round(qn, j - SH);
+#endif''',
+    '''#if RVDD_XP & (512 | 1024)
+                if (j >= SH + 1 && j - SH - 1 < G::NR) combine_round(j - SH - 1);
+                if (j >= SH && j - SH < G::NR) fetch_round(qn, j - SH);
+#elif !(RVDD_XP & 2)
+                if (j >= SH && j - SH < G::NR) fetch_round(qn, j - SH);
+#endif''')
+rep('''            for (int r0 = 0; r0 < G::NR; ++r0) fetch_round(q, r0);
+#pragma unroll
+            for (int r0 = 0; r0 < G::NR; ++r0) split4<SC>(pre[r0], sc_nxt, shi[r0], slo[r0]);''',
+    '''            for (int r0 = 0; r0 < G::NR; ++r0) {
+                fetch_round(q, r0);
+#if RVDD_XP & (512 | 1024)
+                combine_round(r0);
+#endif
+            }
+#pragma unroll
+            for (int r0 = 0; r0 < G::NR; ++r0) split4<SC>(pre[r0], sc_nxt, shi[r0], slo[r0]);''')
 s = s.replace('#include "rvdd_internal.h"', '#ifndef RVDD_XP\n#define RVDD_XP 0\n#endif\n#include "rvdd_internal.h"', 1)
 out = sys.argv[1]
 os.makedirs(os.path.dirname(out) or ".", exist_ok=True)
