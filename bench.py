@@ -104,6 +104,8 @@ def parse_args(argv=None):
                          "previous frame of every step after the first is TV-L1 (rvdd_tvl1flow_batch) from the current noisy "
                          "frame to the re-mosaicked previous OUTPUT, inside the timed region; a mode of its own, labelled in "
                          "the JSON line, never the headline metric")
+    ap.add_argument("--online-groups", type=int, default=ONLINE_GROUPS,
+                    help="--online-flow: the sequences of a GPU as this many independent groups on as many HIP streams (1 = round 5's single stream)")
     ap.add_argument("--collate-outputs", action="store_true",
                     help="after the timed region, all-gather the output frames of the last group (timed separately)")
     ap.add_argument("--cpu-frames", type=int, default=10, help="timed frames of the CPU-oracle sample (0 = skip)")
@@ -281,6 +283,50 @@ def advance(rt, raw, fprev, fnext, outs, T, fut, online_flow):
         rt.step(raw[t - 1] if t == 1 else None, raw[t], raw[t + 1] if fut else None, fp, fnext[t] if fut else None, out=outs[t - 1])
 
 
+ONLINE_GROUPS = 2      # the online-flow mode's default: the B sequences as two groups of B / 2 on two HIP streams (see OnlineGroups)
+
+
+class OnlineGroups:
+    """The online-flow loop with the B sequences as G independent groups of B / G, each with its own runtime handle and HIP
+    stream.  A group's chain is serial (output t-1 -> TV-L1 -> step t) but the groups share nothing, so one group's
+    latency-bound coarse TV-L1 scales run beside another group's convolutions.  Bit-identical outputs to G = 1 (a sequence's
+    arithmetic does not depend on its batch: tools/online_overlap_probe.py, profiles/r05ad_online_flow_two_streams.txt:
+    G = 2 +4.6 %, G = 4 -13 %).  Every group's work of a frame is enqueued before the next frame's, the host never waits."""
+
+    def __init__(self, make_rt, B, G, dev):
+        import torch
+        if B % G:
+            raise SystemExit(f"--online-groups {G} does not divide the batch {B}")
+        self.G, self.per, self.dev = G, B // G, dev
+        self.rts = [make_rt(self.per) for _ in range(G)]
+        for rt in self.rts:
+            rt.set_option("tvl1_async", 1)       # the flow batch stays on the stream: no host round trip per frame
+        self.streams = [torch.cuda.Stream(device=dev) for _ in range(G)]
+
+    def advance(self, raw, fprev, outs, T):
+        """raw [T,B,4,h,w], fprev [T,B,2,h,w], outs [T-1,B,3,H,W]: one pass over all frames (advance()'s loop, per group)."""
+        import torch
+        cur = torch.cuda.current_stream(self.dev)
+        for st in self.streams:
+            st.wait_stream(cur)
+        for rt in self.rts:
+            rt.reset()
+        for t in range(1, T):
+            for g, (rt, st) in enumerate(zip(self.rts, self.streams)):
+                sl = slice(g * self.per, (g + 1) * self.per)
+                with torch.cuda.stream(st):
+                    fp = fprev[t, sl] if t == 1 else flow_from_denoised(rt, outs[t - 2, sl], raw[t, sl])
+                    rt.step(raw[t - 1, sl] if t == 1 else None, raw[t, sl], None, fp, None, out=outs[t - 1, sl])
+        for st in self.streams:
+            cur.wait_stream(st)
+
+    def close(self):
+        import torch
+        for rt in self.rts:
+            rt.psnr_l1(torch.zeros(1, 3, 2, 2, device=self.dev), torch.zeros(1, 3, 2, 2, device=self.dev))   # reads the asynchronous batches' control word
+            rt.close()
+
+
 def roofline_of(dom, k, config, arch, events_note):
     """The `roofline` object of a kernel class from its event-timed launches (k: launches, avg_us, tflops, gbps, bytes_per_launch)."""
     # HBM bytes per launch from the PMC passes of the same command (tools/gpu_profile.sh + tools/pmc_summary.py:
@@ -339,7 +385,7 @@ def kernel_table(prof):
     return kernels
 
 
-def quick_config(name, steps, dev_index, online_flow=False, batch=None, sampler=None):
+def quick_config(name, steps, dev_index, online_flow=False, batch=None, sampler=None, online_groups=ONLINE_GROUPS):
     """A short run of another configuration (default: at its default batch): 1 warm-up step, `steps` timed steps (wall clock
     between device synchronisations) of the SAME loop the headline run times (advance), HIP events around every 3rd launch of
     its dominant kernel and that kernel's `roofline`.  Inputs synthetic, resident in HBM."""
@@ -350,10 +396,20 @@ def quick_config(name, steps, dev_index, online_flow=False, batch=None, sampler=
     arch, stem, fut, iso, H, W, T, B, gflop = CONFIGS[name]
     B = batch or B
     dev = torch.device("cuda", dev_index)
-    rt = RvddRuntime(arch, fut, B, H, W, dev_index)
-    rt.load_state_dict(load_file(os.path.join(REPO, "weights", stem + ".safetensors")))
-    if online_flow:
-        rt.set_option("tvl1_async", 1)       # the flow batch stays on the stream: no host round trip per frame
+    sd = load_file(os.path.join(REPO, "weights", stem + ".safetensors"))
+
+    def make_rt(b):
+        r = RvddRuntime(arch, fut, b, H, W, dev_index)
+        r.load_state_dict(sd)
+        return r
+    og = None
+    if online_flow and online_groups > 1 and not fut and B % online_groups == 0:
+        og = OnlineGroups(make_rt, B, online_groups, dev)
+        rt = og.rts[0]           # (metrics, and the event sample: group 0's launches, B / G sequences each)
+    else:
+        rt = make_rt(B)
+        if online_flow:
+            rt.set_option("tvl1_async", 1)       # the flow batch stays on the stream: no host round trip per frame
     seqs = [synth.make_sequence(T, H, W, iso=iso, seed=1000 * int(name[1]) + b, device=str(dev)) for b in range(B)]
     raw = torch.stack([s.raw for s in seqs], 1).contiguous()
     fprev = torch.stack([s.flow_prev for s in seqs], 1).contiguous()
@@ -363,13 +419,18 @@ def quick_config(name, steps, dev_index, online_flow=False, batch=None, sampler=
     n_out = T - 1 - fut
     outs = torch.empty(n_out, B, 3, H, W, dtype=torch.float32, device=dev)
 
-    advance(rt, raw, fprev, fnext, outs, T, fut, online_flow)
+    def one_pass():
+        if og is not None:
+            og.advance(raw, fprev, outs, T)
+        else:
+            advance(rt, raw, fprev, fnext, outs, T, fut, online_flow)
+    one_pass()
     torch.cuda.synchronize()
     rt.profile_select(DOMINANT[arch], EVENT_STRIDE)
     rt.profile_enable(True)
     t0 = time.perf_counter()
     for _ in range(steps):
-        advance(rt, raw, fprev, fnext, outs, T, fut, online_flow)
+        one_pass()
     torch.cuda.synchronize()
     t1 = time.perf_counter()
     el = t1 - t0
@@ -377,12 +438,19 @@ def quick_config(name, steps, dev_index, online_flow=False, batch=None, sampler=
     rt.profile_enable(False)
     psnr_last = rt.psnr_l1(outs[n_out - 1], gt_last)[1]      # (also the call that reads an asynchronous flow batch's control word)
     finite = bool(torch.isfinite(outs).all())
-    rt.close()
+    if og is not None:
+        og.close()
+    else:
+        rt.close()
     res = {"workload": f"{name}: {DESCR[name]}" + (" -- with the flow towards the previous frame recomputed by TV-L1 from every previous "
                                                   "output inside the timed loop (validate.py --val_flow_from_denoised)" if online_flow else ""),
            "value": round(steps * n_out * B / el, 2), "unit": "frames/s",
            "ms_per_step": round(1e3 * el / steps, 3), "steps": steps, "warmup": 1, "sequences_in_lockstep": B,
            "output_frames_per_step": n_out * B, "finite": finite, "task_psnr_db_last_frame": round(psnr_last, 3)}
+    if og is not None:
+        res["online_groups"] = {"groups": og.G, "sequences_per_group": og.per,
+                                "what": "independent groups of sequences on their own HIP streams; outputs bit-identical to one group; "
+                                        "the dominant kernel's events are group 0's launches (B / G sequences each)"}
     if sampler is not None:
         res["gpu_clock_power"] = sampler.window(t0, t1)
     dom = DOMINANT[arch]
@@ -466,12 +534,23 @@ def main():
         del seqs
     outs = torch.empty(n_out, B, 3, H, W, dtype=torch.float32, device=dev)   # outputs of the group being advanced
 
+    og = None
     if args.online_flow and not stub:
         rt.set_option("tvl1_async", 1)       # the flow batch stays on the stream: no host round trip per frame
+        if args.online_groups > 1 and not fut and B % args.online_groups == 0:
+            def make_rt(b):
+                r = RvddRuntime(arch, fut, b, H, W, dev_index)
+                r.load_state_dict(sd)
+                return r
+            og = OnlineGroups(make_rt, B, args.online_groups, dev)
 
     def one_step(rt=rt, outs=outs):
         for raw, fprev, fnext in inputs:
-            advance(rt, raw, fprev, fnext, outs, T, fut, args.online_flow)
+            if og is not None and rt is og_main:
+                og.advance(raw, fprev, outs, T)
+            else:
+                advance(rt, raw, fprev, fnext, outs, T, fut, args.online_flow)
+    og_main = rt
 
     def barrier():
         shard.barrier(dist, None if on_host else dev)
@@ -498,6 +577,8 @@ def main():
     clock_power = sampler.window(t0, t1) if sampler is not None else None
     prof = rt.profile_read() if not args.no_kernel_events else []
     rt.profile_enable(False)
+    if og is not None:
+        prof = []                # the launches ran on the groups' handles, not on `rt`
 
     elapsed = shard.max_over_ranks(wall, dist, coll_dev)
     n_ranks_seen = shard.count_ranks(dist, coll_dev)             # from the collective itself, not from the environment
@@ -652,7 +733,8 @@ def main():
            if args.scaling == "strong" else f"sequences sharded over {world} GPU(s), {B} per GPU in lockstep")
     data = "synthetic"
     if args.online_flow:
-        data += " (ONLINE FLOW: TV-L1 from the previous output inside the timed region, validate.py --val_flow_from_denoised; not the headline metric)"
+        data += " (ONLINE FLOW: TV-L1 from the previous output inside the timed region, validate.py --val_flow_from_denoised; not the headline metric"
+        data += (f"; the {B} sequences as {og.G} independent groups on {og.G} HIP streams)" if og is not None else ")")
     if rehearsal:
         data += " (REHEARSAL: all ranks on one GPU, not a measurement)"
     if stub:
@@ -690,6 +772,8 @@ def main():
     if cpu:
         line["gpu_over_cpu"] = round(fps / cpu["value"], 1)
     print(json.dumps(line), flush=True)
+    if og is not None:
+        og.close()
     if dist is not None:
         dist.destroy_process_group()
 
