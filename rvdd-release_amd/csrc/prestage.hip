@@ -67,10 +67,33 @@ __global__ void ha_green_kernel(const float* __restrict__ raw, float* __restrict
     green[idx] = gval;
 }
 
-// algo2 (util/Hamilton_Adam_demo.py:145-172) for red (k = 0) and blue (k = 1) at pixel (y, x); g0 = its green
-__device__ __forceinline__ void ha_red_blue(const Cfa& c, const float* __restrict__ gp, int H, int W, int y, int x, float g0,
-                                            float (&rb)[2]) {
-    auto G = [&](int yy, int xx) { return gp[(size_t)clampi(yy, 0, H - 1) * W + clampi(xx, 0, W - 1)]; };
+// The 3x3 neighbourhood of a pixel in the green plane and in the CFA (replicate padded: coordinates clamped before the lookup),
+// loaded UNCONDITIONALLY and together: algo2 below picks among them by the pixel's CFA site, and a load inside one of its four
+// site branches was a memory round trip of its own (the branches diverge inside a wave: every path ran, each with its loads and
+// its s_waitcnt vmcnt(0) -- 25 dependent round trips per pixel in netin_kernel, profiles/r06g_netin_load_batches.txt).
+struct Ring {
+    float g[3][3], r[3][3];
+    int site[3][3];      // CFA site of the (clamped) neighbour
+};
+__device__ __forceinline__ void load_ring(const Cfa& c, const float* __restrict__ gp, int H, int W, int y, int x, Ring& q) {
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+            const int yy = clampi(y + dy - 1, 0, H - 1), xx = clampi(x + dx - 1, 0, W - 1);
+            const int st = ((yy & 1) << 1) | (xx & 1);
+            q.site[dy][dx] = st;
+            q.g[dy][dx] = gp[(size_t)yy * W + xx];
+            q.r[dy][dx] = c.raw[((size_t)st * c.h + (yy >> 1)) * c.w + (xx >> 1)];
+        }
+}
+
+// algo2 (util/Hamilton_Adam_demo.py:145-172) for red (k = 0) and blue (k = 1) at the ring's centre pixel (y, x)
+__device__ __forceinline__ void ha_red_blue(const Ring& q, int y, int x, float (&rb)[2]) {
+    auto G = [&](int dy, int dx) { return q.g[dy + 1][dx + 1]; };
+    // sparse colour plane `own` at a neighbour (Cfa::plane): the sample where the neighbour's site is `own`, zero elsewhere
+    auto P = [&](int dy, int dx, int own) { return q.site[dy + 1][dx + 1] == own ? q.r[dy + 1][dx + 1] : 0.f; };
+    const float g0 = q.g[1][1];
     const int site = ((y & 1) << 1) | (x & 1);   // 0 Gb(e,e) 1 B 2 R 3 Gr(o,o)
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
@@ -79,24 +102,24 @@ __device__ __forceinline__ void ha_red_blue(const Cfa& c, const float* __restric
         const int vsite = k == 0 ? 0 : 3;        // sites with vertical neighbours
         float v;
         if (site == own) {
-            v = c.at(y, x);
+            v = q.r[1][1];
         } else if (site == hsite) {
-            const float Kh = 0.5f * c.plane(y, x - 1, own) + 0.5f * c.plane(y, x + 1, own);
-            const float gD = (0.25f * G(y, x - 1) + (-0.5f) * g0) + 0.25f * G(y, x + 1);
+            const float Kh = 0.5f * P(0, -1, own) + 0.5f * P(0, 1, own);
+            const float gD = (0.25f * G(0, -1) + (-0.5f) * g0) + 0.25f * G(0, 1);
             v = Kh - gD;
         } else if (site == vsite) {
-            const float Kv = 0.5f * c.plane(y - 1, x, own) + 0.5f * c.plane(y + 1, x, own);
-            const float gD = (0.25f * G(y - 1, x) + (-0.5f) * g0) + 0.25f * G(y + 1, x);
+            const float Kv = 0.5f * P(-1, 0, own) + 0.5f * P(1, 0, own);
+            const float gD = (0.25f * G(-1, 0) + (-0.5f) * g0) + 0.25f * G(1, 0);
             v = Kv - gD;
         } else {  // mask_ochan site (B sites for red, R sites for blue): diagonal, hard selection
-            const float a = c.plane(y - 1, x - 1, own), d = c.plane(y + 1, x + 1, own);
-            const float bq = c.plane(y - 1, x + 1, own), cq = c.plane(y + 1, x - 1, own);
+            const float a = P(-1, -1, own), d = P(1, 1, own);
+            const float bq = P(-1, 1, own), cq = P(1, -1, own);
             const float Kp = 0.5f * a + 0.5f * d;
             const float Kn = 0.5f * bq + 0.5f * cq;
             const float Fp = (-1.f) * a + d;
             const float Fn = (-1.f) * bq + cq;
-            const float gDp = (G(y - 1, x - 1) + (-2.f) * g0) + G(y + 1, x + 1);
-            const float gDn = (G(y - 1, x + 1) + (-2.f) * g0) + G(y + 1, x - 1);
+            const float gDp = (G(-1, -1) + (-2.f) * g0) + G(1, 1);
+            const float gDn = (G(-1, 1) + (-2.f) * g0) + G(1, -1);
             const float Cp = Kp - gDp / 4.f;
             const float Cn = Kn - gDn / 4.f;
             const float CLp = fabsf(Fp) + fabsf(gDp);
@@ -119,9 +142,11 @@ __global__ void ha_rb_kernel(const float* __restrict__ raw, const float* __restr
     const int b = idx / ((size_t)W * H);
     Cfa c{raw + (size_t)b * rbs, h, w, H, W};
     const float* gp = green + (size_t)b * H * W;
-    const float g0 = gp[(size_t)y * W + x];
+    Ring q;
+    load_ring(c, gp, H, W, y, x, q);
+    const float g0 = q.g[1][1];
     float rb[2];
-    ha_red_blue(c, gp, H, W, y, x, g0, rb);
+    ha_red_blue(q, y, x, rb);
     float* o = out + (size_t)b * bstride + ((size_t)y * W + x) * pstride;
     o[0] = rb[0];
     o[cstride] = g0;
@@ -145,21 +170,38 @@ __device__ __forceinline__ void cubic_w(float t, float w[4]) {
 // full-resolution flow at (y,x) from the raw-resolution one:
 // F.interpolate(x2, bilinear, align_corners=True) * 2  (util/flow_utils.py:159-174,
 // models/recurrent_model.py:128-129)
-__device__ __forceinline__ void flow_at(const float* __restrict__ fr, int h, int w, int H, int W, int y,
-                                        int x, float& fx, float& fy) {
+struct FlowQ {      // the four raw-resolution flow vectors around a pixel and their bilinear weights
+    float f[2][4];
+    float ly0, ly1, lx0, lx1;
+};
+__device__ __forceinline__ void flow_fetch(const float* __restrict__ fr, int h, int w, int H, int W, int y, int x, FlowQ& q) {
     const float sy = H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.f;
     const float sx = W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.f;
     const float py = sy * (float)y, px = sx * (float)x;
     const int y0 = (int)py, x0 = (int)px;
     const int y1 = y0 + (y0 < h - 1 ? 1 : 0), x1 = x0 + (x0 < w - 1 ? 1 : 0);
-    const float ly1 = py - (float)y0, lx1 = px - (float)x0;
-    const float ly0 = 1.f - ly1, lx0 = 1.f - lx1;
-    const float* f0 = fr;
-    const float* f1 = fr + (size_t)h * w;
-    fx = (ly0 * (lx0 * f0[y0 * w + x0] + lx1 * f0[y0 * w + x1]) +
-          ly1 * (lx0 * f0[y1 * w + x0] + lx1 * f0[y1 * w + x1])) * 2.f;
-    fy = (ly0 * (lx0 * f1[y0 * w + x0] + lx1 * f1[y0 * w + x1]) +
-          ly1 * (lx0 * f1[y1 * w + x0] + lx1 * f1[y1 * w + x1])) * 2.f;
+    q.ly1 = py - (float)y0;
+    q.lx1 = px - (float)x0;
+    q.ly0 = 1.f - q.ly1;
+    q.lx0 = 1.f - q.lx1;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const float* f = fr + (size_t)c * h * w;
+        q.f[c][0] = f[y0 * w + x0];
+        q.f[c][1] = f[y0 * w + x1];
+        q.f[c][2] = f[y1 * w + x0];
+        q.f[c][3] = f[y1 * w + x1];
+    }
+}
+__device__ __forceinline__ void flow_combine(const FlowQ& q, float& fx, float& fy) {
+    fx = (q.ly0 * (q.lx0 * q.f[0][0] + q.lx1 * q.f[0][1]) + q.ly1 * (q.lx0 * q.f[0][2] + q.lx1 * q.f[0][3])) * 2.f;
+    fy = (q.ly0 * (q.lx0 * q.f[1][0] + q.lx1 * q.f[1][1]) + q.ly1 * (q.lx0 * q.f[1][2] + q.lx1 * q.f[1][3])) * 2.f;
+}
+__device__ __forceinline__ void flow_at(const float* __restrict__ fr, int h, int w, int H, int W, int y,
+                                        int x, float& fx, float& fy) {
+    FlowQ q;
+    flow_fetch(fr, h, w, H, W, y, x, q);
+    flow_combine(q, fx, fy);
 }
 
 // util/flow_utils.py:90-99 + ATen grid_sampler (bicubic, border, align_corners=True)
@@ -228,19 +270,20 @@ __global__ void warp3_kernel(const float* __restrict__ src4, const float* __rest
 // pixel's whole NHWC16 vector -- three 16-B stores of full sectors.  Written by three kernels (red/blue, two warps)
 // every pixel's 64 bytes were touched three times with 12-B partial stores.  Same arithmetic as ha_rb_kernel and
 // warp3_kernel (the demosaic stays bit-exact).
-__device__ __forceinline__ f32x4 warp3_at(const f32x4* __restrict__ s, const float* __restrict__ flow_b, int h, int w, int H,
-                                          int W, int y, int x) {
-    if (!flow_b) return s[(size_t)y * W + x];          // --no_warp
-    float fx, fy;
-    flow_at(flow_b, h, w, H, W, y, x, fx, fy);
-    Taps t;
-    make_taps(fx, fy, x, y, H, W, t);
+// (the 16 taps of a pixel are loaded TOGETHER, then summed in warp3_kernel's order)
+__device__ __forceinline__ void warp3_gather(const f32x4* __restrict__ s, const Taps& t, int W, f32x4 (&v)[16]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[4 * j + i] = s[(size_t)t.yi[j] * W + t.xi[i]];
+}
+__device__ __forceinline__ f32x4 warp3_sum(const Taps& t, const f32x4 (&v)[16]) {
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         f32x4 row = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int i = 0; i < 4; ++i) row = row + s[(size_t)t.yi[j] * W + t.xi[i]] * t.wx[i];
+        for (int i = 0; i < 4; ++i) row = row + v[4 * j + i] * t.wx[i];
         acc = acc + row * t.wy[j];
     }
     return acc;
@@ -252,22 +295,57 @@ struct NetinArgs {
     int B, h, w;
     int64_t rbs, fbs;
 };
+// Three batches of loads, each in flight together: (1) the flow vectors around the pixel (both directions) and the 3x3 rings of the
+// green plane and the CFA, (2) the 16 bicubic taps of the previous output, (3) those of the next frame -- with the demosaic's
+// arithmetic between them.  Written as one expression after another (round 1-5) the compiler kept the kernel at 8 waves per SIMD by
+// issuing every load next to its use: ~60 dependent memory round trips per pixel, waves 75 % of their life in s_waitcnt
+// (profiles/r06f_c4_prestage_counters.json).  Same operations on the same values: same bits.
 __device__ __forceinline__ void netin_pixel(const NetinArgs& a, size_t idx, f32x4 (&o)[3]) {
     const int H = 2 * a.h, W = 2 * a.w;
-    const int x = idx % W;
-    const int y = (idx / W) % H;
-    const int b = idx / ((size_t)W * H);
+    const unsigned i32 = (unsigned)idx;      // (B H W < 2^32: launch_netin checks; 64-bit divisions are ~100 instructions each)
+    const int x = (int)(i32 % (unsigned)W);
+    const unsigned yb = i32 / (unsigned)W;
+    const int y = (int)(yb % (unsigned)H);
+    const int b = (int)(yb / (unsigned)H);
     Cfa c{a.raw_cur + (size_t)b * a.rbs, a.h, a.w, H, W};
     const float* gp = a.green + (size_t)b * H * W;
-    const float g0 = gp[(size_t)y * W + x];
+    const f32x4* sp = reinterpret_cast<const f32x4*>(a.prev4) + (size_t)b * H * W;
+    const f32x4* sn = reinterpret_cast<const f32x4*>(a.next4) + (size_t)b * H * W;
+    const bool warp_p = a.flow_prev != nullptr, has_n = a.next4 != nullptr, warp_n = has_n && a.flow_next != nullptr;
+    // ---- batch 1
+    FlowQ fq_p, fq_n;
+    if (warp_p) flow_fetch(a.flow_prev + (size_t)b * a.fbs, a.h, a.w, H, W, y, x, fq_p);
+    if (warp_n) flow_fetch(a.flow_next + (size_t)b * a.fbs, a.h, a.w, H, W, y, x, fq_n);
+    Ring q;
+    load_ring(c, gp, H, W, y, x, q);
+    // ---- batch 2: the taps of the previous output, gathered together (--no_warp: the pixel itself, models/recurrent_model.py:156-158)
+    Taps tp;
+    f32x4 vt[16];
+    f32x4 p, n = {0.f, 0.f, 0.f, 0.f};
+    if (warp_p) {
+        float fx, fy;
+        flow_combine(fq_p, fx, fy);
+        make_taps(fx, fy, x, y, H, W, tp);
+        warp3_gather(sp, tp, W, vt);
+    } else {
+        p = sp[(size_t)y * W + x];
+    }
+    // ---- the demosaic's red and blue under the gather's flight
     float rb[2];
-    ha_red_blue(c, gp, H, W, y, x, g0, rb);
-    const f32x4 p = warp3_at(reinterpret_cast<const f32x4*>(a.prev4) + (size_t)b * H * W,
-                             a.flow_prev ? a.flow_prev + (size_t)b * a.fbs : nullptr, a.h, a.w, H, W, y, x);
-    f32x4 n = {0.f, 0.f, 0.f, 0.f};
-    if (a.next4)
-        n = warp3_at(reinterpret_cast<const f32x4*>(a.next4) + (size_t)b * H * W,
-                     a.flow_next ? a.flow_next + (size_t)b * a.fbs : nullptr, a.h, a.w, H, W, y, x);
+    ha_red_blue(q, y, x, rb);
+    const float g0 = q.g[1][1];
+    if (warp_p) p = warp3_sum(tp, vt);
+    // ---- batch 3: the next frame's taps (one gather's 64 registers at a time: both in flight spill)
+    if (warp_n) {
+        float fx, fy;
+        flow_combine(fq_n, fx, fy);
+        Taps tn;
+        make_taps(fx, fy, x, y, H, W, tn);
+        warp3_gather(sn, tn, W, vt);
+        n = warp3_sum(tn, vt);
+    } else if (has_n) {
+        n = sn[(size_t)y * W + x];
+    }
     o[0] = f32x4{p[0], p[1], p[2], rb[0]};
     o[1] = f32x4{g0, rb[1], n[0], n[1]};
     o[2] = f32x4{n[2], 0.f, 0.f, 0.f};
@@ -280,7 +358,8 @@ __device__ __forceinline__ unsigned xcd_contiguous_block() {
     return blockIdx.x < 8u * per ? (blockIdx.x & 7u) * per + (blockIdx.x >> 3) : blockIdx.x;
 }
 
-__global__ __launch_bounds__(256) void netin_kernel(NetinArgs a, float* __restrict__ netin) {
+// (at most five waves per SIMD asked of the compiler: with the default target of eight it serialises the loads again to save registers)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) void netin_kernel(NetinArgs a, float* __restrict__ netin) {
     const size_t idx = (size_t)xcd_contiguous_block() * blockDim.x + threadIdx.x;
     if (idx >= (size_t)a.B * 4 * a.h * a.w) return;
     f32x4 v[3];
@@ -296,7 +375,7 @@ __global__ __launch_bounds__(256) void netin_kernel(NetinArgs a, float* __restri
 // through LDS (pixel pitch 24 floats: the 16 lanes of a ds_read_b128 group on 16 distinct bank quads) and each wave projects
 // four 16-pixel groups on the f32 matrix pipe (16x16x4, exact f32 products).  pw as proj1x1_kernel<16, 0>'s:
 // [m 3][lr 16][g 4][i 4] = W[16m+lr][4g+i] (zero for channels the input does not have).
-__global__ __launch_bounds__(256, 5) void netin_proj_kernel(NetinArgs a, const float* __restrict__ pw, const float* __restrict__ bias,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) void netin_proj_kernel(NetinArgs a, const float* __restrict__ pw, const float* __restrict__ bias,
                                                          float* __restrict__ out) {
     __shared__ __attribute__((aligned(16))) float s_t[256][24];
     const size_t total = (size_t)a.B * 4 * a.h * a.w;
@@ -859,6 +938,7 @@ hipError_t launch_netin(const float* raw_cur, float* green_scratch, const float*
                         int64_t raw_bstride, int64_t flow_bstride, const float* proj_w16, const float* proj_b, float* proj_out) {
     const size_t n = (size_t)B * 4 * h * w;
     if (!n) return hipSuccess;
+    if (n >= 0x100000000ull) return hipErrorInvalidValue;      // netin_pixel's 32-bit pixel index
     const int64_t rbs = raw_bstride ? raw_bstride : (int64_t)4 * h * w, fbs = flow_bstride ? flow_bstride : (int64_t)2 * h * w;
     hipLaunchKernelGGL(ha_green_kernel, dim3(nblocks(n, 256)), dim3(256), 0, s, raw_cur, green_scratch, B, h, w, rbs);
     const NetinArgs a{raw_cur, green_scratch, prev4, flow_prev, next4, flow_next, B, h, w, rbs, fbs};
