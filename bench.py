@@ -225,6 +225,8 @@ class GpuSampler:
         import threading
         self.dev, self.period = dev_index, period
         self.samples = []                       # (perf_counter, sclk MHz or None, W or None)
+        # the child must not inherit a profiler's preload (it would initialise the GPU in rocm-smi, whose `env python3` hop is then refused)
+        self._env = {k: v for k, v in os.environ.items() if k != "LD_PRELOAD" and not k.startswith(("ROCP", "ROCPROF"))}
         self._stop = threading.Event()
         self._thread = threading.Thread(target=self._run, daemon=True)
         self.error = None
@@ -236,7 +238,7 @@ class GpuSampler:
             t = time.perf_counter()
             try:
                 txt = subprocess.run(["rocm-smi", "-d", str(self.dev), "--showpower", "--showclocks"], capture_output=True,
-                                     text=True, timeout=10).stdout
+                                     text=True, timeout=10, env=self._env).stdout
                 mc = re.search(r"sclk[^\n]*?\((\d+)Mhz\)", txt)
                 mp = re.search(r"Power \(W\):\s*([\d.]+)", txt)
                 self.samples.append((0.5 * (t + time.perf_counter()), int(mc.group(1)) if mc else None, float(mp.group(1)) if mp else None))
@@ -558,7 +560,8 @@ def main():
     for _ in range(args.warmup):
         one_step()
     # shader clock and package power through every timed region of this process (rank 0 of a single-node run samples its own GPU)
-    sampler = GpuSampler(dev_index) if (rank == 0 and not stub and not args.no_gpu_sampler) else None
+    under_profiler = "rocprof" in os.environ.get("LD_PRELOAD", "").lower() or any(k.startswith("ROCPROF") for k in os.environ)
+    sampler = GpuSampler(dev_index) if (rank == 0 and not stub and not args.no_gpu_sampler and not under_profiler) else None
     barrier()
     if not args.no_kernel_events:
         if args.all_kernel_events:
