@@ -329,6 +329,17 @@ class OnlineGroups:
             rt.close()
 
 
+def csrc_hash():
+    """sha256[:16] over the kernel sources (what tools/pmc_summary.py stamps profiles/traffic.json with)."""
+    import glob
+    import hashlib
+    hs = hashlib.sha256()
+    d = os.path.join(REPO, "rvdd-release_amd", "csrc")
+    for fn in sorted(glob.glob(os.path.join(d, "*.hip")) + glob.glob(os.path.join(d, "*.inc")) + glob.glob(os.path.join(d, "*.h"))):
+        hs.update(open(fn, "rb").read())
+    return hs.hexdigest()[:16]
+
+
 def roofline_of(dom, k, config, arch, events_note):
     """The `roofline` object of a kernel class from its event-timed launches (k: launches, avg_us, tflops, gbps, bytes_per_launch)."""
     # HBM bytes per launch from the PMC passes of the same command (tools/gpu_profile.sh + tools/pmc_summary.py:
@@ -339,6 +350,11 @@ def roofline_of(dom, k, config, arch, events_note):
         tj = json.load(open(os.path.join(REPO, "profiles", "traffic.json")))
         ent = tj.get(config) or tj.get("C2" if config in ("C5", "C3") else config)      # C3 / C5: C2's maps and launch mix
         traffic, traffic_src = ent["kernels"].get(dom), ent.get("source")
+        # a committed measurement is quoted only for the kernel sources it was taken on: after a kernel change without a
+        # re-profile (tools/gpu_profile.sh + tools/pmc_summary.py) the line says so instead of quoting stale bytes
+        if ent.get("csrc_sha256_16") != csrc_hash():
+            traffic_src = f"{traffic_src} -- STALE: measured on csrc {ent.get('csrc_sha256_16')}, this build is {csrc_hash()}; traffic withheld"
+            traffic = None
     except Exception:
         pass
     factor = next((f for pre, f in EXECUTED_PER_ALGORITHMIC.items() if dom.startswith(pre)), 1.0)

@@ -280,6 +280,7 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3h_kernel(ConvArgs a) {
                                        // 2^31 for a column outside the image or a thread without a piece (it stays out of range
                                        // through all the rounds: they add a few MB at most)
         int y0, x0;
+        int soff;                      // UPS, interior tile (see fetch_ups): byte offset of the tile's first source pixel; -1: the general form
     };
     auto source = [&](const TilePos& p, bool live) {
         Src q;
@@ -290,6 +291,10 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3h_kernel(ConvArgs a) {
         q.base = xok ? (unsigned)(g_lane + ((p.y0 - PAD) * a.W + (p.x0 - PAD)) * (CIN * 4)) : 0x80000000u;
         q.y0 = p.y0;
         q.x0 = p.x0;
+        q.soff = -1;
+        if constexpr (UPS) {
+            if (p.y0 >= 16 && p.y0 + IH <= a.H && p.x0 >= 16 && p.x0 + IW <= a.W) q.soff = (((p.y0 >> 1) - 1) * iw + (p.x0 >> 1) - 1) * (CIN * 4);
+        }
         return q;
     };
     // (one v_add per round; the image's rows above and below come out of the buffer's range check, see Src::base.  Rows of the
@@ -303,16 +308,21 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3h_kernel(ConvArgs a) {
     // Two items per thread (972 of 1024 slots); a group of four waves with its 10x18 halo: 5x9 blocks, three per thread.
     constexpr int UNR = UPS ? (NGRP == 1 ? 2 : 3) : 1;
     constexpr int UBLK = (IH / 2) * 9;
-    int u_by[UNR], u_bx[UNR], u_part[UNR];
-    bool u_ok[UNR];
+    // per item: (block row | block column << 8 | piece << 16 | valid << 24) in ONE register, and the LDS byte address of the block's first
+    // pixel and piece (the other three pixels of the block at immediate offsets): this instantiation sits at the 256-register limit
+    int u_pk[UNR];
+    unsigned u_lds[UNR];
 #pragma unroll
     for (int r0 = 0; r0 < UNR; ++r0) {
         const int item = gtid + G::NT * r0, blk = item / 12;
-        u_part[r0] = item - blk * 12;
-        u_by[r0] = blk / 9;
-        u_bx[r0] = blk - u_by[r0] * 9;
-        u_ok[r0] = blk < UBLK;
+        const int part_ = item - blk * 12, by_ = blk / 9, bx_ = blk - by_ * 9;
+        u_pk[r0] = by_ | (bx_ << 8) | (part_ << 16) | ((blk < UBLK ? 1 : 0) << 24);
+        u_lds[r0] = plane0 + (unsigned)(((2 * by_) * IW + 2 * bx_) * G::S + part_ * 8);
     }
+    auto U_BY = [&](int r0) { return u_pk[r0] & 0xff; };
+    auto U_BX = [&](int r0) { return (u_pk[r0] >> 8) & 0xff; };
+    auto U_PART = [&](int r0) { return (u_pk[r0] >> 16) & 0xff; };
+    auto U_OK = [&](int r0) { return (u_pk[r0] >> 24) != 0; };
     f32x4 ulo[UNR][4];                 // source pixels (row 0 col 0, row 0 col 1, row 1 col 0, row 1 col 1)
     float u_ly[UNR][2], u_lx[UNR][2];  // weight of the second source row / column per block row / column; < 0: outside the map
     u32x2 ushi[UNR][4], uslo[UNR][4];
@@ -325,32 +335,29 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3h_kernel(ConvArgs a) {
     int u_off00[UNR];
 #pragma unroll
     for (int r0 = 0; r0 < UNR; ++r0)
-        u_off00[r0] = u_ok[r0] ? ((u_by[r0] * (a.W >> 1) + u_bx[r0]) * (CIN * 4) + u_part[r0] * 16) : (int)0x80000000;
-    auto interior = [&](const Src& q) {
-        return UPS && q.y0 >= 16 && q.y0 + IH <= a.H && q.x0 >= 16 && q.x0 + IW <= a.W;
-    };
+        u_off00[r0] = U_OK(r0) ? ((U_BY(r0) * (a.W >> 1) + U_BX(r0)) * (CIN * 4) + U_PART(r0) * 16) : (int)0x80000000;
     auto fetch_ups = [&](const Src& q, int r0) {
         const int ih = a.H >> 1, iw = a.W >> 1;
-        if (interior(q)) {
-            const int soff0 = (((q.y0 >> 1) - 1) * iw + (q.x0 >> 1) - 1) * (CIN * 4), soff1 = soff0 + iw * (CIN * 4);
+        if (q.soff >= 0) {
+            const int soff0 = q.soff, soff1 = soff0 + iw * (CIN * 4);
             ulo[r0][0] = bload(q.r, (unsigned)u_off00[r0], soff0);
             ulo[r0][1] = bload(q.r, (unsigned)u_off00[r0] + (unsigned)(CIN * 4), soff0);
             ulo[r0][2] = bload(q.r, (unsigned)u_off00[r0], soff1);
             ulo[r0][3] = bload(q.r, (unsigned)u_off00[r0] + (unsigned)(CIN * 4), soff1);
             return;
         }
-        const int i = (q.y0 >> 1) - 1 + u_by[r0], jx = (q.x0 >> 1) - 1 + u_bx[r0];
+        const int i = (q.y0 >> 1) - 1 + U_BY(r0), jx = (q.x0 >> 1) - 1 + U_BX(r0);
         const int rr0 = min(max(i, 0), ih - 1), cc0 = min(max(jx, 0), iw - 1);
         const int rr1 = rr0 + (rr0 < ih - 1 ? 1 : 0), cc1 = cc0 + (cc0 < iw - 1 ? 1 : 0);
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
-            const int Y = q.y0 - 1 + 2 * u_by[r0] + e, X = q.x0 - 1 + 2 * u_bx[r0] + e;
+            const int Y = q.y0 - 1 + 2 * U_BY(r0) + e, X = q.x0 - 1 + 2 * U_BX(r0) + e;
             const float py = fmaxf(0.5f * ((float)Y + 0.5f) - 0.5f, 0.f), px = fmaxf(0.5f * ((float)X + 0.5f) - 0.5f, 0.f);
             u_ly[r0][e] = (unsigned)Y < (unsigned)a.H ? py - (float)(int)py : -1.f;
             u_lx[r0][e] = (unsigned)X < (unsigned)a.W ? px - (float)(int)px : -1.f;
         }
-        const bool any = u_ok[r0] && (u_ly[r0][0] >= 0.f || u_ly[r0][1] >= 0.f) && (u_lx[r0][0] >= 0.f || u_lx[r0][1] >= 0.f);
-        const unsigned p16 = (unsigned)(u_part[r0] * 16);
+        const bool any = U_OK(r0) && (u_ly[r0][0] >= 0.f || u_ly[r0][1] >= 0.f) && (u_lx[r0][0] >= 0.f || u_lx[r0][1] >= 0.f);
+        const unsigned p16 = (unsigned)(U_PART(r0) * 16);
         ulo[r0][0] = bload(q.r, any ? (unsigned)((rr0 * iw + cc0) * (CIN * 4)) + p16 : 0x80000000u);
         ulo[r0][1] = bload(q.r, any ? (unsigned)((rr0 * iw + cc1) * (CIN * 4)) + p16 : 0x80000000u);
         ulo[r0][2] = bload(q.r, any ? (unsigned)((rr1 * iw + cc0) * (CIN * 4)) + p16 : 0x80000000u);
@@ -360,7 +367,7 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3h_kernel(ConvArgs a) {
     auto interp_ups = [&](const Src& q, int r0, float sc_st, auto scaled_tag) {
         constexpr bool SC_ = decltype(scaled_tag)::value;
         auto fma4 = [](f32x4 x, float sc, f32x4 c) { return __builtin_elementwise_fma(x, f32x4{sc, sc, sc, sc}, c); };
-        if (interior(q)) {      // halo rows / columns of an interior tile: odd first (weight 1/4 on the second source), then even (3/4)
+        if (q.soff >= 0) {      // halo rows / columns of an interior tile: odd first (weight 1/4 on the second source), then even (3/4)
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
                 const float ly1 = e ? 0.75f : 0.25f, ly0 = 1.f - ly1;
@@ -388,12 +395,12 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3h_kernel(ConvArgs a) {
     auto write_ups = [&]() {
 #pragma unroll
         for (int r0 = 0; r0 < UNR; ++r0)
-            if (u_ok[r0]) {
+            if (U_OK(r0)) {
 #pragma unroll
                 for (int e = 0; e < 2; ++e)
 #pragma unroll
                     for (int f = 0; f < 2; ++f) {
-                        const unsigned ad = plane0 + (unsigned)(((2 * u_by[r0] + e) * IW + 2 * u_bx[r0] + f) * G::S + u_part[r0] * 8);
+                        const unsigned ad = u_lds[r0] + (unsigned)((e * IW + f) * G::S);
                         *(lds_u2*)(L + ad) = ushi[r0][2 * e + f];
                         *(lds_u2*)(L + ad + G::PLANE) = uslo[r0][2 * e + f];
                     }

@@ -121,15 +121,17 @@ def test_no_kernel_spills_to_scratch():
     # of the MFMA loop (+0.4 % on C2): pinned at that one
     plain = ("conv3x3h_kernel<48, 0, false, false, 1, 3, 3>", "conv3x3h_kernel<48, 1, false, false, 1, 3, 3>")
     # the output-channel-split instantiations (conv3x3h.hip MT = 1: launches with at most a third of a tile per CU, where a launch
-    # is one tile per workgroup) are not the hot path: pinned on their own at what they have (the fused-upsample one 26)
+    # is one tile per workgroup) are not the hot path: pinned on their own at what they have (the fused-upsample one 31: round 6's
+    # interior-tile form of its halo fetch added five scalars to the 26 -- and took 85 vector instructions per item out of the loop)
     small = [r for r in rows if r["name"].startswith("conv3x3h_kernel<48, ") and r["name"].endswith(", 1>")]
-    assert small and all(r.get("sgpr_spill_count", 0) <= 26 for r in small), [(r["name"], r["sgpr_spill_count"]) for r in small]
+    assert small and all(r.get("sgpr_spill_count", 0) <= 31 for r in small), [(r["name"], r["sgpr_spill_count"]) for r in small]
     rows = [r for r in rows if r not in small]
     bad = [(r["name"], r["sgpr_spill_count"]) for r in rows if r["name"].startswith(hot) and not r["name"].startswith(once)
            and r.get("sgpr_spill_count", 0) > (1 if r["name"].startswith(plain) else 0)]
     assert not bad, bad
     # the fused-upsample instantiations (three launches per frame-step) carry the interpolation's row / column constants on
-    # top of the tile loop's: 20 and 17 scalars in vector lanes, pinned there
+    # top of the tile loop's, and since round 6 two forms of the fetch (interior tiles: no address / weight arithmetic; border tiles:
+    # the general form): 27 scalars in vector lanes, pinned there -- at most nine v_readlane in the chunk loop's code, none per chunk
     ups = ("conv3x3h_kernel<48, 1, false, true, ",)
     bad = [(r["name"], r["sgpr_spill_count"]) for r in rows if r["name"].startswith(once) and not r["name"].startswith(ups)
            and r.get("sgpr_spill_count", 0) > 16]
@@ -137,7 +139,7 @@ def test_no_kernel_spills_to_scratch():
     bad = [(r["name"], r["sgpr_spill_count"]) for r in rows if r["name"].startswith(few) and not r["name"].startswith(ups)
            and r.get("sgpr_spill_count", 0) > 14]
     assert not bad, bad
-    bad = [(r["name"], r["sgpr_spill_count"]) for r in rows if r["name"].startswith(ups) and r.get("sgpr_spill_count", 0) > 20]
+    bad = [(r["name"], r["sgpr_spill_count"]) for r in rows if r["name"].startswith(ups) and r.get("sgpr_spill_count", 0) > 27]
     assert not bad, bad
     # the pipelined ConvBlock is C4's hot kernel (about 25 launches per frame-step), not a once-per-step variant: its plain
     # instantiation is pinned at what it has today, the pooling / 1x1-output ones at a handful

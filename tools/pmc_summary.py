@@ -48,6 +48,13 @@ json.dump({"config": config, "correction": "bytes = (2*FETCH_SIZE + WRITE_SIZE)*
            "kernels": out}, open(dst, "w"), indent=1)
 tj = os.path.join(root, "profiles", "traffic.json")
 allc = json.load(open(tj)) if os.path.exists(tj) else {}
-allc[config] = {"source": os.path.basename(dst), "kernels": {k: v["hbm_bytes_per_launch"] for k, v in out.items()}}
+# the kernel sources these bytes were measured on: bench.py quotes the traffic only while the sources still hash to this
+import hashlib
+hs = hashlib.sha256()
+for fn in sorted(glob.glob(os.path.join(root, "rvdd-release_amd", "csrc", "*.hip")) + glob.glob(os.path.join(root, "rvdd-release_amd", "csrc", "*.inc"))
+                 + glob.glob(os.path.join(root, "rvdd-release_amd", "csrc", "*.h"))):
+    hs.update(open(fn, "rb").read())
+allc[config] = {"source": os.path.basename(dst), "csrc_sha256_16": hs.hexdigest()[:16],
+                "kernels": {k: v["hbm_bytes_per_launch"] for k, v in out.items()}}
 json.dump(allc, open(tj, "w"), indent=1)
 print(open(dst).read()[:1500])
