@@ -381,7 +381,7 @@ def roofline_of(dom, k, config, arch, events_note):
             "mfma_dtype": "f16 (f32 operands split hi + lo, f32 accumulation)" if split else "f32",
             "hbm_gbps_algorithmic": round(k["gbps"], 1),
             "what_is_executed": ("F16 MFMA flops the kernel executes in its two 1x1 convs (114 MFMAs per 16 pixels; the depth-wise 7x7, "
-                                 "LayerNorm and GELU run on the vector ALU and bound the kernel: DESIGN.md 4.3c)")
+                                 "LayerNorm and GELU run on the vector ALU and bound the kernel: DESIGN.md 4.4)")
                                 if split and dom == "convblock_kernel" else
                                 "F16 MFMA flops the kernel executes: 3 MFMAs per product (hi.hi, hi.lo, lo.hi), K 432 padded to 448"
                                 if split else
@@ -768,10 +768,10 @@ def main():
         "dtype": "f32 (products as 3 split-f16 MFMAs, f32 accumulation)" if split_path else "f32", "data": data,
         "arithmetic": ("f32 in, f32 out, f32 accumulation; the convunet's 48-channel 3x3 convs multiply on the F16 matrix pipe with "
                        "every f32 operand split into two f16 halves (3 MFMAs per product): as close to the reference as the "
-                       "f32-MFMA kernels (tests/split_precision_study.py, DESIGN.md 4.1c); RVDD_CONV=f32 runs those instead")
+                       "f32-MFMA kernels (tests/split_precision_study.py, DESIGN.md 4); RVDD_CONV=f32 runs those instead")
                       if (not arch.startswith("next") and _CONV.startswith("conv3x3h")) else
                       ("f32 in, f32 out, f32 accumulation; the ConvBlock's two 1x1 convs multiply on the F16 matrix pipe with every f32 "
-                       "operand split into two f16 halves (DESIGN.md 4.3c); RVDD_NEXT_SPLIT=0 runs the f32-MFMA form")
+                       "operand split into two f16 halves (DESIGN.md 4.4); RVDD_NEXT_SPLIT=0 runs the f32-MFMA form")
                       if (arch.startswith("next") and os.environ.get("RVDD_NEXT_SPLIT") != "0" and os.environ.get("RVDD_NEXT_FUSED") != "0")
                       else "f32 throughout (f32 MFMA, f32 VALU)",
         "config": {"workload": f"{config}: {DESCR[config]}" + (f" (run with --frames {T})" if args.frames else ""),

@@ -190,7 +190,7 @@ int rvdd_srgb_metrics(rvdd_t* h, const uint8_t* a, const uint8_t* b, int32_t n, 
  *   "conv_kernel": which kernel runs the convunet's 3x3 convs.  0 (default) = EVERY 3x3 conv of the net -- the
  *              16-channel first layer and UpConv's fused upsample included -- on the F16 matrix pipe with each f32
  *              operand split into two f16 halves, three MFMAs per product, f32 accumulation (conv3x3h.hip: as close
- *              to the reference as the f32 kernels, DESIGN.md section 4.1c).  The f16 exponent range is not a limit
+ *              to the reference as the f32 kernels, DESIGN.md section 4).  The f16 exponent range is not a limit
  *              of the path: every map carries its max |x| per sequence and is multiplied by a power of two before
  *              the split (block floating point, exact), so frames of any finite magnitude keep fp32 semantics
  *              (tests/test_gpu_parity.py::test_split_path_any_magnitude).  1 = the direct f32 kernel everywhere;

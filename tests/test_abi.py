@@ -118,7 +118,7 @@ def test_no_kernel_spills_to_scratch():
            "conv3x3h_kernel<48, 3, ", "conv3x3h_kernel<48, 4, ", "conv3x3h_kernel<16, ")
     once = once + few
     # the plain 48 -> 48 instantiations keep ONE loop invariant in a vector lane since the tile's own offsets moved to chunk 6
-    # of the MFMA loop (+0.4 % on C2): pinned at that one
+    # of the MFMA loop (+0.4 % on C2, LABBOOK.md 4.1d): pinned at that one
     plain = ("conv3x3h_kernel<48, 0, false, false, 1, 3, 3>", "conv3x3h_kernel<48, 1, false, false, 1, 3, 3>")
     # the output-channel-split instantiations (conv3x3h.hip MT = 1: launches with at most a third of a tile per CU, where a launch
     # is one tile per workgroup) are not the hot path: pinned on their own at what they have (the fused-upsample one 31: round 6's

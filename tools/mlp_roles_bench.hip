@@ -1,4 +1,4 @@
-// Microbenchmark (gfx950) for the NEXT organisation of the fused ConvBlock ("what a wave costs"): the MLP of a tile
+// Microbenchmark (gfx950) for the NEXT organisation of the fused ConvBlock (LABBOOK.md 4.3e, "what a wave costs"): the MLP of a tile
 // (per 16-pixel group 60 + 54 split-f16 MFMAs with a GELU + split of 192 hidden values between them) run
 //   MODE 0  as convblock_pipe_kernel's back waves run it today: one wave per SIMD does fc1, GELU + split, fc2 for two pixel groups at a time;
 //   MODE 1  by PURE roles: per SIMD one wave that issues nothing but MFMAs (and the LDS traffic around them) and one wave that does nothing
