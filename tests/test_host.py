@@ -131,3 +131,44 @@ def test_synth_is_deterministic_and_shaped():
     # the GBRG mosaic of the clean frame is what the noise was added to: residual ~ noise model
     g = a.gt[:, 1, 0::2, 0::2]
     assert (a.raw[:, 0] - g).abs().mean() < 0.05
+
+
+def test_bench_traffic_is_stamped_with_the_kernel_sources_it_was_measured_on():
+    """profiles/traffic.json (the PMC bytes bench.py quotes in roofline.traffic) carries the hash of csrc/ it was measured on;
+    bench.py withholds the number -- and says so -- for any other sources.  The committed tree must be consistent: a kernel
+    change is followed by tools/r06_evidence.sh (tools/gpu_profile.sh + tools/pmc_summary.py) before it is committed."""
+    import json
+    import os
+    import bench
+    tj = json.load(open(os.path.join(bench.REPO, "profiles", "traffic.json")))
+    now = bench.csrc_hash()
+    for cfg in ("C2", "C4"):
+        assert tj[cfg].get("csrc_sha256_16") == now, (cfg, tj[cfg].get("csrc_sha256_16"), now)
+    k = {"launches": 10, "avg_us": 222.0, "tflops": 370.0, "gbps": 3400.0, "bytes_per_launch": 768e6}
+    r = bench.roofline_of("conv3x3h_kernel<48, 1, false, false>", k, "C2", "convunet+feat", "test")
+    assert r["traffic"] and "STALE" not in r["traffic_source"]
+    assert r["peak_sustained"] == bench.F16_SUSTAINED_TFLOPS and abs(r["frac_executed_sustained"] - 370.0 * 3 * 448 / 432 / 1926.0) < 1e-3
+    # other sources: withheld
+    real = bench.csrc_hash
+    try:
+        bench.csrc_hash = lambda: "0" * 16
+        r2 = bench.roofline_of("conv3x3h_kernel<48, 1, false, false>", k, "C2", "convunet+feat", "test")
+    finally:
+        bench.csrc_hash = real
+    assert r2["traffic"] is None and "STALE" in r2["traffic_source"]
+
+
+def test_gpu_sampler_window_and_failure_modes():
+    """bench.GpuSampler never raises, reports only the samples inside the asked window, and summarises clock and power."""
+    import time
+    import bench
+    s = bench.GpuSampler.__new__(bench.GpuSampler)
+    s.samples = [(1.0, 1900, 1300.0), (2.0, 1950, 1350.0), (3.0, None, None), (9.0, 2400, 300.0)]
+    s.error = None
+    w = s.window(0.5, 3.5)
+    assert w["samples"] == 3 and w["sclk_mhz_mean"] == 1925.0 and w["sclk_mhz_min"] == 1900 and w["package_w_max"] == 1350.0
+    assert s.window(4.0, 5.0)["samples"] == 0
+    live = bench.GpuSampler(0, 0.05)          # no GPU here: rocm-smi prints nothing useful or is absent -- no exception either way
+    time.sleep(0.3)
+    live.close()
+    assert isinstance(live.window(0.0, time.perf_counter()), dict)
