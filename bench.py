@@ -66,7 +66,7 @@ F16_SUSTAINED_SOURCE = "profiles/r04_mfma_f16_shapes_power.txt (tools/mfma_f16_s
 # the convunet's plain 48 -> 48 3x3 conv: the split-f16 kernel (default), or the f32-MFMA kernels (RVDD_CONV=f32 | winograd | direct)
 _CONV = {"direct": "conv3x3_kernel<48, 1, false>", "winograd": "wino3x3_kernel<1, false>",
          "f32": "wino3x3_kernel<1, false>"}.get(os.environ.get("RVDD_CONV", ""), "conv3x3h_kernel<48, 1, false, false>")
-_NEXT = "mlp_kernel" if os.environ.get("RVDD_NEXT_FUSED") == "0" else "convblock_kernel"
+_NEXT = "convblock_kernel"
 DOMINANT = {"convunet": _CONV, "convunet+feat": _CONV, "next": _NEXT, "next+feat": _NEXT}
 # The launches of a kernel class inside one frame-step repeat with period 11 (plain 48->48 3x3 conv; 14 when the
 # upsample is not fused) or 25 (ConvNeXt ConvBlock) over the four resolution levels; bracketing every 3rd launch (3 is
@@ -759,7 +759,7 @@ def main():
     if stub:
         data += " (STUB: CPU stand-in for the HIP runtime, launcher/collective test only, not a measurement)"
     split_path = (_CONV.startswith("conv3x3h") if not arch.startswith("next") else
-                  (os.environ.get("RVDD_NEXT_SPLIT") != "0" and os.environ.get("RVDD_NEXT_FUSED") != "0"))
+                  os.environ.get("RVDD_NEXT_SPLIT") != "0")
     line = {
         "metric": "frames/sec (whole job), recurrent video denoise+demosaic inference", "value": round(fps, 3),
         "unit": "frames/s", "n_gpus": world, "n_ranks_seen": n_ranks_seen, "distributed": distributed, "steps": args.steps, "warmup": args.warmup,
@@ -772,7 +772,7 @@ def main():
                       if (not arch.startswith("next") and _CONV.startswith("conv3x3h")) else
                       ("f32 in, f32 out, f32 accumulation; the ConvBlock's two 1x1 convs multiply on the F16 matrix pipe with every f32 "
                        "operand split into two f16 halves (DESIGN.md 4.4); RVDD_NEXT_SPLIT=0 runs the f32-MFMA form")
-                      if (arch.startswith("next") and os.environ.get("RVDD_NEXT_SPLIT") != "0" and os.environ.get("RVDD_NEXT_FUSED") != "0")
+                      if (arch.startswith("next") and os.environ.get("RVDD_NEXT_SPLIT") != "0")
                       else "f32 throughout (f32 MFMA, f32 VALU)",
         "config": {"workload": f"{config}: {DESCR[config]}" + (f" (run with --frames {T})" if args.frames else ""),
                    "arch": arch, "checkpoint": stem,

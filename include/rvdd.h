@@ -200,9 +200,7 @@ int rvdd_srgb_metrics(rvdd_t* h, const uint8_t* a, const uint8_t* b, int32_t n, 
  *   "fuse_upsample": 0 = UpConv's bilinear x2 upsample runs as its own kernel instead of inside the Winograd patch
  *              load of the conv behind it (default 1; same bits either way).
  *   "graphs":   1 = frame-steps are captured into hipGraphs and replayed (measured slower on ROCm 7.2; off).
- *   "next_fused": 0 = ConvNeXtUnet's ConvBlock (networks/new_unet.py:74-103) as two kernels (depth-wise + LayerNorm,
- *               then the MLP) instead of the one fused kernel: the A/B reference; same results to a few ulp.
- *   "next_split": 0 = the fused ConvBlock multiplies its two 1x1 convs on the f32 matrix pipe (exact-f32 products) instead
+ *   "next_split": 0 = ConvNeXtUnet's ConvBlock (networks/new_unet.py:74-103, one fused kernel) multiplies its two 1x1 convs on the f32 matrix pipe (exact-f32 products) instead
  *               of the F16 pipe with split f32 operands (the default, as "conv_kernel" 0; the A/B reference).  The split
  *               operands are bounded by the block's LayerNorm whatever the frames are; a block whose weights would let
  *               them leave the f16 range (checked at rvdd_finalize_weights) runs the f32 form by itself.
@@ -210,7 +208,7 @@ int rvdd_srgb_metrics(rvdd_t* h, const uint8_t* a, const uint8_t* b, int32_t n, 
  *               (convblock_kernel) instead of as a pipeline over tiles -- depth-wise conv and LayerNorm of the next tile on
  *               four waves beside the MLP of the current one on the other four (convblock_pipe_kernel, the default with
  *               next_split; same bits either way).
- *   "next_pool": 0 = with next_fused, MaxPool2d(2) in front of a DownConv (new_unet.py:200-204) as its own kernel instead
+ *   "next_pool": 0 = MaxPool2d(2) in front of a DownConv (new_unet.py:200-204) as its own kernel instead
  *               of the fused block's epilogue (default 1; same bits either way).
  *   "cout_split": 0 = every launch of the split-f16 conv kernel forms all 48 output channels of a tile in one workgroup.
  *               Default 1: a launch with at most a third of a 16x16 tile per compute unit (the coarse levels of one small

@@ -2,23 +2,23 @@
 //   x -> [proj 1x1 when Cin != 48] -> r = dwconv7x7 -> LayerNorm_C -> 1x1 48->192
 //     -> GELU(erf) -> 1x1 192->48 ; out = x + layerscale * r
 //
-// Three kernels, all NHWC fp32:
-//   proj1x1_kernel  : 1x1 projection (9|6 -> 48 from the padded 16-channel network
-//                     input, or 96 -> 48 from two 48-channel maps = virtual concat)
-//                     on f32 MFMA with the whole weight matrix held in registers.
-//   dwln_kernel     : depth-wise 7x7 (+bias) and the per-pixel channel LayerNorm
-//                     (biased variance, eps 1e-6, :12-28) from an LDS halo tile.
-//   mlp_kernel      : 48->192 (+bias) -> exact GELU -> 192->48 (+bias), layerscale,
-//                     residual.  Both GEMMs run on v_mfma_f32_16x16x4_f32 in the
-//                     orientation D[channel][pixel]; the accumulators of the first
-//                     GEMM (lane = pixel, 4 consecutive hidden channels per register
-//                     quad) ARE the B fragments of the second one, so the 192-channel
-//                     hidden map never leaves the register file (the reference writes
-//                     and re-reads it: 708 MB per block at 720p).
+// Kernels, all NHWC fp32:
+//   proj1x1_kernel        : 1x1 projection (9|6 -> 48 from the padded 16-channel network input, or 96 -> 48 from two
+//                           48-channel maps = virtual concat) on f32 MFMA with the whole weight matrix held in registers
+//                           (levels where the projection halves cannot ride in the blocks' epilogues: odd sizes).
+//   convblock_pipe_kernel : the whole block per 16x16-pixel tile as a two-stage pipeline inside the workgroup (the default):
+//                           depth-wise 7x7 + LayerNorm (biased variance, eps 1e-6, :12-28) of tile t + 1 on four waves beside the
+//                           MLP of tile t on the other four -- both 1x1 convs on the F16 matrix pipe with split f32 operands in the
+//                           orientation D[channel][pixel]: the accumulators of the first GEMM (lane = pixel, 4 consecutive hidden
+//                           channels per register quad) ARE the B fragments of the second one, so the 192-channel hidden map never
+//                           leaves the register file (the reference writes and re-reads it: 708 MB per block at 720p).
+//   convblock_kernel      : the same block with its phases one after the other in all eight waves: SPLIT = false is the
+//                           exact-f32-product form (f32 MFMA; option next_split 0, and blocks whose weights break the split's
+//                           bound), SPLIT = true the same-bits sibling of the pipelined kernel (option next_pipe 0).
+// (The two-kernel form of rounds 1-2, dwln_kernel + mlp_kernel, was retired in round 6; LABBOOK.md 4.3 describes it.)
 //
-// Lane <-> data map shared by all three (the MFMA B-operand map): lane l owns pixel
-// l&15 of its 16-pixel group and, in every 16-channel chunk j, channels 16j+4g..+3
-// with g = l>>4.
+// Lane <-> data map of the MLP (the MFMA B-operand map): lane l owns pixel l&15 of its 16-pixel group and, in every
+// 16-channel chunk j, channels 16j+4g..+3 with g = l>>4.
 #include "rvdd_internal.h"
 
 #include <algorithm>
@@ -101,182 +101,10 @@ constexpr int E_TH = 16, E_TW = 16, E_IH = E_TH + 6, E_PITCH = 24;
 constexpr int E_BUF_FLOATS = E_IH * E_PITCH * 16;          // 8448 floats = 33 KiB: one 16-channel chunk of the halo tile
 constexpr int E_PIECES = E_BUF_FLOATS / 256;                // 33 LDS-DMA pieces of 1 KiB
 constexpr int E_PAR_FLOATS = 3 * kF;                         // dw bias | LayerNorm weight | LayerNorm bias
-constexpr size_t E_LDS_BYTES = (size_t)(D_W_FLOATS + E_PAR_FLOATS + 2 * E_BUF_FLOATS) * 4;
 
-__global__ __launch_bounds__(256, 2) void dwln_kernel(const float* __restrict__ x, const float* __restrict__ dw_w,
-                                                      const float* __restrict__ dw_b, const float* __restrict__ ln_w,
-                                                      const float* __restrict__ ln_b, float* __restrict__ out,
-                                                      int B, int H, int W, int tiles_x, int tiles_y, int ntiles) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* Wl = smem;                        // [49][48]
-    // The three per-channel vectors live in LDS, not in registers (the kernel has none to spare) and not in global
-    // memory: vmcnt counts in order, so a wait for a 16-byte global load issued after a chunk's LDS-DMA is a wait for
-    // the whole chunk -- reloading the bias at the top of a tile and the LayerNorm vectors before the stores
-    // serialised the DMA of the next chunk with this one's arithmetic (the "38 us of overlap" of the phase timings).
-    float* Pl = smem + D_W_FLOATS;           // dw_b | ln_w | ln_b
-    float* Tl = Pl + E_PAR_FLOATS;           // two chunk buffers
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // Persistent workgroups (two per CU).  Blocks that share an XCD (blockIdx & 7 under round-robin placement:
-    // speed only) walk one contiguous band of tiles side by side, so the halo a tile shares with its neighbours
-    // is served by that XCD's L2.
-    const int per_xcd = (ntiles + 7) >> 3;
-    const int band_end = min(((int)(blockIdx.x & 7) + 1) * per_xcd, ntiles);
-    const int stride = (int)(gridDim.x >> 3);
-    int tile = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
-    if (tile >= band_end) return;
-    const int tiles_per_img = tiles_x * tiles_y;
-    struct TilePos { int b, y0, x0; };
-    auto locate = [&](int t) {
-        TilePos p;
-        p.b = t / tiles_per_img;
-        const int rr = t - p.b * tiles_per_img;
-        const int ty = rr / tiles_x;
-        p.y0 = ty * E_TH;
-        p.x0 = (rr - ty * tiles_x) * E_TW;
-        return p;
-    };
+// (dwln_kernel, the depth-wise + LayerNorm kernel of the two-kernel ConvBlock these constants were first written for, was retired in
+// round 6 with mlp_kernel: the fused kernels below share its tile geometry, LDS image and lane map.  LABBOOK.md 4.3.)
 
-    // lane -> (row of the wave's four rows, quad of four pixels, channel group); popcount parity puts the 16
-    // lanes of each ds_read_b128 lane group {0-3,12-15,20-27}, {4-11,16-19,28-31}, ... in one row
-    const int g = lane & 3;
-    const int idx = lane >> 2;
-    const int quad = idx & 3;
-    const int row = wave * 4 + ((idx >> 3) << 1) + (__builtin_popcount(idx & 7) & 1);
-
-    // which halo pixel / channel group each lane fetches for its (at most 9) DMA pieces: fixed for the kernel
-    int piece_yx[9];
-#pragma unroll
-    for (int n = 0; n < 9; ++n) {
-        const int k = wave + 4 * n;
-        const int R = k * 4 + (lane >> 4), sl = lane & 15;
-        const int p = 4 * R + ((sl >> 2) ^ (R & 3));
-        const int iy = p / E_PITCH, ix = p - iy * E_PITCH;
-        piece_yx[n] = (k < E_PIECES && ix < E_TW + 6) ? (iy << 8) | ix : -1;
-    }
-    auto dma_chunk = [&](const TilePos& tp, int j, int buf) {
-        __amdgpu_buffer_rsrc_t ir =
-            __builtin_amdgcn_make_buffer_rsrc((void*)(x + (size_t)tp.b * H * W * kF), 0, H * W * kF * 4, 0x00020000);
-        float* dst = Tl + buf * E_BUF_FLOATS;
-#pragma unroll
-        for (int n = 0; n < 9; ++n) {
-            const int k = wave + 4 * n;
-            if (k < E_PIECES) {
-                const int gy = tp.y0 - 3 + (piece_yx[n] >> 8), gx = tp.x0 - 3 + (piece_yx[n] & 255);
-                const bool ok = piece_yx[n] >= 0 && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
-                dma16(ir, dst + k * 256, ok ? (unsigned)(((gy * W + gx) * kF + 16 * j + 4 * (lane & 3)) * 4) : 0x80000000u);
-            }
-        }
-    };
-    TilePos cur = locate(tile);
-    dma_chunk(cur, 0, 0);
-    for (int q = tid; q < D_W_FLOATS / 4; q += 256)
-        reinterpret_cast<f32x4*>(Wl)[q] = reinterpret_cast<const f32x4*>(dw_w)[q];
-    if (tid < E_PAR_FLOATS) Pl[tid] = tid < kF ? dw_b[tid] : (tid < 2 * kF ? ln_w[tid - kF] : ln_b[tid - 2 * kF]);
-    __syncthreads();                         // the bias is read before the first barrier of the tile loop
-
-    // read addresses: pixel (row + ky, 4 quad + dx) -> R = (row + ky) * 6 + quad + (dx >> 2); float offset =
-    // R * 64 + (((dx & 3) ^ (R & 3)) * 4 + g) * 4.  (R & 3) = (2 row + quad + 2 ky + (dx >> 2)) & 3: sixteen
-    // registers base + swizzle[c][d] for c = (2 ky + (dx >> 2)) & 3, d = dx & 3; the rest is an immediate.
-    const int t0 = (2 * row + quad) & 3;
-    int rd0[4][4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c)
-#pragma unroll
-        for (int d = 0; d < 4; ++d) rd0[c][d] = (row * 6 + quad) * 64 + ((d ^ ((t0 + c) & 3)) * 4 + g) * 4;
-
-    int par = 0;                 // buffer that holds (or receives) the chunk about to be used
-#pragma unroll 1
-    for (;;) {
-        const int next_tile = tile + stride;
-        const bool more = next_tile < band_end;
-        const TilePos nxt = locate(more ? next_tile : tile);
-        f32x4 acc[4][3];
-#pragma unroll
-        for (int j = 0; j < 3; ++j)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) acc[i][j] = *reinterpret_cast<const f32x4*>(Pl + 16 * j + 4 * g);
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();                              // this chunk landed; every wave is done with the other buffer
-            if (j + 1 < 3) dma_chunk(cur, j + 1, par ^ 1);
-            else if (more) dma_chunk(nxt, 0, par ^ 1);    // the next tile's first chunk rides under this tile's last
-            const float* tb = Tl + par * E_BUF_FLOATS;
-            const float* wb = Wl + 16 * j + 4 * g;
-            // rows are software-pipelined: the 17 reads of row ky + 1 are in flight under the 28 float4 FMAs of row ky
-            f32x4 win[2][10], wv[2][7];
-            auto read_row = [&](int ky, f32x4 (&wn)[10], f32x4 (&ww)[7]) {
-#pragma unroll
-                for (int dx = 0; dx < 10; ++dx)
-                    wn[dx] = *reinterpret_cast<const f32x4*>(tb + rd0[(2 * ky + (dx >> 2)) & 3][dx & 3] + ky * 6 * 64 + (dx >> 2) * 64);
-#pragma unroll
-                for (int kx = 0; kx < 7; ++kx) ww[kx] = *reinterpret_cast<const f32x4*>(wb + (ky * 7 + kx) * kF);
-            };
-            read_row(0, win[0], wv[0]);
-#pragma unroll
-            for (int ky = 0; ky < 7; ++ky) {
-                if (ky + 1 < 7) read_row(ky + 1, win[(ky + 1) & 1], wv[(ky + 1) & 1]);
-#pragma unroll
-                for (int kx = 0; kx < 7; ++kx)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) acc[i][j] = acc[i][j] + win[ky & 1][i + kx] * wv[ky & 1][kx];
-                // one filter row at a time: left alone, instruction selection emits the (unchained) FMAs of a chunk
-                // behind ALL of its 119 LDS reads and spills a thousand registers.  The empty asm makes this row's
-                // sums a side effect that is ordered with the reads that follow.
-                asm volatile("" : "+v"(acc[0][j]), "+v"(acc[1][j]), "+v"(acc[2][j]), "+v"(acc[3][j])::"memory");
-            }
-            par ^= 1;
-        }
-        // LayerNorm over the 48 channels of each pixel: 12 here, the rest in lanes l^1, l^2, l^3
-        const int y = cur.y0 + row;
-        f32x4 lw[3], lb[3];
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            lw[j] = *reinterpret_cast<const f32x4*>(Pl + kF + 16 * j + 4 * g);
-            lb[j] = *reinterpret_cast<const f32x4*>(Pl + 2 * kF + 16 * j + 4 * g);
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            float sm = 0.f;
-#pragma unroll
-            for (int j = 0; j < 3; ++j) sm += (acc[i][j][0] + acc[i][j][1]) + (acc[i][j][2] + acc[i][j][3]);
-            sm = lane_xor_add<1>(sm);
-            sm = lane_xor_add<2>(sm);
-            const float u = sm / 48.f;
-            float v2 = 0.f;
-#pragma unroll
-            for (int j = 0; j < 3; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float d = acc[i][j][r] - u;
-                    v2 += d * d;
-                }
-            v2 = lane_xor_add<1>(v2);
-            v2 = lane_xor_add<2>(v2);
-            // (x - u) / sqrt(var + eps) as (x - u) * (1 / sqrt(...)): one correctly rounded division per pixel instead
-            // of twelve per lane (each ~10 instructions); the quotient moves by at most one ulp
-            const float rden = 1.0f / sqrtf(v2 / 48.f + 1e-6f);
-            const int xx = cur.x0 + 4 * quad + i;
-            if (y < H && xx < W) {
-                float* o = out + (((size_t)cur.b * H + y) * W + xx) * kF + 4 * g;
-#pragma unroll
-                for (int j = 0; j < 3; ++j) {
-                    f32x4 r;
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) r[k] = lw[j][k] * ((acc[i][j][k] - u) * rden) + lb[j][k];
-                    *reinterpret_cast<f32x4*>(o + 16 * j) = r;
-                }
-            }
-        }
-        if (!more) break;
-        tile = next_tile;
-        cur = nxt;
-    }
-}
-
-// ---------------------------------------------------------------------- MLP --
 // LDS: fc1 arranged [j(3)][m(12)][lane = 16g+lr][i] = W1[16m+lr][16j+4g+i]     (9216 floats)
 //      fc2 arranged [m(12)][mo(3)][lane = 16g+lr][r] = W2[16mo+lr][16m+4g+r]   (9216 floats)
 //      fc1_b (192) | fc2_b (48) | layerscale (48)
@@ -293,7 +121,6 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // SQ counters (profiles/r02_k_mlp_*): the wave is never idle - MFMA 76 %, GELU 14 %, waits 10 % of its cycles.
 typedef __attribute__((address_space(3))) f32x4 lds_frag;
 constexpr int M2_BV_FLOATS = 192 + 48 + 48;                       // fc1_b | fc2_b | layerscale
-constexpr size_t M2_LDS_BYTES = 84 * 1024;                        // 73.1 KiB used; past half of the CU's 160 KiB = one workgroup per CU
 
 __device__ __forceinline__ f32x4 bload(__amdgpu_buffer_rsrc_t r, unsigned off) {
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
@@ -384,212 +211,6 @@ struct Out3 {
     float* nhwc4;          // [B][hw][4] or null
     int hw;                // pixels per image
 };
-template <int NPB, int NW, bool OUT3>
-__global__ __launch_bounds__(64 * NW, NPB == 2 ? 1 : 8 / NW) void mlp_kernel(const float* __restrict__ ln, const float* __restrict__ x,
-                                                         const float* __restrict__ fc1_w,
-                                                         const float* __restrict__ fc1_b,
-                                                         const float* __restrict__ fc2_w,
-                                                         const float* __restrict__ fc2_b,
-                                                         const float* __restrict__ ls, float* __restrict__ out,
-                                                         long npix, Out3 o3) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* W1 = smem;
-    float* W2 = smem + M_W_FLOATS;
-    float* BV = smem + 2 * M_W_FLOATS;
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int lr = lane & 15, g = lane >> 4;
-    {
-        __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc((void*)fc1_w, 0, M_W_FLOATS * 4, 0x00020000);
-        __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc((void*)fc2_w, 0, M_W_FLOATS * 4, 0x00020000);
-        for (int k = wave; k < M_W_FLOATS / 256; k += NW) {
-            dma16(r1, W1 + k * 256, (unsigned)(k * 1024 + lane * 16));
-            dma16(r2, W2 + k * 256, (unsigned)(k * 1024 + lane * 16));
-        }
-        for (int i = tid; i < M2_BV_FLOATS; i += 64 * NW)
-            BV[i] = i < 192 ? fc1_b[i] : (i < 240 ? fc2_b[i - 192] : ls[i - 240]);
-        if constexpr (OUT3) {
-            for (int i = tid; i < 147; i += 64 * NW) BV[M2_BV_FLOATS + i] = i < 144 ? o3.w[i] : o3.b[i - 144];
-        }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-
-    // lane-linear fragments behind opaque LDS pointers: every read is "register + immediate"
-    lds_frag* w1p = (lds_frag*)W1 + lane;
-    lds_frag* w2p = (lds_frag*)W2 + lane;
-    lds_frag* bvp = (lds_frag*)BV + g;
-    asm volatile("" : "+v"(w1p), "+v"(w2p), "+v"(bvp));
-    auto F1 = [&](int j, int m) { return w1p[(j * 12 + m) * 64]; };
-    auto F2 = [&](int m, int mo) { return w2p[(m * 3 + mo) * 64]; };
-
-    constexpr int GP = 16 * NPB;                                  // pixels per wave iteration
-    const long nblk = (npix + GP - 1) / GP;
-    const long nwaves = (long)gridDim.x * NW;
-    const unsigned lane_off = (unsigned)(lr * (kF * 4) + g * 16);
-    // rows of a map that belong to block `blk`: a descriptor over exactly those pixels (none past the end of the
-    // map: loads return zeros there and stores are dropped), so no offset depends on the size of the map
-    auto rows = [&](const float* base, long blk) {
-        const long first = blk * GP, rem = npix - first;
-        const int recs = rem <= 0 ? 0 : (int)(rem < GP ? rem : GP) * (kF * 4);
-        return __builtin_amdgcn_make_buffer_rsrc((void*)(base + first * kF), 0, recs, 0x00020000);
-    };
-    auto load_rows = [&](f32x4 (&q)[NPB][3], const float* base, long blk) {
-        __amdgpu_buffer_rsrc_t r = rows(base, blk);
-#pragma unroll
-        for (int n = 0; n < NPB; ++n)
-#pragma unroll
-            for (int j = 0; j < 3; ++j) q[n][j] = bload(r, lane_off + (unsigned)(n * 16 * kF * 4 + 64 * j));
-    };
-    auto gelu_pair = [&](f32x4 (&h)[12][NPB], int m) {
-#pragma unroll
-        for (int k = 0; k < 2; ++k)
-#pragma unroll
-            for (int n = 0; n < NPB; ++n) h[m + k][n] = gelu_phi4(h[m + k][n]);
-    };
-
-    long blk = (long)blockIdx.x * NW + wave;
-    f32x4 xc[NPB][3], xn[NPB][3], xr[NPB][3];
-    load_rows(xc, ln, blk);
-    // hipcc's wait-count bookkeeping joins this path with the loop's back edge: rows still in flight here would
-    // become a "wait for all but the newest six" at the top of EVERY iteration, which also waits for the stores of
-    // the iteration before (vmcnt counts loads and stores in order)
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(xc[0][0]), "+v"(xc[0][1]), "+v"(xc[0][2]));
-    // Everything that comes from LDS is read one step before its use, across the phases too: the first fc2
-    // fragments and biases during the last fc1 step, the first fc1 fragments and biases of the NEXT iteration and the
-    // layerscale during the last fc2 step (an exposed ds_read_b128 costs the lone wave ~150 cycles; there were 11).
-    f32x4 wq[2][2], b1n[2];
-    wq[0][0] = F1(0, 0);
-    wq[0][1] = F1(0, 1);
-    b1n[0] = bvp[0];
-    b1n[1] = bvp[4];
-    for (; blk < nblk; blk += nwaves) {
-        load_rows(xn, ln, blk + nwaves);
-        // ---- fc1 (+bias) in 18 steps = (pair of hidden blocks m, m+1) x (input chunk j): two independent
-        // accumulator chains per pixel group
-        f32x4 hid[12][NPB];
-        f32x4 acc[3][NPB];
-        f32x4 vq[2][3];
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int st = 0; st < 18; ++st) {
-            const int m = 2 * (st / 3), j = st % 3;
-            if (j == 0) {
-#pragma unroll
-                for (int n = 0; n < NPB; ++n) {
-                    hid[m][n] = b1n[0];
-                    hid[m + 1][n] = b1n[1];
-                }
-            }
-            if (st + 1 < 18) {
-                wq[(st + 1) & 1][0] = F1((st + 1) % 3, 2 * ((st + 1) / 3));
-                wq[(st + 1) & 1][1] = F1((st + 1) % 3, 2 * ((st + 1) / 3) + 1);
-                if (j == 2) {
-                    b1n[0] = bvp[4 * (m + 2)];
-                    b1n[1] = bvp[4 * (m + 3)];
-                }
-            } else {
-#pragma unroll
-                for (int mo = 0; mo < 3; ++mo) {
-                    vq[0][mo] = F2(0, mo);
-                    const f32x4 b2 = bvp[48 + 4 * mo];
-#pragma unroll
-                    for (int n = 0; n < NPB; ++n) acc[mo][n] = b2;
-                }
-            }
-            if (j == 1 && m >= 2) gelu_pair(hid, m - 2);          // the previous pair, its MFMAs long retired
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int n = 0; n < NPB; ++n) {
-                    hid[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[st & 1][0][i], xc[n][j][i], hid[m][n], 0, 0, 0);
-                    hid[m + 1][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[st & 1][1][i], xc[n][j][i], hid[m + 1][n], 0, 0, 0);
-                }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        // ---- fc2 in 12 steps (hidden block m), three output blocks each: the hidden accumulators are the B
-        // fragments (k-slot g of step (m, r) = hidden channel 16m+4g+r); consecutive MFMAs rotate over the three
-        // output blocks, so none waits for its own predecessor.  The residual rows are requested first; the last
-        // pair's GELU runs after the first hidden block has been consumed.
-        load_rows(xr, x, blk);
-        f32x4 lv[3];
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int m = 0; m < 12; ++m) {
-            if (m + 1 < 12) {
-#pragma unroll
-                for (int mo = 0; mo < 3; ++mo) vq[(m + 1) & 1][mo] = F2(m + 1, mo);
-            } else {
-                wq[0][0] = F1(0, 0);
-                wq[0][1] = F1(0, 1);
-                b1n[0] = bvp[0];
-                b1n[1] = bvp[4];
-#pragma unroll
-                for (int mo = 0; mo < 3; ++mo) lv[mo] = bvp[60 + 4 * mo];
-            }
-            if (m == 1) gelu_pair(hid, 10);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-#pragma unroll
-                for (int n = 0; n < NPB; ++n)
-#pragma unroll
-                    for (int mo = 0; mo < 3; ++mo)
-                        acc[mo][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(vq[m & 1][mo][r], hid[m][n][r], acc[mo][n], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        // ---- out = x + layerscale * r
-        {
-            __amdgpu_buffer_rsrc_t ro = rows(out, blk);
-            float part[NPB][3];
-#pragma unroll
-            for (int n = 0; n < NPB; ++n) part[n][0] = part[n][1] = part[n][2] = 0.f;
-#pragma unroll
-            for (int mo = 0; mo < 3; ++mo)
-#pragma unroll
-                for (int n = 0; n < NPB; ++n) {
-                    const f32x4 v = xr[n][mo] + lv[mo] * acc[mo][n];
-                    bstore(ro, lane_off + (unsigned)(n * 16 * kF * 4 + 64 * mo), v);
-                    if constexpr (OUT3) {
-#pragma unroll
-                        for (int c = 0; c < 3; ++c) {
-                            const f32x4 w = bvp[M2_BV_FLOATS / 4 + c * 12 + 4 * mo];     // w[c][16 mo + 4 g ..]
-                            part[n][c] += (v[0] * w[0] + v[1] * w[1]) + (v[2] * w[2] + v[3] * w[3]);
-                        }
-                    }
-                }
-            if constexpr (OUT3) {
-#pragma unroll
-                for (int n = 0; n < NPB; ++n) {
-                    float t[3];
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) {
-                        float v = part[n][c];
-                        v = lane_xor_add<16>(v);
-                        v = lane_xor_add<32>(v);
-                        t[c] = v + BV[M2_BV_FLOATS + 144 + c];
-                    }
-                    const long pix = (blk * NPB + n) * 16 + lr;
-                    if (g == 0 && pix < npix) {
-                        const long b = pix / o3.hw, p = pix - b * o3.hw;
-                        if (o3.nchw) {
-#pragma unroll
-                            for (int c = 0; c < 3; ++c) o3.nchw[(b * 3 + c) * o3.hw + p] = t[c];
-                        }
-                        if (o3.nhwc4) reinterpret_cast<f32x4*>(o3.nhwc4)[pix] = f32x4{t[0], t[1], t[2], 0.f};
-                    }
-                }
-            }
-        }
-#pragma unroll
-        for (int n = 0; n < NPB; ++n)
-#pragma unroll
-            for (int j = 0; j < 3; ++j) xc[n][j] = xn[n][j];
-    }
-}
-
 // ------------------------------------- the whole ConvBlock in one kernel --
 // convblock_kernel = dwln_kernel's depth-wise phase + LayerNorm, then mlp_kernel's two GEMMs, per 16x16-pixel tile,
 // in ONE persistent workgroup per CU (networks/new_unet.py:74-103).  What the fusion removes:
@@ -1146,7 +767,7 @@ __global__ __launch_bounds__(512, 2) void convblock_kernel(const float* __restri
 }
 
 // convblock_pipe_kernel: convblock_kernel<.., SPLIT = true> as a two-stage pipeline over tiles (option next_pipe).
-// Per-wave stamps of convblock_kernel: waves 4-7 idle through the depth-wise phase and the
+// Per-wave stamps of convblock_kernel (LABBOOK.md section 8): waves 4-7 idle through the depth-wise phase and the
 // LayerNorm, then both waves of a SIMD share its vector port through the MLP phase.  Here waves 0-3 ("front", one per
 // SIMD) run the depth-wise taps and the LayerNorm of tile t+1 while waves 4-7 ("back", one per SIMD) run the MLP of tile
 // t -- all 16 rows, four 16-pixel groups per wave.  Same LDS plan, same arithmetic in the same order per pixel, same bits.
@@ -1708,46 +1329,6 @@ hipError_t launch_proj1x1(const float* in1, int c1, const float* in2, int c2, co
     else
         return hipErrorInvalidValue;
     return hipGetLastError();
-}
-
-hipError_t launch_next_dwln(const float* x, float* ln_out, const NextBlockW& w, int B, int H, int W, hipStream_t s) {
-    if ((size_t)H * W * kF * 4 >= 0x80000000ull) return hipErrorInvalidValue;
-    static std::atomic<uint64_t> attr{0};
-    if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(dwln_kernel), E_LDS_BYTES, attr); e != hipSuccess)
-        return e;
-    const int tx = (W + E_TW - 1) / E_TW, ty = (H + E_TH - 1) / E_TH;
-    const int ntiles = B * tx * ty;
-    // persistent: two workgroups per CU (LDS), never more blocks than tiles; the XCD band map needs a multiple of 8
-    const int grid = ((std::min(ntiles, 2 * num_cus()) + 7) / 8) * 8;
-    hipLaunchKernelGGL(dwln_kernel, dim3(grid), dim3(256), E_LDS_BYTES, s, x, w.dw_w, w.dw_b, w.ln_w, w.ln_b, ln_out, B, H, W,
-                       tx, ty, ntiles);
-    return hipGetLastError();
-}
-
-template <bool OUT3>
-static hipError_t launch_mlp(const float* ln, const float* x, float* out, const NextBlockW& w, int64_t npix, Out3 o3, hipStream_t s) {
-    // one 16-pixel group per wave iteration, eight waves per workgroup: measured against <2, 4> and <1, 4>
-    // (profiles/r02_k_mlp_variants.json)
-    constexpr int NPB = 1, NW = 8;
-    static std::atomic<uint64_t> attr{0};
-    if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(mlp_kernel<NPB, NW, OUT3>), M2_LDS_BYTES, attr); e != hipSuccess)
-        return e;
-    const long nblk = (npix + 16 * NPB - 1) / (16 * NPB);
-    const long blocks = std::min<long>((nblk + NW - 1) / NW, num_cus());
-    hipLaunchKernelGGL((mlp_kernel<NPB, NW, OUT3>), dim3((unsigned)blocks), dim3(64 * NW), M2_LDS_BYTES, s, ln, x, w.fc1_w,
-                       w.fc1_b, w.fc2_w, w.fc2_b, w.ls, out, (long)npix, o3);
-    return hipGetLastError();
-}
-
-hipError_t launch_next_mlp(const float* ln, const float* x, float* out, const NextBlockW& w, int64_t npix, hipStream_t s) {
-    if (npix <= 0) return hipSuccess;
-    return launch_mlp<false>(ln, x, out, w, npix, Out3{}, s);
-}
-
-hipError_t launch_next_mlp_out3(const float* ln, const float* x, float* out, const NextBlockW& w, int64_t npix,
-                                const float* w3x48, const float* b3, float* out_nchw, float* out_nhwc4, int hw, hipStream_t s) {
-    if (npix <= 0) return hipSuccess;
-    return launch_mlp<true>(ln, x, out, w, npix, Out3{w3x48, b3, out_nchw, out_nhwc4, hw}, s);
 }
 
 template <bool OUT3, bool POOL, bool SPLIT>

@@ -146,7 +146,6 @@ struct rvdd_handle {
                                   // operands split as they are, the round-3 behaviour with its 2^-14 .. 65504 domain -- A/B reference only)
     int seq_major = 0;            // 1 = full-resolution stages one sequence at a time (see seq_major_on)
     bool fuse_upsample = true;    // UpConv's bilinear x2 inside the Winograd patch load (RVDD_FUSE_UPSAMPLE=0: separate kernel)
-    bool next_fused = true;       // ConvNeXt ConvBlock as ONE kernel (RVDD_NEXT_FUSED=0 / option "next_fused" 0: dwln + mlp kernels, the A/B reference)
     bool next_split = true;       // ConvNeXt, fused blocks: the two 1x1 convs on the F16 matrix pipe with split f32 operands (RVDD_NEXT_SPLIT=0: f32 MFMA)
     bool next_pipe = true;        // ConvNeXt, fused split-f16 blocks as a front / back pipeline over tiles (convblock_pipe_kernel; RVDD_NEXT_PIPE=0: convblock_kernel's phases)
     bool next_pool = true;        // ConvNeXt, fused blocks: MaxPool2d(2) from the epilogue of the block in front of a DownConv
@@ -949,7 +948,6 @@ int rvdd_create(const rvdd_cfg* cfg, rvdd_t** out) {
     h->cfg = *cfg;
     if (const char* sm = std::getenv("RVDD_SEQ_MAJOR")) h->seq_major = std::atoi(sm) != 0;     // measurement switches
     if (const char* fu = std::getenv("RVDD_FUSE_UPSAMPLE")) h->fuse_upsample = std::atoi(fu) != 0;
-    if (const char* nf = std::getenv("RVDD_NEXT_FUSED")) h->next_fused = std::atoi(nf) != 0;
     if (const char* bf = std::getenv("RVDD_BFP")) h->bfp = std::atoi(bf) != 0;
     if (const char* fp = std::getenv("RVDD_FUSE_PRE")) h->fuse_pre = std::atoi(fp) != 0;
     if (const char* np = std::getenv("RVDD_NEXT_POOL")) h->next_pool = std::atoi(np) != 0;
@@ -1181,11 +1179,6 @@ int rvdd_set_option(rvdd_t* h, const char* name, int32_t value) {
         h->fuse_upsample = value != 0;
         return RVDD_OK;
     }
-    if (std::strcmp(name, "next_fused") == 0) {
-        // 0 = ConvNeXt ConvBlock as two kernels (depth-wise + LayerNorm, then the MLP): A/B reference of convblock_kernel
-        h->next_fused = value != 0;
-        return RVDD_OK;
-    }
     if (std::strcmp(name, "next_split") == 0) {
         // 0 = the fused ConvBlock's two 1x1 convs on the f32 matrix pipe (exact-f32 products: the A/B reference of the split-f16 form)
         h->next_split = value != 0;
@@ -1257,7 +1250,7 @@ int rvdd_set_option(rvdd_t* h, const char* name, int32_t value) {
         h->split16 = value == 0;
         return RVDD_OK;
     }
-    return fail(h, RVDD_ERR_ARG, "rvdd_set_option: unknown option '%s' (known: no_warp, warp_raw, prev_noisy_frame, conv_kernel, seq_major, graphs, fuse_upsample, next_fused, next_split, next_pipe, next_pool, next_projfuse, tvl1_async, block_fp, fuse_pre, cout_split)", name);
+    return fail(h, RVDD_ERR_ARG, "rvdd_set_option: unknown option '%s' (known: no_warp, warp_raw, prev_noisy_frame, conv_kernel, seq_major, graphs, fuse_upsample, next_split, next_pipe, next_pool, next_projfuse, tvl1_async, block_fp, fuse_pre, cout_split)", name);
 }
 
 int rvdd_reset(rvdd_t* h) {

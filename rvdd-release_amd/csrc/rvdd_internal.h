@@ -289,13 +289,6 @@ struct NextProj {
     const float* add;        // NHWC48 map of the block's output size added to the projection (the other half, with the bias), or null
     int inv_e;               // -s: added to a float's exponent field it multiplies by 2^-s
 };
-// one ConvBlock = dwln (x -> LayerNorm(dwconv7x7(x))) then mlp (ln, x -> x + ls * MLP(ln)); x NHWC48
-hipError_t launch_next_dwln(const float* x, float* ln_out, const NextBlockW& w, int B, int H, int W, hipStream_t s);
-hipError_t launch_next_mlp(const float* ln, const float* x, float* out, const NextBlockW& w, int64_t npix, hipStream_t s);
-// the same, and the 1x1 conv 48 -> 3 on the block's output in the epilogue (out_nchw [B][3][hw], out_nhwc4 [B][hw][4];
-// either may be null)
-hipError_t launch_next_mlp_out3(const float* ln, const float* x, float* out, const NextBlockW& w, int64_t npix,
-                                const float* w3x48, const float* b3, float* out_nchw, float* out_nhwc4, int hw, hipStream_t s);
 // the whole ConvBlock in ONE kernel (convblock_kernel): x -> x + ls * MLP(LayerNorm(dwconv7x7(x))); x, out NHWC48
 // [B][H][W], out != x.  _out3: also the 1x1 conv 48 -> 3 on the block's output (out_nchw [B][3][H*W], out_nhwc4
 // [B][H*W][4]; either may be null)

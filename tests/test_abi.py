@@ -53,7 +53,7 @@ def test_library_carries_gfx950_code_object():
     from rvdd_release_amd import _lib
     blob = open(_lib.LIB_PATH, "rb").read()
     assert b"amdgcn-amd-amdhsa--gfx950" in blob
-    assert b"conv3x3_kernel" in blob and b"warp48_kernel" in blob and b"mlp_kernel" in blob
+    assert b"conv3x3_kernel" in blob and b"warp48_kernel" in blob and b"convblock_pipe_kernel" in blob
 
 
 def test_create_validates_arguments():
@@ -107,9 +107,8 @@ def test_no_kernel_spills_to_scratch():
     # carry a frame-step; a handful in the epilogue variants that run once (OUT3: the 1x1 conv 48 -> 3) or three times
     # (the fused ConvBlock's pooling epilogue, split-f16 form) per frame-step, or whose two role branches (the pipelined
     # ConvBlock: front and back waves) each keep their own set of loop invariants
-    hot = ("wino3x3", "conv3x3", "mlp_kernel", "dwln_kernel", "convblock_kernel", "convblock_pipe_kernel", "proj1x1", "warp48", "netin", "ha_")
-    once = ("convblock_kernel<true, false, ", "convblock_kernel<false, true, true>", "convblock_pipe_kernel", "mlp_kernel<1, 8, true>",
-            "mlp_kernel<1, 4, true>", "wino3x3_kernel<4, false>")
+    hot = ("wino3x3", "conv3x3", "convblock_kernel", "convblock_pipe_kernel", "proj1x1", "warp48", "netin", "ha_")
+    once = ("convblock_kernel<true, false, ", "convblock_kernel<false, true, true>", "convblock_pipe_kernel", "wino3x3_kernel<4, false>")
     # conv3x3h_kernel holds two forms of its tile loop since round 4 (with and without the block floating point's scaling,
     # chosen per workgroup): the instantiations with the most loop invariants (second pass of the two-source layers, fused
     # upsample, bottleneck sum, fused 1x1 output, the 16-channel first layer) keep a few of them in lanes of a vector register -- written once at the top

@@ -811,42 +811,6 @@ def test_model_runtime_survives_denoiser_calls_at_other_sizes():
         rt.reset()
 
 
-@pytest.mark.parametrize("arch,stem,fut", [("next+feat", "recurrent-ConvNeXtUnet+feat-future-iso3200", 1),
-                                           ("next", "recurrent-ConvNeXtUnet-iso3200", 0)])
-def test_convblock_one_kernel_equals_two_kernels(arch, stem, fut):
-    """ConvBlock (networks/new_unet.py:74-103) as ONE kernel (depth-wise 7x7, LayerNorm and both 1x1 convs per 16x16
-    tile, the default) against the two-kernel form it replaces (option next_fused = 0): the same operations in the
-    same order up to where hipcc contracts a multiply-add (the LayerNorm scale and the residual are compiled in
-    different surroundings), so equal to a few ulp -- max-abs < 2e-6, parity PSNR > 130 dB -- at sizes with ragged
-    tiles in x and y, levels smaller than a tile, zero-padded decoder levels, batches, and two recurrent steps."""
-    from rvdd_release_amd import synth
-    from rvdd_release_amd.runtime import RvddRuntime
-    if "next-iso3200" not in BUILT:
-        pytest.skip("ConvNeXt path not built")
-    sd = load_weights(stem)
-    for B, H, W in ((1, 16, 16), (3, 22, 130), (2, 130, 22), (1, 50, 66), (2, 72, 104), (1, 256, 256), (2, 180, 320)):
-        T = 3 + fut
-        seqs = [synth.make_sequence(T, H, W, iso=3200, seed=600 + b, device="cuda") for b in range(B)]
-        st = lambda f: torch.stack([f(s) for s in seqs], 0)
-        outs = []
-        for fused in (1, 0):
-            rt = RvddRuntime(arch, fut, B, H, W, 0)
-            rt.set_option("next_fused", fused)
-            rt.load_state_dict(sd)
-            o = []
-            for t in range(1, T - fut):
-                o.append(rt.step(st(lambda s: s.raw[t - 1]) if t == 1 else None, st(lambda s: s.raw[t]),
-                                 st(lambda s: s.raw[t + 1]) if fut else None, st(lambda s: s.flow_prev[t]),
-                                 st(lambda s: s.flow_next[t]) if fut else None).clone())
-            feat = rt.get_state()[1]
-            outs.append((o, feat))
-            rt.close()
-        for a, b in zip(outs[0][0], outs[1][0]):
-            assert (a - b).abs().max() < 2e-6 and parity_psnr(a.cpu(), b.cpu()) > 130.0, (B, H, W, float((a - b).abs().max()))
-        if outs[0][1] is not None:
-            assert (outs[0][1] - outs[1][1]).abs().max() < 1e-5, (B, H, W)
-
-
 @pytest.mark.parametrize("arch,stem,fut,opt", [
     ("convunet+feat", "recurrent-convunet+feat-iso3200", 0, ("conv_kernel", 4)),
     ("convunet", "recurrent-convunet-future-iso3200", 1, ("conv_kernel", 2)),
@@ -1209,22 +1173,3 @@ def test_pooling_epilogue_equals_maxpool_kernel():
         for a, b in zip(outs[0][0], outs[1][0]):
             assert torch.equal(a, b), (B, H, W, float((a - b).abs().max()))
         assert torch.equal(outs[0][1], outs[1][1]), (B, H, W)
-
-
-@pytest.mark.parametrize("name", [n for n in BUILT if ARCH[n].startswith("next")])
-def test_two_kernel_convblock_golden(name, monkeypatch):
-    """The two-kernel ConvBlock (A/B reference of the fused kernel that runs by default, RVDD_NEXT_FUSED=0) on the
-    reference's fixtures."""
-    from rvdd_release_amd.networks import define_net_arch
-    monkeypatch.setenv("RVDD_NEXT_FUSED", "0")
-    stem, fut, _ = VARIANTS[name]
-    g = _npz(f"net_{name}.npz")
-    net = define_net_arch(3 * (2 + fut), 3, NETSTR[ARCH[name]], gpu_ids=[0])
-    net.load_state_dict(load_weights(stem))
-    for tag in ("20x28", "16x24"):
-        fin = g.get(f"feat_in_{tag}")
-        if fin is not None:
-            net.set_rec_features([fin.cuda()])
-        out = net(g[f"x_{tag}"].cuda()).cpu()
-        assert (out - g[f"out_{tag}"]).abs().max() < 1e-4, tag
-

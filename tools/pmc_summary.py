@@ -30,8 +30,6 @@ for k in sorted(f):
     if name.startswith("conv3x3h_kernel<"):      # <CIN, EPI, ACC_IN, UPS, groups, taps>: bench.py names the first four; the 5x5 form by itself
         a = [x.strip() for x in name[len("conv3x3h_kernel<"):-1].split(",")]
         name = "conv5x5h_kernel<16>" if len(a) > 5 and a[5] == "5" else "conv3x3h_kernel<" + ", ".join(a[:4]) + ">"
-    if name.startswith("mlp_kernel"):
-        name = "mlp_kernel"                      # one instantiation; bench.py looks it up by its plain name
     fm = sum(f[k]) / len(f[k])
     wm = sum(w[k]) / len(w[k]) if k in w else 0.0
     out[name] = {"launches": len(f[k]), "FETCH_SIZE_KiB_avg": round(fm, 1), "WRITE_SIZE_KiB_avg": round(wm, 1),

@@ -10,7 +10,6 @@ from rvdd_release_amd.runtime import RvddRuntime
 B, H, W = 4, 720, 1280
 sd = load_file(ROOT + "/weights/recurrent-ConvNeXtUnet+feat-future-iso3200.safetensors")
 rt = RvddRuntime("next+feat", 1, B, H, W, 0)
-rt.set_option("next_fused", 1)
 rt.load_state_dict(sd)
 s = synth.make_sequence(4, H, W, seed=1, device="cuda")
 st = lambda x: torch.stack([x] * B, 0)
