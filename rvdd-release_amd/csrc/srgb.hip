@@ -30,7 +30,7 @@ struct PpipeArgs {
 // x / c for a divisor known at launch time, correctly rounded (bit-identical to the IEEE division the reference
 // performs) in 3 instructions instead of the ~10 of v_div_*: Markstein's sequence with rc = RN(1/c) --
 // q = RN(x*rc); r = x - c*q (exact in an FMA); RN(q + r*rc) = RN(x/c).  Checked against np.float32 division on
-// 16M samples per divisor used here (tools note in DESIGN.md); inputs are finite and far from the subnormal range.
+// 16M samples per divisor used here; inputs are finite and far from the subnormal range.
 __device__ __forceinline__ float div_c(float x, float c, float rc) {
     const float q = x * rc;
     const float r = __builtin_fmaf(-c, q, x);

@@ -2,7 +2,7 @@
 // (libBridge.cpp:44-163 -> 3rdparty/tvl1flow/tvl1flow_lib.c:91-278, 343-472; mask.c; zoom.c;
 // bicubic_interpolation.c), SURVEY.md section 8f rank 1.  Same algorithm, same hard-wired parameters
 // (tau .25, lambda .15, theta .3, zoom .5, 5 warps, <= 300 iterations, epsilon .01), same quirks
-// (listed in DESIGN.md), fp32 with the reference's double-precision islands (Gaussian,
+// (listed in LABBOOK.md 4.4), fp32 with the reference's double-precision islands (Gaussian,
 // bicubic cell, normalisation, hypot).  Compiled with -ffp-contract=off.
 //
 // All maps are planar fp32 [ny][nx].  One scale of the pyramid = ONE persistent cooperative kernel: gradient of I1,
