@@ -3,7 +3,7 @@
 # same build for C2, kernel stats + traffic for C4, power / clock log.  Summaries land in gpurun_out/ (and are copied to profiles/).
 TAG=${1:-r06z}
 mkdir -p gpurun_out
-echo "== bench (driver form)"; timeout -k 10 500 python bench.py 2>gpurun_out/${TAG}_default.err | grep '^{' > gpurun_out/${TAG}_default.json.log; cut -c1-200 gpurun_out/${TAG}_default.json.log
+
 echo "== C2 profile"; bash tools/gpu_profile.sh ${TAG} > gpurun_out/${TAG}_profile.log 2>&1; tail -2 gpurun_out/${TAG}_profile.log | cut -c1-200
 python tools/pmc_summary.py ${TAG} C2 > /dev/null && cp profiles/${TAG}_pmc_traffic.json gpurun_out/${TAG}_c2_pmc_traffic.json
 cp gpurun_out/prof_${TAG}/stats/*/*kernel_stats.csv gpurun_out/${TAG}_c2_kernel_stats.csv
