@@ -20,3 +20,5 @@ rm -rf gpurun_out/sq_${TAG}c4/*/*/*.csv
 echo "== power C4"; bash tools/power_probe.sh C4 > /dev/null 2>&1; mv gpurun_out/power_C4.log gpurun_out/${TAG}_power_C4.log; tail -3 gpurun_out/${TAG}_power_C4.log | cut -c1-200
 echo "== power"; bash tools/power_probe.sh C2 > /dev/null 2>&1; mv gpurun_out/power_C2.log gpurun_out/${TAG}_power_C2.log; tail -3 gpurun_out/${TAG}_power_C2.log
 echo "== C4 bench"; timeout -k 10 300 python bench.py --config C4 --steps 5 --warmup 2 --cpu-frames 4 2>/dev/null | grep '^{' > gpurun_out/${TAG}_C4.json.log; cut -c1-120 gpurun_out/${TAG}_C4.json.log
+# (last: profiles/traffic.json has been re-stamped by the two pmc_summary runs above, so this line quotes this build's traffic)
+echo "== bench (driver form)"; timeout -k 10 500 python bench.py 2>gpurun_out/${TAG}_default.err | grep '^{' > gpurun_out/${TAG}_default.json.log; cut -c1-200 gpurun_out/${TAG}_default.json.log
