@@ -214,6 +214,10 @@ int rvdd_srgb_metrics(rvdd_t* h, const uint8_t* a, const uint8_t* b, int32_t n, 
  *               Default 1: a launch with at most a third of a 16x16 tile per compute unit (the coarse levels of one small
  *               sequence) gives a tile to three workgroups of 16 output channels each -- a third of the filter bank's copy and
  *               of the matrix work per workgroup; same sums in the same order, same bits.  Process-wide.
+ *   "small_prestage": 0 = the pre-stage of a frame-step (bound of the network input, green plane, network input) always as
+ *               its three kernels.  Default 1: a step of at most 1024 tiles of 16x16 pixels without a future frame (a single
+ *               small sequence: the launches there are 5-15 us each, back to back) forms them in one kernel; same bits.
+ *               Process-wide.
  *   "tvl1_async": 1 = rvdd_tvl1flow_batch called without iteration counts enqueues its launches on the stream and returns
  *               (the flows are ready in stream order; nothing is read back, the stream is not synchronised): the form for a
  *               caller that feeds the flows straight into rvdd_step on the same stream (validate.py's --val_flow_from_denoised loop

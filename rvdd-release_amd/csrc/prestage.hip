@@ -33,6 +33,7 @@ struct Cfa {
     }
 };
 
+__device__ __forceinline__ float ha_green_at(const Cfa& c, int y, int x);
 // algo1 (util/Hamilton_Adam_demo.py:123-142)
 // rbs = floats from one sequence's raw frame to the next one's (4hw when dense; more for a channel slice of a wider tensor)
 __global__ void ha_green_kernel(const float* __restrict__ raw, float* __restrict__ green, int n, int h,
@@ -44,6 +45,9 @@ __global__ void ha_green_kernel(const float* __restrict__ raw, float* __restrict
     const int y = (idx / W) % H;
     const int b = idx / ((size_t)W * H);
     Cfa c{raw + (size_t)b * rbs, h, w, H, W};
+    green[idx] = ha_green_at(c, y, x);
+}
+__device__ __forceinline__ float ha_green_at(const Cfa& c, int y, int x) {
     const float cc = c.at(y, x);
     float gval;
     if (((y ^ x) & 1) == 0) {
@@ -64,7 +68,7 @@ __global__ void ha_green_kernel(const float* __restrict__ raw, float* __restrict
         const float sg = signf(CLh - CLv);
         gval = (1.f + sg) * rawv / 2.f + (1.f - sg) * rawh / 2.f;
     }
-    green[idx] = gval;
+    return gval;
 }
 
 // The 3x3 neighbourhood of a pixel in the green plane and in the CFA (replicate padded: coordinates clamped before the lookup),
@@ -450,6 +454,88 @@ __global__ __launch_bounds__(256) void netin_bound_kernel(const float* __restric
     const unsigned e = (bits >> 23) & 0xffu;
     if (e >= 1 && e < 250) bits += 4u << 23;
     amax_commit_block(words, b, blockIdx.x, __uint_as_float(bits), red);
+}
+
+// The three pre-stage launches of a frame-step -- netin_bound_kernel, ha_green_kernel, netin_kernel -- in ONE for small frames without
+// a future frame (round 6: BASELINE's C1 as stated, one 256x256 sequence, is 28 launches of 5-15 us back to back; these three were
+// 14.7 us of ~270).  A block owns a 16x16 tile: the green plane of the 18x18 pixels around it goes to LDS (ha_green_at at the
+// clamped coordinates, i.e. what the green kernel wrote and netin_kernel read back through a clamped index), then netin_pixel's
+// sequence per pixel with the ring's greens from LDS, then netin_bound_kernel's tail: every raw sample of the current frame is some
+// thread's own CFA sample.  Same operations on the same values: same bits as the three kernels.  Only where the launch is small: one
+// atomic per block on the amax words costs 100 us at 28 800 blocks (720p, round 4) -- launch_netin_small refuses above 1024 blocks.
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) void netin_small_kernel(
+    NetinArgs a, float* __restrict__ netin, const unsigned* __restrict__ prev_words, unsigned* __restrict__ words,
+    unsigned* __restrict__ zero_a, size_t zero_na, unsigned* __restrict__ zero_b, size_t zero_nb, int tiles_x) {
+    __shared__ float gs[18][20];
+    __shared__ unsigned red[4];
+    const int H = 2 * a.h, W = 2 * a.w;
+    const int b = blockIdx.y, t = threadIdx.x;
+    const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+    const int y0 = ty * 16, x0 = tx * 16;
+    {   // housekeeping for the step AFTER this one (netin_bound_kernel's)
+        const size_t me = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 256 + t, all = (size_t)gridDim.x * gridDim.y * 256;
+        if (zero_a) for (size_t i = me; i < zero_na; i += all) zero_a[i] = 0u;
+        if (zero_b) for (size_t i = me; i < zero_nb; i += all) zero_b[i] = 0u;
+    }
+    Cfa c{a.raw_cur + (size_t)b * a.rbs, a.h, a.w, H, W};
+    for (int i = t; i < 18 * 18; i += 256) {
+        const int r = i / 18, cc = i - r * 18;
+        gs[r][cc] = ha_green_at(c, clampi(y0 - 1 + r, 0, H - 1), clampi(x0 - 1 + cc, 0, W - 1));
+    }
+    const int ly = t >> 4, lx = t & 15, y = y0 + ly, x = x0 + lx;
+    const bool inside = y < H && x < W;
+    // flow vectors and the CFA ring while the greens are being formed
+    FlowQ fq;
+    Ring q;
+    const bool warp_p = a.flow_prev != nullptr;
+    const f32x4* sp = reinterpret_cast<const f32x4*>(a.prev4) + (size_t)b * H * W;
+    if (inside) {
+        if (warp_p) flow_fetch(a.flow_prev + (size_t)b * a.fbs, a.h, a.w, H, W, y, x, fq);
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                const int yy = clampi(y + dy - 1, 0, H - 1), xx = clampi(x + dx - 1, 0, W - 1);
+                const int st = ((yy & 1) << 1) | (xx & 1);
+                q.site[dy][dx] = st;
+                q.r[dy][dx] = c.raw[((size_t)st * c.h + (yy >> 1)) * c.w + (xx >> 1)];
+            }
+    }
+    __syncthreads();
+    float m = 0.f;
+    if (inside) {
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) q.g[dy][dx] = gs[ly + dy][lx + dx];
+        Taps tp;
+        f32x4 vt[16];
+        f32x4 p;
+        if (warp_p) {
+            float fx, fy;
+            flow_combine(fq, fx, fy);
+            make_taps(fx, fy, x, y, H, W, tp);
+            warp3_gather(sp, tp, W, vt);
+        } else {
+            p = sp[(size_t)y * W + x];
+        }
+        float rb[2];
+        ha_red_blue(q, y, x, rb);
+        const float g0 = q.g[1][1];
+        if (warp_p) p = warp3_sum(tp, vt);
+        f32x4* o = reinterpret_cast<f32x4*>(netin) + ((size_t)b * H * W + (size_t)y * W + x) * 4;
+        o[0] = f32x4{p[0], p[1], p[2], rb[0]};
+        o[1] = f32x4{g0, rb[1], 0.f, 0.f};
+        o[2] = f32x4{0.f, 0.f, 0.f, 0.f};
+        m = fabsf(q.r[1][1]);
+    }
+    if (words) {      // netin_bound_kernel's tail
+        unsigned bits = __float_as_uint(m);
+        if (blockIdx.x == 0 && prev_words && t < kAmaxLines) bits = max(bits, prev_words[(size_t)b * kAmaxSeqWords + t * kAmaxLineWords]);
+        const unsigned e = (bits >> 23) & 0xffu;
+        if (e >= 1 && e < 250) bits += 4u << 23;
+        amax_commit_block(words, b, blockIdx.x, __uint_as_float(bits), red);
+    }
 }
 
 // grid = (ceil(W/32), H, B), 192 threads = 16 PAIRS of horizontally adjacent pixels x 12 float4 chunks.
@@ -959,6 +1045,25 @@ hipError_t launch_netin_bound(const float* raw_a, const float* raw_b, const floa
     nblk = nblk < 1 ? 1 : (nblk > 64 ? 64 : nblk);
     hipLaunchKernelGGL(netin_bound_kernel, dim3(nblk, B), dim3(256), 0, s, raw_a, raw_b, raw_c, n, raw_bstride ? raw_bstride : n,
                        prev_words, words, zero_a, zero_na, zero_b, zero_nb);
+    return hipGetLastError();
+}
+
+bool g_small_prestage = true;      // prestage_set_small: false = the three pre-stage kernels at every size (A/B reference, tests)
+void prestage_set_small(bool on) { g_small_prestage = on; }
+// Can a frame-step of this size take the one-kernel pre-stage (netin_small_kernel)?  No future frame, at most 1024 tiles of 16x16.
+bool netin_small_applies(int B, int h, int w, bool future) {
+    const long tiles = (long)B * ((2 * h + 15) / 16) * ((2 * w + 15) / 16);
+    return g_small_prestage && !future && h >= 1 && w >= 1 && tiles <= 1024;
+}
+hipError_t launch_netin_small(const float* raw_cur, const float* prev4, const float* flow_prev, float* netin, int B, int h, int w,
+                              int64_t raw_bstride, int64_t flow_bstride, const unsigned* prev_words, unsigned* words, hipStream_t s,
+                              unsigned* zero_a, size_t zero_na, unsigned* zero_b, size_t zero_nb) {
+    if (B <= 0 || h <= 0 || w <= 0) return hipSuccess;
+    const int tiles_x = (2 * w + 15) / 16, tiles_y = (2 * h + 15) / 16;
+    const int64_t rbs = raw_bstride ? raw_bstride : (int64_t)4 * h * w, fbs = flow_bstride ? flow_bstride : (int64_t)2 * h * w;
+    const NetinArgs a{raw_cur, nullptr, prev4, flow_prev, nullptr, nullptr, B, h, w, rbs, fbs};
+    hipLaunchKernelGGL(netin_small_kernel, dim3(tiles_x * tiles_y, B), dim3(256), 0, s, a, netin, prev_words, words, zero_a, zero_na,
+                       zero_b, zero_nb, tiles_x);
     return hipGetLastError();
 }
 

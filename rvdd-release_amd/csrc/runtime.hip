@@ -1001,6 +1001,7 @@ int rvdd_create(const rvdd_cfg* cfg, rvdd_t** out) {
     // streams every handle used to create -- made that one's cooperative TV-L1 launches and the kernels behind them 20 % slower
     // (profiles/r05k_online_flow_two_handles.txt)
     if (const char* cs = std::getenv("RVDD_COUT_SPLIT")) conv3x3h_set_cout_split(std::atoi(cs) != 0);      // process-wide A/B switch
+    if (const char* sp = std::getenv("RVDD_SMALL_PRESTAGE")) prestage_set_small(std::atoi(sp) != 0);       // likewise
     if (const char* gv = std::getenv("RVDD_GRAPH")) h->use_graphs = std::atoi(gv) != 0 && graph_stream(h);
     *out = h;
     return RVDD_OK;
@@ -1207,6 +1208,12 @@ int rvdd_set_option(rvdd_t* h, const char* name, int32_t value) {
         conv3x3h_set_cout_split(value != 0);
         return RVDD_OK;
     }
+    if (std::strcmp(name, "small_prestage") == 0) {
+        // 0 = the pre-stage of a frame-step as its three kernels (input bound, green plane, network input) at every size: the A/B
+        // reference of the one-kernel form that small launches without a future frame take (same bits).  Process-wide.
+        prestage_set_small(value != 0);
+        return RVDD_OK;
+    }
     if (std::strcmp(name, "tvl1_async") == 0) {
         // 1 = rvdd_tvl1flow_batch without iteration counts enqueues its launches and returns; its control word is read by the next
         // synchronising call.  0 switches back and reports what is pending now.
@@ -1250,7 +1257,7 @@ int rvdd_set_option(rvdd_t* h, const char* name, int32_t value) {
         h->split16 = value == 0;
         return RVDD_OK;
     }
-    return fail(h, RVDD_ERR_ARG, "rvdd_set_option: unknown option '%s' (known: no_warp, warp_raw, prev_noisy_frame, conv_kernel, seq_major, graphs, fuse_upsample, next_split, next_pipe, next_pool, next_projfuse, tvl1_async, block_fp, fuse_pre, cout_split)", name);
+    return fail(h, RVDD_ERR_ARG, "rvdd_set_option: unknown option '%s' (known: no_warp, warp_raw, prev_noisy_frame, conv_kernel, seq_major, graphs, fuse_upsample, next_split, next_pipe, next_pool, next_projfuse, tvl1_async, block_fp, fuse_pre, cout_split, small_prestage)", name);
 }
 
 int rvdd_reset(rvdd_t* h) {
@@ -1325,6 +1332,15 @@ int run_prologue(rvdd_t* h, const StepInputs& in, Sub sb, hipStream_t s) {
             HIPCHK(h, launch_demosaic(rn_, green, next4, n, H / 2, W / 2, (int64_t)H * W * 4, 4, 1, s, (int64_t)in.rawf));
         }
         Scope sc(h, s, "netin(ha_green+netin_kernel)", 0.0, (double)n * img * (16.0 + 16.0 + 48.0 + (next4 ? 16.0 : 0.0)));
+        // small frames without a future frame (not the first step of a video, whose bound also covers the previous raw frame): the
+        // bound, the green plane and the network input in ONE launch
+        if (!h->is_next() && !in.raw_prev && !h->prev_noisy && netin_small_applies(n, H / 2, W / 2, h->cfg.future != 0)) {
+            h->netin_proj = false;
+            HIPCHK(h, launch_netin_small(rc_, h->lastden4 + o * img * 4, fp_, netin, n, H / 2, W / 2, (int64_t)in.rawf, (int64_t)in.flowf,
+                                         amax_netin ? amax_words(h, h->amax_feat_in, o) : nullptr, amax_netin, s,
+                                         zero_now ? zero_a : nullptr, zero_na, zero_now ? zero_b : nullptr, zero_nb));
+            goto prologue_features;
+        }
         if (amax_netin) {
             // (block floating point) a bound of max |netin| from the raw frames and from the words PostConvs wrote last step;
             // with --prev_noisy_frame the "previous output" is a demosaicked frame whose raw data is gone: its own maximum
@@ -1341,6 +1357,7 @@ int run_prologue(rvdd_t* h, const StepInputs& in, Sub sb, hipStream_t s) {
                                (int64_t)in.flowf, first ? first->w.proj_w : nullptr, first ? first->w.proj_b : nullptr,
                                first ? h->lv[0].t[0] + o * img * kF : nullptr));
     }
+prologue_features:
     if (h->has_feat() && !nw) {
         h->featw_proj = next_pf_pre(h);
         Scope sc(h, s, "warp48_kernel", h->featw_proj ? 2.0 * 48 * 48 * n * img : 0.0, (double)n * img * (384.0 + 2.0));

@@ -286,6 +286,42 @@ def test_fused_upsample_equals_upsample_then_conv(B, H, W, conv):
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("arch,stem,B,H,W", [("convunet", "recurrent-convunet-iso3200", 1, 256, 256),
+                                              ("convunet+feat", "recurrent-convunet+feat-iso3200", 2, 50, 66),
+                                              ("convunet", "recurrent-convunet-iso3200", 3, 18, 34),
+                                              ("convunet+feat", "recurrent-convunet+feat-iso3200", 1, 136, 248)])
+def test_one_kernel_prestage_equals_three_kernels(arch, stem, B, H, W):
+    """The pre-stage of a small frame-step without a future frame (bound of the network input, green plane, network input) in
+    ONE kernel (prestage.hip netin_small_kernel, option small_prestage, the default where it applies) against its three
+    kernels: same bits in frames and recurrent features over four steps (the first step of a video always takes the three
+    kernels: its bound also covers the previous raw frame), ragged tiles, clamped borders, flows pointing outside, a frame
+    1e4 times brighter (the bound's words steer the block floating point of the convs behind it)."""
+    from rvdd_release_amd import synth
+    from rvdd_release_amd.runtime import RvddRuntime
+    sd = load_weights(stem)
+    seqs = [synth.make_sequence(6, H, W, iso=3200, seed=700 + b, device="cuda") for b in range(B)]
+    for scale in (1.0, 1e4):
+        outs = []
+        for small in (1, 0):
+            rt = RvddRuntime(arch, 0, B, H, W, 0)
+            rt.set_option("small_prestage", small)
+            rt.load_state_dict(sd)
+            st = lambda f: torch.stack([f(s) for s in seqs], 0)
+            o = []
+            for t in range(1, 5):
+                fl = st(lambda s: s.flow_prev[t]).clone()
+                fl[:, :, :, -3:] += 200.0
+                o.append(rt.step(st(lambda s: s.raw[t - 1]) * scale if t == 1 else None, st(lambda s: s.raw[t]) * scale, None, fl, None).clone())
+            feat = rt.get_state()[1]
+            o.append(feat.clone() if feat is not None else torch.zeros(1, device="cuda"))
+            outs.append(o)
+            rt.set_option("small_prestage", 1)
+            rt.close()
+        for a, b in zip(*outs):
+            assert torch.equal(a, b), (scale, float((a - b).abs().max()))
+        assert torch.isfinite(outs[0][3]).all()
+
+
 def test_step_on_channel_slices_without_copies():
     """rvdd_step_strided: the model hands the runtime `n[:, 0:4]`, `n[:, 4:8]`, `n[:, 8:12]` and `flow[:, k]` of the
     dataset's tensors; with B > 1 those are strided over the batch.  Same bits as the dense call, and no copy."""
