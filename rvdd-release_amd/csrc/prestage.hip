@@ -464,8 +464,8 @@ __global__ __launch_bounds__(256) void netin_bound_kernel(const float* __restric
 // thread's own CFA sample.  Same operations on the same values: same bits as the three kernels.  Only where the launch is small: one
 // atomic per block on the amax words costs 100 us at 28 800 blocks (720p, round 4) -- launch_netin_small refuses above 1024 blocks.
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) void netin_small_kernel(
-    NetinArgs a, float* __restrict__ netin, const unsigned* __restrict__ prev_words, unsigned* __restrict__ words,
-    unsigned* __restrict__ zero_a, size_t zero_na, unsigned* __restrict__ zero_b, size_t zero_nb, int tiles_x) {
+    NetinArgs a, float* __restrict__ netin, const float* __restrict__ raw_prev, const unsigned* __restrict__ prev_words,
+    unsigned* __restrict__ words, unsigned* __restrict__ zero_a, size_t zero_na, unsigned* __restrict__ zero_b, size_t zero_nb, int tiles_x) {
     __shared__ float gs[18][20];
     __shared__ unsigned red[4];
     const int H = 2 * a.h, W = 2 * a.w;
@@ -528,6 +528,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
         o[1] = f32x4{g0, rb[1], 0.f, 0.f};
         o[2] = f32x4{0.f, 0.f, 0.f, 0.f};
         m = fabsf(q.r[1][1]);
+        // (the first step of a video: the "previous output" is the demosaic of the previous raw frame, whose samples bound it)
+        if (raw_prev) m = fmaxf(m, fabsf(raw_prev[(size_t)b * a.rbs + ((size_t)q.site[1][1] * c.h + (y >> 1)) * c.w + (x >> 1)]));
     }
     if (words) {      // netin_bound_kernel's tail
         unsigned bits = __float_as_uint(m);
@@ -1055,15 +1057,15 @@ bool netin_small_applies(int B, int h, int w, bool future) {
     const long tiles = (long)B * ((2 * h + 15) / 16) * ((2 * w + 15) / 16);
     return g_small_prestage && !future && h >= 1 && w >= 1 && tiles <= 1024;
 }
-hipError_t launch_netin_small(const float* raw_cur, const float* prev4, const float* flow_prev, float* netin, int B, int h, int w,
-                              int64_t raw_bstride, int64_t flow_bstride, const unsigned* prev_words, unsigned* words, hipStream_t s,
-                              unsigned* zero_a, size_t zero_na, unsigned* zero_b, size_t zero_nb) {
+hipError_t launch_netin_small(const float* raw_cur, const float* raw_prev, const float* prev4, const float* flow_prev, float* netin, int B,
+                              int h, int w, int64_t raw_bstride, int64_t flow_bstride, const unsigned* prev_words, unsigned* words,
+                              hipStream_t s, unsigned* zero_a, size_t zero_na, unsigned* zero_b, size_t zero_nb) {
     if (B <= 0 || h <= 0 || w <= 0) return hipSuccess;
     const int tiles_x = (2 * w + 15) / 16, tiles_y = (2 * h + 15) / 16;
     const int64_t rbs = raw_bstride ? raw_bstride : (int64_t)4 * h * w, fbs = flow_bstride ? flow_bstride : (int64_t)2 * h * w;
     const NetinArgs a{raw_cur, nullptr, prev4, flow_prev, nullptr, nullptr, B, h, w, rbs, fbs};
-    hipLaunchKernelGGL(netin_small_kernel, dim3(tiles_x * tiles_y, B), dim3(256), 0, s, a, netin, prev_words, words, zero_a, zero_na,
-                       zero_b, zero_nb, tiles_x);
+    hipLaunchKernelGGL(netin_small_kernel, dim3(tiles_x * tiles_y, B), dim3(256), 0, s, a, netin, raw_prev, prev_words, words, zero_a,
+                       zero_na, zero_b, zero_nb, tiles_x);
     return hipGetLastError();
 }
 

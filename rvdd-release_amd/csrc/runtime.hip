@@ -1332,12 +1332,12 @@ int run_prologue(rvdd_t* h, const StepInputs& in, Sub sb, hipStream_t s) {
             HIPCHK(h, launch_demosaic(rn_, green, next4, n, H / 2, W / 2, (int64_t)H * W * 4, 4, 1, s, (int64_t)in.rawf));
         }
         Scope sc(h, s, "netin(ha_green+netin_kernel)", 0.0, (double)n * img * (16.0 + 16.0 + 48.0 + (next4 ? 16.0 : 0.0)));
-        // small frames without a future frame (not the first step of a video, whose bound also covers the previous raw frame): the
-        // bound, the green plane and the network input in ONE launch
-        if (!h->is_next() && !in.raw_prev && !h->prev_noisy && netin_small_applies(n, H / 2, W / 2, h->cfg.future != 0)) {
+        // small frames without a future frame: the bound, the green plane and the network input in ONE launch
+        if (!h->is_next() && !h->prev_noisy && netin_small_applies(n, H / 2, W / 2, h->cfg.future != 0)) {
             h->netin_proj = false;
-            HIPCHK(h, launch_netin_small(rc_, h->lastden4 + o * img * 4, fp_, netin, n, H / 2, W / 2, (int64_t)in.rawf, (int64_t)in.flowf,
-                                         amax_netin ? amax_words(h, h->amax_feat_in, o) : nullptr, amax_netin, s,
+            const float* rp_ = in.raw_prev ? in.raw_prev + o * in.rawf : nullptr;
+            HIPCHK(h, launch_netin_small(rc_, rp_, h->lastden4 + o * img * 4, fp_, netin, n, H / 2, W / 2, (int64_t)in.rawf, (int64_t)in.flowf,
+                                         amax_netin && !in.raw_prev ? amax_words(h, h->amax_feat_in, o) : nullptr, amax_netin, s,
                                          zero_now ? zero_a : nullptr, zero_na, zero_now ? zero_b : nullptr, zero_nb));
             goto prologue_features;
         }

@@ -229,9 +229,10 @@ hipError_t launch_netin_bound(const float* raw_a, const float* raw_b, const floa
 // src NHWC48 -> dst NHWC48.
 // the three pre-stage kernels of a small frame-step without a future frame in one launch (prestage.hip netin_small_kernel); same bits
 bool netin_small_applies(int B, int h, int w, bool future);
-hipError_t launch_netin_small(const float* raw_cur, const float* prev4, const float* flow_prev, float* netin, int B, int h, int w,
-                              int64_t raw_bstride, int64_t flow_bstride, const unsigned* prev_words, unsigned* words, hipStream_t s,
-                              unsigned* zero_a, size_t zero_na, unsigned* zero_b, size_t zero_nb);
+// (raw_prev: the first step of a video, whose bound also covers the previous raw frame -- prev_words is null then)
+hipError_t launch_netin_small(const float* raw_cur, const float* raw_prev, const float* prev4, const float* flow_prev, float* netin, int B,
+                              int h, int w, int64_t raw_bstride, int64_t flow_bstride, const unsigned* prev_words, unsigned* words,
+                              hipStream_t s, unsigned* zero_a, size_t zero_na, unsigned* zero_b, size_t zero_nb);
 void prestage_set_small(bool on);      // false: never; process-wide
 hipError_t launch_warp48(const float* src, const float* flow_raw, float* dst, int B, int H, int W,
                          hipStream_t s, int64_t flow_bstride = 0);

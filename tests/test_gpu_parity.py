@@ -293,8 +293,8 @@ def test_fused_upsample_equals_upsample_then_conv(B, H, W, conv):
 def test_one_kernel_prestage_equals_three_kernels(arch, stem, B, H, W):
     """The pre-stage of a small frame-step without a future frame (bound of the network input, green plane, network input) in
     ONE kernel (prestage.hip netin_small_kernel, option small_prestage, the default where it applies) against its three
-    kernels: same bits in frames and recurrent features over four steps (the first step of a video always takes the three
-    kernels: its bound also covers the previous raw frame), ragged tiles, clamped borders, flows pointing outside, a frame
+    kernels: same bits in frames and recurrent features over four steps (the first, whose bound also covers the previous raw
+    frame, included), ragged tiles, clamped borders, flows pointing outside, a frame
     1e4 times brighter (the bound's words steer the block floating point of the convs behind it)."""
     from rvdd_release_amd import synth
     from rvdd_release_amd.runtime import RvddRuntime
