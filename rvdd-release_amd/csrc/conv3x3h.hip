@@ -160,6 +160,12 @@ template <int CIN, int EPI, bool ACC_IN, bool UPS = false, int NGRP = 2, int KS 
 __global__ __launch_bounds__(NTHREADS) void conv3x3h_kernel(ConvArgs a) {
     using G = HGeo<CIN, NGRP, KS, MT>;
     static_assert(MT == 3 || (MT == 1 && EPI != EPI_RELU_OUT3 && NGRP == 1), "the 1x1 output needs all 48 channels of a pixel");
+#ifdef RVDD_UPS_PAD      // diagnostic builds (tools/ups_layout_matrix.sh): the fused-upsample kernel's code moved by 4 x RVDD_UPS_PAD bytes
+    if constexpr (UPS) {
+#pragma unroll
+        for (int i = 0; i < RVDD_UPS_PAD; ++i) asm volatile("s_nop 0");
+    }
+#endif
     const int mt0 = MT == 3 ? 0 : (int)blockIdx.y;      // first 16-channel output block of this workgroup
     constexpr int TH = G::TH, IH = G::IH, IW = G::IW, PAD = G::PAD;
     static_assert(KS == 3 || (!UPS && !ACC_IN), "the 5x5 form exists for the composed first layer only");
@@ -324,8 +330,22 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3h_kernel(ConvArgs a) {
     auto U_PART = [&](int r0) { return (u_pk[r0] >> 16) & 0xff; };
     auto U_OK = [&](int r0) { return (u_pk[r0] >> 24) != 0; };
     f32x4 ulo[UNR][4];                 // source pixels (row 0 col 0, row 0 col 1, row 1 col 0, row 1 col 1)
-    float u_ly[UNR][2], u_lx[UNR][2];  // weight of the second source row / column per block row / column; < 0: outside the map
     u32x2 ushi[UNR][4], uslo[UNR][4];
+    // The weights of a border tile's item -- of the second source row / column per block row / column, < 0: outside the map -- are formed
+    // where they are used, in the interpolation, NOT kept from the fetch four chunks earlier.  Kept, they were the one state of this loop
+    // that an interior tile leaves unwritten (it needs none), i.e. loop-carried registers whose value nobody wants on most trips; builds
+    // with that shape staged wrong pixels in the first trip of the loop, rarely, and only when the kernel's code was not in the
+    // instruction cache yet (profiles/r06s_upsample_nondeterminism.md: found by a run-to-run soak, every build without such registers is
+    // clean at every code alignment tried).  Every register of this loop is now written in full on every path before it is read.
+    auto ups_weights = [&](const Src& q, int r0, float (&ly)[2], float (&lx)[2]) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int Y = q.y0 - 1 + 2 * U_BY(r0) + e, X = q.x0 - 1 + 2 * U_BX(r0) + e;
+            const float py = fmaxf(0.5f * ((float)Y + 0.5f) - 0.5f, 0.f), px = fmaxf(0.5f * ((float)X + 0.5f) - 0.5f, 0.f);
+            ly[e] = (unsigned)Y < (unsigned)a.H ? py - (float)(int)py : -1.f;
+            lx[e] = (unsigned)X < (unsigned)a.W ? px - (float)(int)px : -1.f;
+        }
+    };
     // INTERIOR tiles (the halo and the source rows / columns it interpolates between all inside the map: 93 % of a 720p level's tiles):
     // no clamp acts and no weight depends on the tile -- an item's four source pieces sit at a thread constant plus a wave-uniform
     // offset (scalar operand of the load, the column step in the instruction's immediate), the weights are 1/4 and 3/4.  No address
@@ -349,14 +369,10 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3h_kernel(ConvArgs a) {
         const int i = (q.y0 >> 1) - 1 + U_BY(r0), jx = (q.x0 >> 1) - 1 + U_BX(r0);
         const int rr0 = min(max(i, 0), ih - 1), cc0 = min(max(jx, 0), iw - 1);
         const int rr1 = rr0 + (rr0 < ih - 1 ? 1 : 0), cc1 = cc0 + (cc0 < iw - 1 ? 1 : 0);
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            const int Y = q.y0 - 1 + 2 * U_BY(r0) + e, X = q.x0 - 1 + 2 * U_BX(r0) + e;
-            const float py = fmaxf(0.5f * ((float)Y + 0.5f) - 0.5f, 0.f), px = fmaxf(0.5f * ((float)X + 0.5f) - 0.5f, 0.f);
-            u_ly[r0][e] = (unsigned)Y < (unsigned)a.H ? py - (float)(int)py : -1.f;
-            u_lx[r0][e] = (unsigned)X < (unsigned)a.W ? px - (float)(int)px : -1.f;
-        }
-        const bool any = U_OK(r0) && (u_ly[r0][0] >= 0.f || u_ly[r0][1] >= 0.f) && (u_lx[r0][0] >= 0.f || u_lx[r0][1] >= 0.f);
+        // (a block with no pixel inside the map is not fetched)
+        const int Y0 = q.y0 - 1 + 2 * U_BY(r0), X0 = q.x0 - 1 + 2 * U_BX(r0);
+        const bool any = U_OK(r0) && ((unsigned)Y0 < (unsigned)a.H || (unsigned)(Y0 + 1) < (unsigned)a.H) &&
+                         ((unsigned)X0 < (unsigned)a.W || (unsigned)(X0 + 1) < (unsigned)a.W);
         const unsigned p16 = (unsigned)(U_PART(r0) * 16);
         ulo[r0][0] = bload(q.r, any ? (unsigned)((rr0 * iw + cc0) * (CIN * 4)) + p16 : 0x80000000u);
         ulo[r0][1] = bload(q.r, any ? (unsigned)((rr0 * iw + cc1) * (CIN * 4)) + p16 : 0x80000000u);
@@ -380,13 +396,15 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3h_kernel(ConvArgs a) {
             }
             return;
         }
+        float u_ly[2], u_lx[2];
+        ups_weights(q, r0, u_ly, u_lx);
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
-            const float ly1 = u_ly[r0][e], ly0 = 1.f - ly1;
+            const float ly1 = u_ly[e], ly0 = 1.f - ly1;
             const f32x4 c0 = fma4(ulo[r0][2], ly1, ulo[r0][0] * ly0), c1 = fma4(ulo[r0][3], ly1, ulo[r0][1] * ly0);
 #pragma unroll
             for (int f = 0; f < 2; ++f) {
-                const float lx1 = u_lx[r0][f], lx0 = 1.f - lx1;
+                const float lx1 = u_lx[f], lx0 = 1.f - lx1;
                 const f32x4 v = fma4(c1, lx1, c0 * lx0);
                 split4<SC_>((ly1 < 0.f || lx1 < 0.f) ? f32x4{0.f, 0.f, 0.f, 0.f} : v, sc_st, ushi[r0][2 * e + f], uslo[r0][2 * e + f]);
             }

@@ -108,6 +108,38 @@ def test_whole_sequence_vs_oracle(cfg, arch, stem, fut, iso, T):
     rt.close()
 
 
+def test_fused_upsample_at_bench_size_over_a_sequence():
+    """UpConv's fused upsample against the two-kernel form at the BENCH shape (8 sequences of 1280x720, 12 frames): every frame and the
+    recurrent features bit for bit.  The small shapes of test_fused_upsample_equals_upsample_then_conv give every workgroup of the conv one
+    tile; round 6 had a build whose workgroups staged wrong pixels in the first trip of their tile loop when the tile fetched there was a
+    border tile -- only a launch with several tiles per workgroup shows that (profiles/r06s_upsample_nondeterminism.md; the rare form of
+    the same defect takes tools/determinism_soak.py)."""
+    from rvdd_release_amd import synth
+    from rvdd_release_amd.runtime import RvddRuntime
+    sd = load_weights("recurrent-convunet+feat-iso3200")
+    B, H, W, T = 8, 720, 1280, 12
+    seqs = [synth.make_sequence(T, H, W, iso=3200, seed=6100 + b, device="cuda") for b in range(B)]
+    raw = torch.stack([s.raw for s in seqs], 1)
+    fl = torch.stack([s.flow_prev for s in seqs], 1)
+    del seqs
+    res = []
+    for fused in (1, 0):
+        rt = RvddRuntime("convunet+feat", 0, B, H, W, 0)
+        rt.set_option("fuse_upsample", fused)
+        rt.load_state_dict(sd)
+        outs = torch.empty(T - 1, B, 3, H, W, device="cuda")
+        for t in range(1, T):
+            rt.step(raw[0] if t == 1 else None, raw[t], None, fl[t], None, out=outs[t - 1])
+        res.append((outs, rt.get_state()[1].clone()))
+        rt.close()
+    (a, fa), (b, fb) = res
+    if not torch.equal(a, b):
+        d = (a - b).abs()
+        bad = [(t, s, int((d[t, s] > 0).sum()), float(d[t, s].max())) for t in range(T - 1) for s in range(B) if bool((d[t, s] > 0).any())]
+        raise AssertionError(f"fused and two-kernel upsample differ in {len(bad)} (frame, slot) pairs, first {bad[:4]}")
+    assert torch.equal(fa, fb)
+
+
 def test_c5_share_720p_ninety_frames():
     """The per-GPU share of BASELINE config C5 at its real size: 8 sequences x 90 frames of 1280x720 in lockstep.
     * run to run: every one of the 8 x 89 output frames identical;
