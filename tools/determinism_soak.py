@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Run-to-run determinism soak: the same B sequences of T frames through one runtime REPS times, every repetition compared bit for bit
 with the first (frames and recurrent features).  Reports every repetition that differs: first frame / slot, element count, rows, columns.
-usage (GPU box): python tools/determinism_soak.py [config C2|C3|C4] [REPS] [T]      -> one JSON line"""
+usage (GPU box): python tools/determinism_soak.py [config C1|C2|C3|C4] [REPS] [T] [B]      -> one JSON line
+(B = 1 with C1 is the shape that takes the one-kernel pre-stage and the output-channel split of the convs)"""
 import json
 import os
 import sys
@@ -17,6 +18,7 @@ cfg = sys.argv[1] if len(sys.argv) > 1 else "C2"
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 30
 arch, stem, fut, iso, H, W, T, B, _ = bench.CONFIGS[cfg]
 T = int(sys.argv[3]) if len(sys.argv) > 3 else 12
+B = int(sys.argv[4]) if len(sys.argv) > 4 else B
 sd = load_file(os.path.join(bench.REPO, "weights", stem + ".safetensors"))
 seqs = [synth.make_sequence(T, H, W, iso=iso, seed=4000 + b, device="cuda") for b in range(B)]
 raw = torch.stack([s.raw for s in seqs], 1).contiguous()
