@@ -140,6 +140,31 @@ def test_fused_upsample_at_bench_size_over_a_sequence():
     assert torch.equal(fa, fb)
 
 
+def test_c1_one_sequence_run_to_run():
+    """BASELINE's C1 as it states it -- ONE 256x256 sequence -- takes launches no batch of eight takes (the one-kernel pre-stage, the
+    output-channel split of the small conv launches): 40 repetitions of a 30-frame sequence through one runtime, all identical."""
+    from rvdd_release_amd import synth
+    from rvdd_release_amd.runtime import RvddRuntime
+    sd = load_weights("recurrent-convunet-iso3200")
+    H = W = 256
+    T = 30
+    s = synth.make_sequence(T, H, W, iso=3200, seed=6200, device="cuda")
+    rt = RvddRuntime("convunet", 0, 1, H, W, 0)
+    rt.load_state_dict(sd)
+
+    def run():
+        rt.reset()
+        outs = torch.empty(T - 1, 1, 3, H, W, device="cuda")
+        for t in range(1, T):
+            rt.step(s.raw[0][None] if t == 1 else None, s.raw[t][None], None, s.flow_prev[t][None], None, out=outs[t - 1])
+        return outs
+
+    ref = run()
+    for rep in range(40):
+        assert torch.equal(run(), ref), rep
+    rt.close()
+
+
 def test_c5_share_720p_ninety_frames():
     """The per-GPU share of BASELINE config C5 at its real size: 8 sequences x 90 frames of 1280x720 in lockstep.
     * run to run: every one of the 8 x 89 output frames identical;
